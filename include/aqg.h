@@ -1,0 +1,227 @@
+/*
+ * aqg.h -- C-ABI of the MI355X (gfx950) AQuery execution library.
+ *
+ * This is the drop-in boundary for the column-batch hot path of the AQuery
+ * "AQuery Library" headers (reference: server/vector_type.hpp, server/table.h,
+ * server/aggregations.h, server/hasher.h).  Everything above this header is
+ * host C++ (include/aquery/ *.h mirror the reference's header-level API);
+ * everything below it is hand-written HIP for CDNA4.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types cross this boundary.
+ *   - every column pointer is a DEVICE pointer (HBM) unless the parameter is
+ *     documented "host".  Sizes are uint32_t like the reference
+ *     (server/vector_type.hpp:66: `uint32_t size, capacity`).
+ *   - dtype tags are the reference's own (server/aquery_types.h:1-5).
+ *   - every entry point returns an int status (0 = AQG_OK).  The reference has
+ *     no error channel on this path; a non-zero status here means
+ *     "nothing was written, caller may fall back".
+ *   - kernels are enqueued on the context's HIP stream.  Entry points that
+ *     return a host value synchronise that stream before returning; all others
+ *     are asynchronous (call aqg_sync).
+ *   - __int128 results (reference: types::GetLongType, server/types.h:205-210)
+ *     are written as 16-byte little-endian two's complement.
+ */
+#ifndef AQG_H
+#define AQG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- dtype tags: reference server/aquery_types.h:1-5 (same order) -------- */
+typedef enum aqg_dtype {
+    AQG_INT32 = 0, AQG_FLOAT = 1, AQG_STR = 2, AQG_DOUBLE = 3, AQG_LDOUBLE = 4,
+    AQG_INT64 = 5, AQG_INT128 = 6, AQG_INT16 = 7, AQG_DATE = 8, AQG_TIME = 9,
+    AQG_INT8 = 10, AQG_UINT32 = 11, AQG_UINT64 = 12, AQG_UINT128 = 13,
+    AQG_UINT16 = 14, AQG_UINT8 = 15, AQG_BOOL = 16, AQG_VECTOR = 17,
+    AQG_TIMESTAMP = 18, AQG_CHAR = 19, AQG_SV = 20, AQG_NONE = 21, AQG_ERROR = 22
+} aqg_dtype;
+
+/* ---- status codes --------------------------------------------------------- */
+enum {
+    AQG_OK = 0,
+    AQG_ERR_HIP = 1,       /* a HIP runtime call failed (see aqg_last_error)  */
+    AQG_ERR_DTYPE = 2,     /* dtype / op combination not implemented on device */
+    AQG_ERR_ARG = 3,       /* bad argument                                     */
+    AQG_ERR_NOMEM = 4,     /* device allocation failed                         */
+    AQG_ERR_NODEVICE = 5,  /* no gfx950 device visible                         */
+    AQG_ERR_OVERFLOW = 6   /* table / workspace capacity exceeded              */
+};
+
+typedef struct aqg_ctx aqg_ctx;
+
+/* ---- type rules (host, pure) ----------------------------------------------
+ * Replace the reference's compile-time type functions so that every caller
+ * (templates, tests, other languages) derives result dtypes the same way.   */
+size_t aqg_dtype_size(int dt);           /* types::AType_sizes, server/types.h:192-193 */
+int aqg_long_type(int dt);               /* types::GetLongType, server/types.h:205-210 */
+int aqg_fp_type(int dt);                 /* types::GetFPType,   server/types.h:199-204 */
+int aqg_coercion(int dt1, int dt2);      /* types::Coercion,    server/types.h:264-275 */
+
+/* ---- context / stream / memory --------------------------------------------
+ * One context per (process, GPU).  `stream` may be an existing hipStream_t
+ * (e.g. torch's current stream) or NULL to let the library create its own.   */
+int aqg_device_count(void);
+int aqg_ctx_create(int device, void* hip_stream, aqg_ctx** out);
+void aqg_ctx_destroy(aqg_ctx* ctx);
+const char* aqg_last_error(aqg_ctx* ctx);
+void* aqg_ctx_stream(aqg_ctx* ctx);
+int aqg_sync(aqg_ctx* ctx);
+/* pre-size the internal workspace arena (block partials, hash tables) so that
+ * later calls never allocate: call once before a timed / graph-captured region */
+int aqg_reserve_workspace(aqg_ctx* ctx, size_t bytes);
+
+/* Replaces malloc/GC::reg/ScratchSpace for device temporaries
+ * (server/vector_type.hpp:70-80,367-371; server/gc.h:7-41).                  */
+int aqg_malloc(aqg_ctx* ctx, size_t bytes, void** dptr);
+int aqg_free(aqg_ctx* ctx, void* dptr);
+int aqg_h2d(aqg_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int aqg_d2h(aqg_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int aqg_memset(aqg_ctx* ctx, void* dst_dev, int byte, size_t bytes);
+
+/* Device mirror of a borrowed host column (the ColRef<T>(len, server->getCol(i))
+ * binding, engine/ast.py:367-370): uploads on first sight of (host_ptr, bytes),
+ * returns the cached device pointer afterwards; aqg_col_unpin_all drops the
+ * cache (the reference's per-dll session end).                               */
+int aqg_col_pin(aqg_ctx* ctx, const void* host_ptr, size_t bytes, void** dptr);
+int aqg_col_unpin(aqg_ctx* ctx, const void* host_ptr);
+int aqg_col_unpin_all(aqg_ctx* ctx);
+
+/* ---- element-wise column arithmetic / compare ------------------------------
+ * Replaces the free operators server/table.h:820-937 and aqop_* :954-973.
+ * ret[i] = l[i] OP r[i] evaluated in the C++ usual-arithmetic-conversion type
+ * of (lt, rt) exactly as the reference loop body does, then converted to `ot`.
+ * `ot` is the caller's result dtype: Coercion for + and -, GetLongType for *,
+ * GetFPType for / (so int32/int32 is an INTEGER quotient stored as float),
+ * AQG_BOOL for comparisons.                                                   */
+typedef enum aqg_binop {
+    AQG_OP_ADD = 0, AQG_OP_SUB = 1, AQG_OP_MUL = 2, AQG_OP_DIV = 3, AQG_OP_MOD = 4,
+    AQG_OP_AND = 5, AQG_OP_OR = 6, AQG_OP_XOR = 7,
+    AQG_OP_GT = 8, AQG_OP_LT = 9, AQG_OP_GE = 10, AQG_OP_LE = 11, AQG_OP_EQ = 12, AQG_OP_NE = 13
+} aqg_binop;
+enum { AQG_VEC_VEC = 0, AQG_VEC_SCALAR = 1, AQG_SCALAR_VEC = 2 };
+/* for *_SCALAR kinds the scalar side is a HOST pointer to one value of its dtype */
+int aqg_ewise(aqg_ctx* ctx, int op, int kind, int lt, const void* l, int rt, const void* r,
+              int ot, void* out, uint32_t n);
+/* result dtype of the reference's FREE operator for (op, lt, rt): table.h:779-818 */
+int aqg_ewise_out_dtype(int op, int lt, int rt);
+
+/* sqrt (server/aggregations.h:34-46) / truncate (:57-69) */
+typedef enum aqg_unop { AQG_UN_SQRT = 0, AQG_UN_TRUNCATE = 1 } aqg_unop;
+int aqg_unary(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, uint32_t param, int ot, void* out);
+
+/* ---- full-column reductions: server/aggregations.h:10-32,71-86,332-348,383-416,487-497
+ * `out_host` receives 16 bytes: SUM -> GetLongType (int128/uint128/double),
+ * MIN/MAX/FIRST/LAST -> T, COUNT -> uint64, AVG/VAR/STDDEV -> double.
+ * Reference quirks kept on purpose: max seeds with numeric_limits<T>::min()
+ * (:73, D8), var divides by len+1 (:347, D9).                                 */
+typedef enum aqg_redop {
+    AQG_RED_SUM = 0, AQG_RED_MIN = 1, AQG_RED_MAX = 2, AQG_RED_COUNT = 3, AQG_RED_AVG = 4,
+    AQG_RED_VAR = 5, AQG_RED_STDDEV = 6, AQG_RED_FIRST = 7, AQG_RED_LAST = 8
+} aqg_redop;
+int aqg_reduce(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, void* out_host16);
+int aqg_reduce_out_dtype(int op, int t);
+/* asynchronous form: 16-byte result left in device memory */
+int aqg_reduce_dev(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, void* out_dev16);
+/* corr(x, y): server/aggregations.h:383-407 */
+int aqg_corr(aqg_ctx* ctx, int tx, const void* x, int ty, const void* y, uint32_t n, double* out_host);
+
+/* ---- prefix scans, sliding windows, shifts ---------------------------------
+ * sums/avgs/mins/maxs  server/aggregations.h:89-125,203-236
+ * sumw/avgw/minw/maxw/ratiow :127-191,238-281 ; varw/stddevw :283-330 (D9, unpinned)
+ * deltas/prev/aggnext :439-485 ; ratios = ratiow(1) :193-201 ; vars/stddevs :350-381
+ * window = elements [i-w+1, i]; growing prefix for i < w.                      */
+typedef enum aqg_scanop {
+    AQG_SCAN_SUMS = 0, AQG_SCAN_AVGS = 1, AQG_SCAN_MINS = 2, AQG_SCAN_MAXS = 3,
+    AQG_SCAN_SUMW = 4, AQG_SCAN_AVGW = 5, AQG_SCAN_MINW = 6, AQG_SCAN_MAXW = 7,
+    AQG_SCAN_RATIOW = 8, AQG_SCAN_DELTAS = 9, AQG_SCAN_PREV = 10, AQG_SCAN_NEXT = 11,
+    AQG_SCAN_VARS = 12, AQG_SCAN_STDDEVS = 13, AQG_SCAN_VARW = 14, AQG_SCAN_STDDEVW = 15
+} aqg_scanop;
+int aqg_scan(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, uint32_t w, void* out);
+int aqg_scan_out_dtype(int op, int t);
+
+/* ---- gather / mask filter ---------------------------------------------------
+ * ColRef::operator[](vector_type<uint32_t>&)  server/table.h:184-189
+ * ColRef::operator[](const std::vector<bool>&) server/table.h:190-198 (as a true
+ * stream compaction; the reference's N-junk prefix, defect D11, is not kept)   */
+int aqg_gather(aqg_ctx* ctx, int t, const void* x, const uint32_t* idx, uint32_t m, void* out);
+int aqg_compact(aqg_ctx* ctx, int t, const void* x, const uint8_t* mask, uint32_t n,
+                void* out, uint32_t* m_host);
+/* row ids of set mask entries, ascending (selection vector for multi-column filters) */
+int aqg_mask_to_index(aqg_ctx* ctx, const uint8_t* mask, uint32_t n, uint32_t* idx_out, uint32_t* m_host);
+
+/* ---- hash group-by -----------------------------------------------------------
+ * Replaces AQHashTable (server/hasher.h:146-199) + set::hashtable_push
+ * (server/unordered_dense.h:1117-1147) + HashTableFactory::get (:327-357).
+ * Contract (the only executable one in the reference):
+ *   group ids are dense, numbered by FIRST OCCURRENCE of the key tuple;
+ *   ht_postproc row-id lists are DESCENDING row id within each group.
+ * `row_base` is added to row ids (row-range shards keep global ids).           */
+typedef struct aqg_groupby aqg_groupby;
+int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* const* keys,
+                      uint32_t n, aqg_groupby** out);
+void aqg_groupby_destroy(aqg_groupby* g);
+uint32_t aqg_groupby_ngroups(const aqg_groupby* g);
+uint32_t aqg_groupby_nrows(const aqg_groupby* g);
+/* device views owned by the handle (valid until destroy) */
+const uint32_t* aqg_groupby_reversemap(const aqg_groupby* g); /* [n] group id of row      (hasher.h:149 reversemap) */
+const uint32_t* aqg_groupby_counts(const aqg_groupby* g);     /* [G] rows per group       (ht_base before postproc) */
+const uint32_t* aqg_groupby_first_rows(const aqg_groupby* g); /* [G] first row of group                            */
+/* key column k of every group, in group order (AQHashTable::values()) */
+int aqg_groupby_keys(aqg_groupby* g, int k, void* out_dev);
+/* ht_postproc (hasher.h:181-198): offsets[G+1] (exclusive scan of counts; the
+ * reference's ht_base after postproc is offsets[0..G)), row_ids[n] descending   */
+int aqg_groupby_postproc(aqg_groupby* g, uint32_t* offsets_dev, uint32_t* row_ids_dev);
+
+/* one aggregate over all groups in ONE pass over the value column: the device
+ * form of the generated per-group loop `out[g] = op(col[vecs[g]])`
+ * (engine/ast.py:722-789, mem_opt.cpp:50-65).  Output dtype as aqg_reduce.     */
+int aqg_grouped_reduce(aqg_ctx* ctx, const aqg_groupby* g, int op, int t, const void* x, void* out_dev);
+
+/* fused single-pass group-by + aggregates (h2o Q1..Q5 shape): reads each key and
+ * value column exactly once.  outs[j] has ngroups elements of
+ * aqg_reduce_out_dtype(ops[j], val_dtypes[j]); group order = first occurrence.
+ * On return *out holds keys/counts/first_rows (no reversemap / postproc).       */
+int aqg_groupby_agg(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* const* keys,
+                    int naggs, const int* ops, const int* val_dtypes, const void* const* vals,
+                    uint32_t n, uint32_t max_groups_hint, aqg_groupby** out, void* const* outs_dev);
+
+/* ---- hash join (new functionality; reference runs joins in MonetDB)
+ * inner equi-join on one integer key: build on (build_keys, nb), probe with
+ * (probe_keys, np).  Emits matching row-id pairs ordered by probe row, then by
+ * build row ascending.  Two-call protocol: pass NULL outputs to get the count.  */
+int aqg_join_count(aqg_ctx* ctx, int t, const void* build_keys, uint32_t nb,
+                   const void* probe_keys, uint32_t np, uint64_t* m_host);
+int aqg_join_pairs(aqg_ctx* ctx, int t, const void* build_keys, uint32_t nb,
+                   const void* probe_keys, uint32_t np,
+                   uint32_t* probe_rows_out, uint32_t* build_rows_out, uint64_t capacity, uint64_t* m_host);
+/* unique-build-key lookup join fused with nothing: idx[i] = build row whose key
+ * equals probe_keys[i], or 0xFFFFFFFF                                            */
+int aqg_join_lookup(aqg_ctx* ctx, int t, const void* build_keys, uint32_t nb,
+                    const void* probe_keys, uint32_t np, uint32_t* build_row_of_probe);
+
+/* ---- synthetic h2o / time-series columns (bench + parity inputs) ---
+ * Counter-based: row i of column `col` depends only on (seed, col, row_base+i),
+ * so shards are reproducible independent of the GPU count.  The oracle carries
+ * the same generator for the CPU side.                                          */
+typedef enum aqg_gencol {
+    AQG_GEN_ID1 = 0, AQG_GEN_ID2 = 1, AQG_GEN_ID3 = 2, AQG_GEN_ID4 = 3, AQG_GEN_ID5 = 4, AQG_GEN_ID6 = 5,
+    AQG_GEN_V1 = 6, AQG_GEN_V2 = 7, AQG_GEN_V3 = 8, AQG_GEN_TIMESTAMP = 9, AQG_GEN_PRICE = 10
+} aqg_gencol;
+int aqg_gen_column(aqg_ctx* ctx, int col, uint64_t seed, uint64_t row_base, uint32_t n,
+                   uint64_t n_total, uint32_t K, void* out_dev);
+
+/* ---- HIP-event timing on the context's stream (bench.py roofline leg) ------ */
+int aqg_timer_start(aqg_ctx* ctx);
+int aqg_timer_stop_ms(aqg_ctx* ctx, float* ms_host);
+
+const char* aqg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AQG_H */
