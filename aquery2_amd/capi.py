@@ -1,0 +1,343 @@
+"""ctypes binding of the C-ABI (include/aqg.h).  Test/bench harness only: numpy in, numpy out.
+
+There is NO fallback: if libaqg.so is missing or no GPU is visible, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# dtype tags (reference server/aquery_types.h:1-5)
+INT32, FLOAT, STR, DOUBLE, LDOUBLE, INT64, INT128, INT16, DATE, TIME, INT8 = range(11)
+UINT32, UINT64, UINT128, UINT16, UINT8, BOOL = 11, 12, 13, 14, 15, 16
+ERROR = 22
+I128 = np.dtype([("lo", "<u8"), ("hi", "<i8")])
+U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])
+TAG2NP = {
+    INT8: np.dtype(np.int8), INT16: np.dtype(np.int16), INT32: np.dtype(np.int32), INT64: np.dtype(np.int64),
+    UINT8: np.dtype(np.uint8), UINT16: np.dtype(np.uint16), UINT32: np.dtype(np.uint32), UINT64: np.dtype(np.uint64),
+    FLOAT: np.dtype(np.float32), DOUBLE: np.dtype(np.float64), BOOL: np.dtype(np.uint8), INT128: I128, UINT128: U128,
+}
+NP2TAG = {v: k for k, v in TAG2NP.items() if k != BOOL}
+NP2TAG[np.dtype(np.bool_)] = BOOL
+VEC_VEC, VEC_SCALAR, SCALAR_VEC = 0, 1, 2
+
+
+class AqgError(RuntimeError):
+    def __init__(self, what, code, detail=""):
+        super().__init__(f"{what}: status {code} {detail}")
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(HERE, "libaqg.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """dlopen the in-tree libaqg.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise FileNotFoundError(f"{p} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "or `make -C aquery2_amd/csrc`")
+        lib = C.CDLL(p)
+        lib.aqg_version.restype = C.c_char_p
+        lib.aqg_last_error.restype = C.c_char_p
+        lib.aqg_dtype_size.restype = C.c_size_t
+        lib.aqg_ctx_stream.restype = C.c_void_p
+        lib.aqg_groupby_ngroups.restype = C.c_uint32
+        lib.aqg_groupby_nrows.restype = C.c_uint32
+        for f in ("aqg_groupby_reversemap", "aqg_groupby_counts", "aqg_groupby_first_rows", "aqg_groupby_agg_result"):
+            getattr(lib, f).restype = C.c_void_p
+        _LIB = lib
+    return _LIB
+
+
+def tag_of(a):
+    return NP2TAG[np.asarray(a).dtype]
+
+
+class DevBuf:
+    """A device allocation (HBM) with a dtype and element count."""
+
+    def __init__(self, dev, ptr, dtype, n, owned=True):
+        self.dev, self.ptr, self.dtype, self.n, self.owned = dev, ptr, np.dtype(dtype), int(n), owned
+
+    @property
+    def tag(self):
+        return NP2TAG[self.dtype] if self.dtype in NP2TAG else (INT128 if self.dtype == I128 else UINT128)
+
+    def to_host(self):
+        out = np.empty(self.n, dtype=self.dtype)
+        if self.n:
+            self.dev._chk(self.dev.lib.aqg_d2h(self.dev.ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(self.ptr),
+                                               C.c_size_t(out.nbytes)), "aqg_d2h")
+        return out
+
+    def free(self):
+        if self.owned and self.ptr:
+            self.dev.lib.aqg_free(self.dev.ctx, C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class GroupBy:
+    def __init__(self, dev, handle):
+        self.dev, self.h = dev, handle
+
+    @property
+    def ngroups(self):
+        return self.dev.lib.aqg_groupby_ngroups(self.h)
+
+    def _view(self, fn, dtype, n):
+        p = getattr(self.dev.lib, fn)(self.h)
+        if not p:
+            return None
+        return DevBuf(self.dev, p, dtype, n, owned=False).to_host()
+
+    def reversemap(self):
+        return self._view("aqg_groupby_reversemap", np.uint32, self.dev.lib.aqg_groupby_nrows(self.h))
+
+    def counts(self):
+        return self._view("aqg_groupby_counts", np.uint32, self.ngroups)
+
+    def first_rows(self):
+        return self._view("aqg_groupby_first_rows", np.uint32, self.ngroups)
+
+    def keys(self, k, dtype):
+        out = self.dev.empty(self.ngroups, dtype)
+        self.dev._chk(self.dev.lib.aqg_groupby_keys(self.h, k, C.c_void_p(out.ptr)), "aqg_groupby_keys")
+        self.dev.sync()
+        return out.to_host()
+
+    def result(self, j, op, val_tag):
+        ot = self.dev.lib.aqg_reduce_out_dtype(op, val_tag)
+        p = self.dev.lib.aqg_groupby_agg_result(self.h, j)
+        return DevBuf(self.dev, p, TAG2NP[ot], self.ngroups, owned=False).to_host()
+
+    def postproc(self):
+        G, n = self.ngroups, self.dev.lib.aqg_groupby_nrows(self.h)
+        off, rows = self.dev.empty(G + 1, np.uint32), self.dev.empty(max(n, 1), np.uint32)
+        self.dev._chk(self.dev.lib.aqg_groupby_postproc(self.h, C.c_void_p(off.ptr), C.c_void_p(rows.ptr)), "aqg_groupby_postproc")
+        self.dev.sync()
+        return off.to_host(), rows.to_host()[:n]
+
+    def destroy(self):
+        if self.h:
+            self.dev.lib.aqg_groupby_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Device:
+    """One aqg context on one GPU.  numpy-level wrappers upload, run the HIP path, download."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        ctx = C.c_void_p()
+        rc = self.lib.aqg_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(ctx))
+        if rc != 0:
+            raise AqgError("aqg_ctx_create (no MI355X visible? the HIP path has no CPU fallback)", rc)
+        self.ctx = ctx
+
+    def close(self):
+        if self.ctx:
+            self.lib.aqg_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise AqgError(what, rc, self.lib.aqg_last_error(self.ctx).decode())
+
+    def sync(self):
+        self._chk(self.lib.aqg_sync(self.ctx), "aqg_sync")
+
+    # -- memory
+    def empty(self, n, dtype):
+        dtype = np.dtype(dtype)
+        p = C.c_void_p()
+        self._chk(self.lib.aqg_malloc(self.ctx, C.c_size_t(max(int(n), 1) * dtype.itemsize + 64), C.byref(p)), "aqg_malloc")
+        return DevBuf(self, p.value, dtype, n)
+
+    def to_device(self, a):
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.bool_:
+            a = a.astype(np.uint8)
+        b = self.empty(a.size, a.dtype)
+        if a.size:
+            self._chk(self.lib.aqg_h2d(self.ctx, C.c_void_p(b.ptr), a.ctypes.data_as(C.c_void_p), C.c_size_t(a.nbytes)), "aqg_h2d")
+        return b
+
+    def _dev(self, a):
+        return a if isinstance(a, DevBuf) else self.to_device(a)
+
+    # -- generators
+    def gen_column(self, col, seed, row_base, n, n_total, K, out=None):
+        dt = np.float32 if col == 8 else np.int32
+        out = out or self.empty(n, dt)
+        self._chk(self.lib.aqg_gen_column(self.ctx, col, C.c_uint64(seed), C.c_uint64(row_base), C.c_uint32(n),
+                                          C.c_uint64(n_total), C.c_uint32(K), C.c_void_p(out.ptr)), "aqg_gen_column")
+        return out
+
+    # -- element-wise
+    def ewise(self, op, l, r, ot=None, keep=False):
+        l_vec = isinstance(l, DevBuf) or np.ndim(l) > 0
+        r_vec = isinstance(r, DevBuf) or np.ndim(r) > 0
+        kind = VEC_VEC if (l_vec and r_vec) else (VEC_SCALAR if l_vec else SCALAR_VEC)
+        ld = self._dev(l) if l_vec else None
+        rd = self._dev(r) if r_vec else None
+        ls = None if l_vec else np.atleast_1d(np.asarray(l))
+        rs = None if r_vec else np.atleast_1d(np.asarray(r))
+        lt = ld.tag if l_vec else tag_of(ls)
+        rt = rd.tag if r_vec else tag_of(rs)
+        n = ld.n if l_vec else rd.n
+        if ot is None:
+            ot = self.lib.aqg_ewise_out_dtype(op, lt, rt)
+        if ot == ERROR:
+            raise AqgError("aqg_ewise_out_dtype", ERROR)
+        out = self.empty(n, TAG2NP[ot])
+        lp = C.c_void_p(ld.ptr) if l_vec else ls.ctypes.data_as(C.c_void_p)
+        rp = C.c_void_p(rd.ptr) if r_vec else rs.ctypes.data_as(C.c_void_p)
+        self._chk(self.lib.aqg_ewise(self.ctx, op, kind, lt, lp, rt, rp, ot, C.c_void_p(out.ptr), C.c_uint32(n)), "aqg_ewise")
+        return out if keep else out.to_host()
+
+    def unary(self, op, x, param=0):
+        xd = self._dev(x)
+        ot = DOUBLE if op == 0 else xd.tag
+        out = self.empty(xd.n, TAG2NP[ot])
+        self._chk(self.lib.aqg_unary(self.ctx, op, xd.tag, C.c_void_p(xd.ptr), C.c_uint32(xd.n), C.c_uint32(param), ot,
+                                     C.c_void_p(out.ptr)), "aqg_unary")
+        return out.to_host()
+
+    # -- reductions
+    def reduce(self, op, x):
+        xd = self._dev(x)
+        buf = (C.c_ubyte * 16)()
+        self._chk(self.lib.aqg_reduce(self.ctx, op, xd.tag, C.c_void_p(xd.ptr), C.c_uint32(xd.n), buf), "aqg_reduce")
+        ot = self.lib.aqg_reduce_out_dtype(op, xd.tag)
+        v = np.frombuffer(bytes(buf), dtype=TAG2NP[ot], count=1)[0]
+        if ot in (INT128, UINT128):
+            lo, hi = int(v["lo"]), int(v["hi"])
+            return (hi << 64) + lo if ot == INT128 else (hi << 64) | lo
+        return v
+
+    def corr(self, x, y):
+        xd, yd = self._dev(x), self._dev(y)
+        out = C.c_double()
+        self._chk(self.lib.aqg_corr(self.ctx, xd.tag, C.c_void_p(xd.ptr), yd.tag, C.c_void_p(yd.ptr), C.c_uint32(xd.n),
+                                    C.byref(out)), "aqg_corr")
+        return out.value
+
+    # -- scans
+    def scan(self, op, x, w=0, keep=False):
+        xd = self._dev(x)
+        ot = self.lib.aqg_scan_out_dtype(op, xd.tag)
+        out = self.empty(xd.n, TAG2NP[ot])
+        self._chk(self.lib.aqg_scan(self.ctx, op, xd.tag, C.c_void_p(xd.ptr), C.c_uint32(xd.n), C.c_uint32(w),
+                                    C.c_void_p(out.ptr)), "aqg_scan")
+        return out if keep else out.to_host()
+
+    # -- gather / filter
+    def gather(self, x, idx):
+        xd, idd = self._dev(x), self._dev(np.ascontiguousarray(idx, dtype=np.uint32) if not isinstance(idx, DevBuf) else idx)
+        out = self.empty(idd.n, xd.dtype)
+        self._chk(self.lib.aqg_gather(self.ctx, xd.tag, C.c_void_p(xd.ptr), C.c_void_p(idd.ptr), C.c_uint32(idd.n),
+                                      C.c_void_p(out.ptr)), "aqg_gather")
+        return out.to_host()
+
+    def compact(self, x, mask):
+        xd = self._dev(x)
+        md = self._dev(np.ascontiguousarray(mask).astype(np.uint8) if not isinstance(mask, DevBuf) else mask)
+        out = self.empty(xd.n, xd.dtype)
+        m = C.c_uint32()
+        self._chk(self.lib.aqg_compact(self.ctx, xd.tag, C.c_void_p(xd.ptr), C.c_void_p(md.ptr), C.c_uint32(xd.n),
+                                       C.c_void_p(out.ptr), C.byref(m)), "aqg_compact")
+        return out.to_host()[:m.value].copy()
+
+    def mask_to_index(self, mask):
+        md = self._dev(np.ascontiguousarray(mask).astype(np.uint8) if not isinstance(mask, DevBuf) else mask)
+        out = self.empty(md.n, np.uint32)
+        m = C.c_uint32()
+        self._chk(self.lib.aqg_mask_to_index(self.ctx, C.c_void_p(md.ptr), C.c_uint32(md.n), C.c_void_p(out.ptr), C.byref(m)),
+                  "aqg_mask_to_index")
+        return out.to_host()[:m.value].copy()
+
+    # -- group by
+    def _keyargs(self, keys):
+        kd = [self._dev(k) for k in keys]
+        dts = (C.c_int * len(kd))(*[k.tag for k in kd])
+        ptrs = (C.c_void_p * len(kd))(*[k.ptr for k in kd])
+        return kd, dts, ptrs
+
+    def groupby_build(self, keys, hint=0):
+        kd, dts, ptrs = self._keyargs(keys)
+        h = C.c_void_p()
+        self._chk(self.lib.aqg_groupby_build(self.ctx, len(kd), dts, ptrs, C.c_uint32(kd[0].n), C.c_uint32(hint), C.byref(h)),
+                  "aqg_groupby_build")
+        return GroupBy(self, h)
+
+    def groupby_agg(self, keys, ops, vals, hint=0, handle=None):
+        kd, dts, ptrs = self._keyargs(keys)
+        vd = [self._dev(v) if v is not None else None for v in vals]
+        vdt = (C.c_int * len(vd))(*[(v.tag if v is not None else INT32) for v in vd])
+        vp = (C.c_void_p * len(vd))(*[(v.ptr if v is not None else None) for v in vd])
+        opa = (C.c_int * len(ops))(*ops)
+        h = handle.h if handle is not None else C.c_void_p()
+        self._chk(self.lib.aqg_groupby_agg(self.ctx, len(kd), dts, ptrs, len(ops), opa, vdt, vp, C.c_uint32(kd[0].n),
+                                           C.c_uint32(hint), C.byref(h)), "aqg_groupby_agg")
+        gb = handle if handle is not None else GroupBy(self, h)
+        gb._val_tags = [v.tag if v is not None else INT32 for v in vd]
+        gb._ops = list(ops)
+        return gb
+
+    def grouped_reduce(self, gb, op, x):
+        xd = self._dev(x)
+        ot = self.lib.aqg_reduce_out_dtype(op, xd.tag)
+        out = self.empty(gb.ngroups, TAG2NP[ot])
+        self._chk(self.lib.aqg_grouped_reduce(self.ctx, gb.h, op, xd.tag, C.c_void_p(xd.ptr), C.c_void_p(out.ptr)), "aqg_grouped_reduce")
+        self.sync()
+        return out.to_host()
+
+    # -- join
+    def join_pairs(self, build, probe):
+        bd, pd = self._dev(build), self._dev(probe)
+        m = C.c_uint64()
+        self._chk(self.lib.aqg_join_count(self.ctx, bd.tag, C.c_void_p(bd.ptr), C.c_uint32(bd.n), C.c_void_p(pd.ptr),
+                                          C.c_uint32(pd.n), C.byref(m)), "aqg_join_count")
+        pr, br = self.empty(m.value, np.uint32), self.empty(m.value, np.uint32)
+        self._chk(self.lib.aqg_join_pairs(self.ctx, bd.tag, C.c_void_p(bd.ptr), C.c_uint32(bd.n), C.c_void_p(pd.ptr),
+                                          C.c_uint32(pd.n), C.c_void_p(pr.ptr), C.c_void_p(br.ptr), C.c_uint64(m.value),
+                                          C.byref(m)), "aqg_join_pairs")
+        return pr.to_host(), br.to_host()
+
+    def join_lookup(self, build, probe):
+        bd, pd = self._dev(build), self._dev(probe)
+        out = self.empty(pd.n, np.uint32)
+        self._chk(self.lib.aqg_join_lookup(self.ctx, bd.tag, C.c_void_p(bd.ptr), C.c_uint32(bd.n), C.c_void_p(pd.ptr),
+                                           C.c_uint32(pd.n), C.c_void_p(out.ptr)), "aqg_join_lookup")
+        return out.to_host()
+
+    # -- timing
+    def timer_start(self):
+        self._chk(self.lib.aqg_timer_start(self.ctx), "aqg_timer_start")
+
+    def timer_stop_ms(self):
+        ms = C.c_float()
+        self._chk(self.lib.aqg_timer_stop_ms(self.ctx, C.byref(ms)), "aqg_timer_stop_ms")
+        return ms.value

@@ -1,0 +1,118 @@
+// aqg_internal.hpp -- host-side internals of libaqg (context, workspace, dtype dispatch).
+// gfx950 only: no portability layer, no CPU fallback (the product fails loudly without a GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/aqg.h"
+
+struct aqg_pin { void* dptr; size_t bytes; };
+
+struct aqg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cu = 256;
+    std::string err;
+    // workspace arena: one allocation, bump-allocated per API call
+    char* ws = nullptr;
+    size_t ws_cap = 0, ws_off = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::unordered_map<const void*, aqg_pin> pins;
+    // pinned host staging for small results
+    void* host_stage = nullptr;
+    size_t host_stage_cap = 0;
+};
+
+#define AQG_HIP(ctx, call)                                                                     \
+    do {                                                                                       \
+        hipError_t _e = (call);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e);                    \
+            return AQG_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+#define AQG_TRY(expr)                          \
+    do {                                       \
+        int _rc = (expr);                      \
+        if (_rc != AQG_OK) return _rc;         \
+    } while (0)
+
+static inline int aqg_fail(aqg_ctx* ctx, int code, const char* msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// workspace: reset at the start of an API call, then bump.  Growing synchronises the
+// stream (earlier kernels may still read the old arena) -- call aqg_reserve_workspace
+// ahead of timed regions.
+int aqg_ws_reset(aqg_ctx* ctx);
+int aqg_ws_alloc(aqg_ctx* ctx, size_t bytes, void** out);
+int aqg_ws_ensure(aqg_ctx* ctx, size_t bytes);
+template <class T> static inline int aqg_ws_get(aqg_ctx* ctx, size_t count, T** out) {
+    void* p = nullptr;
+    int rc = aqg_ws_alloc(ctx, count * sizeof(T), &p);
+    *out = static_cast<T*>(p);
+    return rc;
+}
+int aqg_host_stage(aqg_ctx* ctx, size_t bytes, void** out);
+
+// launch check
+static inline int aqg_check_launch(aqg_ctx* ctx, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ctx->err = std::string(what) + ": " + hipGetErrorString(e);
+        return AQG_ERR_HIP;
+    }
+    return AQG_OK;
+}
+
+// grid sizing for memory-bound grid-stride kernels: enough blocks to fill 256 CUs,
+// capped (guide: Guideline 11)
+static inline unsigned aqg_grid(const aqg_ctx* ctx, uint64_t work_items, unsigned block, unsigned items_per_thread,
+                                unsigned blocks_per_cu = 8) {
+    uint64_t per_block = (uint64_t)block * items_per_thread;
+    uint64_t need = (work_items + per_block - 1) / per_block;
+    uint64_t cap = (uint64_t)ctx->num_cu * blocks_per_cu;
+    if (need < 1) need = 1;
+    return (unsigned)(need < cap ? need : cap);
+}
+
+// ---- dtype helpers (host) ----------------------------------------------------------------
+static inline size_t dt_size(int dt) { return aqg_dtype_size(dt); }
+static inline bool dt_is_fp(int dt) { return dt == AQG_FLOAT || dt == AQG_DOUBLE; }
+static inline bool dt_is_unsigned(int dt) {
+    return dt == AQG_UINT8 || dt == AQG_UINT16 || dt == AQG_UINT32 || dt == AQG_UINT64 || dt == AQG_UINT128 || dt == AQG_BOOL;
+}
+static inline bool dt_is_num(int dt) {
+    switch (dt) {
+    case AQG_INT8: case AQG_INT16: case AQG_INT32: case AQG_INT64: case AQG_UINT8: case AQG_UINT16:
+    case AQG_UINT32: case AQG_UINT64: case AQG_FLOAT: case AQG_DOUBLE: return true;
+    }
+    return false;
+}
+
+// Dispatch a generic lambda on the C type of a numeric dtype tag.
+template <class T> struct aqg_tag { using type = T; };
+template <class F> static inline int aqg_dispatch_num(int dt, F&& f) {
+    switch (dt) {
+    case AQG_INT8: return f(aqg_tag<int8_t>{});
+    case AQG_INT16: return f(aqg_tag<int16_t>{});
+    case AQG_INT32: return f(aqg_tag<int32_t>{});
+    case AQG_INT64: return f(aqg_tag<int64_t>{});
+    case AQG_UINT8: return f(aqg_tag<uint8_t>{});
+    case AQG_UINT16: return f(aqg_tag<uint16_t>{});
+    case AQG_UINT32: return f(aqg_tag<uint32_t>{});
+    case AQG_UINT64: return f(aqg_tag<uint64_t>{});
+    case AQG_FLOAT: return f(aqg_tag<float>{});
+    case AQG_DOUBLE: return f(aqg_tag<double>{});
+    }
+    return AQG_ERR_DTYPE;
+}

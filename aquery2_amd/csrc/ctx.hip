@@ -1,0 +1,235 @@
+// ctx.hip -- context, stream, device memory, column pins, type rules, HIP-event timer.
+#include "aqg_internal.hpp"
+
+extern "C" {
+
+const char* aqg_version(void) { return "aquery2_amd 0.1 (gfx950)"; }
+
+// ---- type rules --------------------------------------------------------------------------
+// server/types.h:192-193 (AType_sizes) for the numeric tags
+size_t aqg_dtype_size(int dt) {
+    switch (dt) {
+    case AQG_INT8: case AQG_UINT8: case AQG_BOOL: case AQG_CHAR: return 1;
+    case AQG_INT16: case AQG_UINT16: return 2;
+    case AQG_INT32: case AQG_UINT32: case AQG_FLOAT: return 4;
+    case AQG_INT64: case AQG_UINT64: case AQG_DOUBLE: return 8;
+    case AQG_INT128: case AQG_UINT128: return 16;
+    default: return 0;
+    }
+}
+// types::GetLongType server/types.h:205-210
+int aqg_long_type(int dt) {
+    if (!aqg_dtype_size(dt)) return AQG_ERROR;
+    if (dt_is_fp(dt)) return AQG_DOUBLE;
+    return dt_is_unsigned(dt) ? AQG_UINT128 : AQG_INT128;
+}
+// types::GetFPType server/types.h:199-204
+int aqg_fp_type(int dt) {
+    if (!aqg_dtype_size(dt)) return AQG_ERROR;
+    return aqg_dtype_size(dt) == 4 ? AQG_FLOAT : AQG_DOUBLE;
+}
+static int int_tag(size_t sz, bool uns) {
+    switch (sz) {
+    case 1: return uns ? AQG_UINT8 : AQG_INT8;
+    case 2: return uns ? AQG_UINT16 : AQG_INT16;
+    case 4: return uns ? AQG_UINT32 : AQG_INT32;
+    case 8: return uns ? AQG_UINT64 : AQG_INT64;
+    case 16: return uns ? AQG_UINT128 : AQG_INT128;
+    }
+    return AQG_ERROR;
+}
+// types::Coercion server/types.h:264-275, including its uint64 quirk (aqis_same<unsigned long,
+// const char*> holds, so uint64 mixed with another type coerces to `const char*`)
+int aqg_coercion(int a, int b) {
+    size_t sa = aqg_dtype_size(a), sb = aqg_dtype_size(b);
+    if (!sa || !sb) return AQG_ERROR;
+    if (a == AQG_BOOL || b == AQG_BOOL) { if (a == b) return a; }
+    else if (dt_is_unsigned(a) == dt_is_unsigned(b) && dt_is_fp(a) == dt_is_fp(b) && sa == sb) return a;
+    if (a == AQG_UINT64 || b == AQG_UINT64) return AQG_STR;
+    int t0;
+    if (sa <= sb) {
+        if (sa == sb) t0 = dt_is_fp(a) ? a : (dt_is_fp(b) ? b : (dt_is_unsigned(a) ? b : a));
+        else t0 = b;
+    } else t0 = a;
+    if (dt_is_fp(a) || dt_is_fp(b)) return aqg_fp_type(t0);
+    if (!(dt_is_unsigned(a) && dt_is_unsigned(b))) return int_tag(aqg_dtype_size(t0), false);
+    return t0;
+}
+
+// ---- context -------------------------------------------------------------------------------
+int aqg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int aqg_ctx_create(int device, void* hip_stream, aqg_ctx** out) {
+    if (!out) return AQG_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return AQG_ERR_NODEVICE;
+    aqg_ctx* ctx = new aqg_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return AQG_ERR_NODEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hip_stream) {
+        ctx->stream = static_cast<hipStream_t>(hip_stream);
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return AQG_ERR_HIP; }
+        ctx->own_stream = true;
+    }
+    hipEventCreate(&ctx->ev0);
+    hipEventCreate(&ctx->ev1);
+    *out = ctx;
+    return AQG_OK;
+}
+
+void aqg_ctx_destroy(aqg_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->pins) hipFree(kv.second.dptr);
+    if (ctx->ws) hipFree(ctx->ws);
+    if (ctx->host_stage) hipHostFree(ctx->host_stage);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* aqg_last_error(aqg_ctx* ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+void* aqg_ctx_stream(aqg_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int aqg_sync(aqg_ctx* ctx) {
+    if (!ctx) return AQG_ERR_ARG;
+    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AQG_OK;
+}
+
+int aqg_reserve_workspace(aqg_ctx* ctx, size_t bytes) {
+    if (!ctx) return AQG_ERR_ARG;
+    return aqg_ws_ensure(ctx, bytes);
+}
+
+int aqg_malloc(aqg_ctx* ctx, size_t bytes, void** dptr) {
+    if (!ctx || !dptr) return AQG_ERR_ARG;
+    AQG_HIP(ctx, hipSetDevice(ctx->device));
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); *dptr = nullptr; return AQG_ERR_NOMEM; }
+    return AQG_OK;
+}
+int aqg_free(aqg_ctx* ctx, void* dptr) {
+    if (!ctx) return AQG_ERR_ARG;
+    if (!dptr) return AQG_OK;
+    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    AQG_HIP(ctx, hipFree(dptr));
+    return AQG_OK;
+}
+int aqg_h2d(aqg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return AQG_ERR_ARG;
+    if (!bytes) return AQG_OK;
+    AQG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AQG_OK;
+}
+int aqg_d2h(aqg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return AQG_ERR_ARG;
+    if (!bytes) return AQG_OK;
+    AQG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return AQG_OK;
+}
+int aqg_memset(aqg_ctx* ctx, void* dst, int byte, size_t bytes) {
+    if (!ctx) return AQG_ERR_ARG;
+    if (!bytes) return AQG_OK;
+    AQG_HIP(ctx, hipMemsetAsync(dst, byte, bytes, ctx->stream));
+    return AQG_OK;
+}
+
+int aqg_col_pin(aqg_ctx* ctx, const void* host_ptr, size_t bytes, void** dptr) {
+    if (!ctx || !host_ptr || !dptr) return AQG_ERR_ARG;
+    auto it = ctx->pins.find(host_ptr);
+    if (it != ctx->pins.end() && it->second.bytes >= bytes) { *dptr = it->second.dptr; return AQG_OK; }
+    if (it != ctx->pins.end()) { aqg_free(ctx, it->second.dptr); ctx->pins.erase(it); }
+    void* d = nullptr;
+    AQG_TRY(aqg_malloc(ctx, bytes, &d));
+    int rc = aqg_h2d(ctx, d, host_ptr, bytes);
+    if (rc != AQG_OK) { hipFree(d); return rc; }
+    ctx->pins[host_ptr] = {d, bytes};
+    *dptr = d;
+    return AQG_OK;
+}
+int aqg_col_unpin(aqg_ctx* ctx, const void* host_ptr) {
+    if (!ctx) return AQG_ERR_ARG;
+    auto it = ctx->pins.find(host_ptr);
+    if (it == ctx->pins.end()) return AQG_OK;
+    int rc = aqg_free(ctx, it->second.dptr);
+    ctx->pins.erase(it);
+    return rc;
+}
+int aqg_col_unpin_all(aqg_ctx* ctx) {
+    if (!ctx) return AQG_ERR_ARG;
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->pins) hipFree(kv.second.dptr);
+    ctx->pins.clear();
+    return AQG_OK;
+}
+
+int aqg_timer_start(aqg_ctx* ctx) {
+    if (!ctx) return AQG_ERR_ARG;
+    AQG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    return AQG_OK;
+}
+int aqg_timer_stop_ms(aqg_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return AQG_ERR_ARG;
+    AQG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    AQG_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    AQG_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return AQG_OK;
+}
+
+} // extern "C"
+
+// ---- workspace arena ---------------------------------------------------------------------------
+int aqg_ws_reset(aqg_ctx* ctx) {
+    ctx->ws_off = 0;
+    return AQG_OK;
+}
+int aqg_ws_ensure(aqg_ctx* ctx, size_t bytes) {
+    if (bytes <= ctx->ws_cap) return AQG_OK;
+    AQG_HIP(ctx, hipSetDevice(ctx->device));
+    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    size_t cap = ctx->ws_cap ? ctx->ws_cap : (size_t)1 << 20;
+    while (cap < bytes) cap *= 2;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess) { ctx->err = std::string("workspace hipMalloc: ") + hipGetErrorString(e); return AQG_ERR_NOMEM; }
+    if (ctx->ws) hipFree(ctx->ws);
+    ctx->ws = static_cast<char*>(p);
+    ctx->ws_cap = cap;
+    return AQG_OK;
+}
+// NOTE: a grow in the middle of a call would invalidate earlier sub-allocations of the same
+// call, so every API entry computes its total need first and calls aqg_ws_ensure once.
+int aqg_ws_alloc(aqg_ctx* ctx, size_t bytes, void** out) {
+    size_t off = (ctx->ws_off + 255) & ~(size_t)255;
+    if (off + bytes > ctx->ws_cap) {
+        if (off != 0) return aqg_fail(ctx, AQG_ERR_NOMEM, "workspace overflow inside a call (internal sizing bug)");
+        AQG_TRY(aqg_ws_ensure(ctx, bytes));
+    }
+    *out = ctx->ws + off;
+    ctx->ws_off = off + bytes;
+    return AQG_OK;
+}
+int aqg_host_stage(aqg_ctx* ctx, size_t bytes, void** out) {
+    if (bytes > ctx->host_stage_cap) {
+        if (ctx->host_stage) { hipStreamSynchronize(ctx->stream); hipHostFree(ctx->host_stage); }
+        size_t cap = bytes < 4096 ? 4096 : bytes;
+        AQG_HIP(ctx, hipHostMalloc(&ctx->host_stage, cap, hipHostMallocDefault));
+        ctx->host_stage_cap = cap;
+    }
+    *out = ctx->host_stage;
+    return AQG_OK;
+}

@@ -1,0 +1,298 @@
+// ewise.hip -- element-wise column arithmetic / compare (reference server/table.h:820-937 free
+// operators, :954-973 aqop_*), sqrt / truncate (server/aggregations.h:34-69).
+//
+// ret[i] = l[i] OP r[i] is evaluated in the C++ usual-arithmetic-conversion type C of the two
+// element types -- exactly what the reference's loop body computes -- and then converted to the
+// caller's result dtype (Coercion / GetLongType / GetFPType / bool, or aqop's Ret).
+// Kernels are instantiated per (C, OT); the input dtypes are wave-uniform runtime switches around
+// 8-element chunk loaders, so every lane still issues 16-byte loads and stores.
+// HBM-bound: algorithmic bytes per row = sizeof(TL) + sizeof(TR) + sizeof(OT).
+#include "aqg_internal.hpp"
+#include "dev_common.hpp"
+
+namespace {
+
+constexpr int E = 8; // elements per lane per step
+
+template <class C, class T> __device__ inline void load_chunk_t(const void* p, size_t base, C (&o)[E]) {
+    pack<T, E> v = *reinterpret_cast<const pack<T, E>*>(static_cast<const T*>(p) + base);
+#pragma unroll
+    for (int j = 0; j < E; ++j) o[j] = (C)v.v[j];
+}
+template <class C> __device__ inline void load_chunk(const void* p, int dt, size_t base, C (&o)[E]) {
+    switch (dt) {
+    case AQG_INT8: load_chunk_t<C, int8_t>(p, base, o); break;
+    case AQG_INT16: load_chunk_t<C, int16_t>(p, base, o); break;
+    case AQG_INT32: load_chunk_t<C, int32_t>(p, base, o); break;
+    case AQG_INT64: load_chunk_t<C, int64_t>(p, base, o); break;
+    case AQG_BOOL: case AQG_UINT8: load_chunk_t<C, uint8_t>(p, base, o); break;
+    case AQG_UINT16: load_chunk_t<C, uint16_t>(p, base, o); break;
+    case AQG_UINT32: load_chunk_t<C, uint32_t>(p, base, o); break;
+    case AQG_UINT64: load_chunk_t<C, uint64_t>(p, base, o); break;
+    case AQG_FLOAT: load_chunk_t<C, float>(p, base, o); break;
+    default: load_chunk_t<C, double>(p, base, o); break;
+    }
+}
+template <class C> __device__ inline C load_one(const void* p, int dt, size_t i) {
+    switch (dt) {
+    case AQG_INT8: return (C) static_cast<const int8_t*>(p)[i];
+    case AQG_INT16: return (C) static_cast<const int16_t*>(p)[i];
+    case AQG_INT32: return (C) static_cast<const int32_t*>(p)[i];
+    case AQG_INT64: return (C) static_cast<const int64_t*>(p)[i];
+    case AQG_BOOL: case AQG_UINT8: return (C) static_cast<const uint8_t*>(p)[i];
+    case AQG_UINT16: return (C) static_cast<const uint16_t*>(p)[i];
+    case AQG_UINT32: return (C) static_cast<const uint32_t*>(p)[i];
+    case AQG_UINT64: return (C) static_cast<const uint64_t*>(p)[i];
+    case AQG_FLOAT: return (C) static_cast<const float*>(p)[i];
+    default: return (C) static_cast<const double*>(p)[i];
+    }
+}
+
+// conversion of a computed value to the output element type
+template <class OT, class R> __device__ inline OT convert_out(R r) {
+    if constexpr (std::is_same_v<OT, aqg_i128>) {
+        static_assert(std::is_integral_v<R>, "128-bit results come from integer arithmetic");
+        if constexpr (std::is_unsigned_v<R>) return i128_from_u64((uint64_t)r); else return i128_from_i64((int64_t)r);
+    } else if constexpr (std::is_same_v<OT, bool>) {
+        return r != 0;
+    } else return (OT)r;
+}
+
+template <class C> __device__ inline C safe_div(C a, C b) {
+    if constexpr (std::is_floating_point_v<C>) return a / b;
+    else {
+        if (b == 0) return 0;                                   // the reference traps (SIGFPE); defined as 0 here
+        if constexpr (std::is_signed_v<C>) if (b == (C)-1) return (C)(0 - (std::make_unsigned_t<C>)a);
+        return a / b;
+    }
+}
+template <class C> __device__ inline C safe_mod(C a, C b) {
+    if constexpr (std::is_floating_point_v<C>) return 0;
+    else {
+        if (b == 0) return 0;
+        if constexpr (std::is_signed_v<C>) if (b == (C)-1) return 0;
+        return a % b;
+    }
+}
+
+template <int OP, class C, class OT> __device__ inline OT apply(C a, C b) {
+    if constexpr (OP == AQG_OP_ADD) return convert_out<OT>((C)(a + b));
+    else if constexpr (OP == AQG_OP_SUB) return convert_out<OT>((C)(a - b));
+    else if constexpr (OP == AQG_OP_MUL) return convert_out<OT>((C)(a * b));
+    else if constexpr (OP == AQG_OP_DIV) return convert_out<OT>(safe_div(a, b));
+    else if constexpr (OP == AQG_OP_MOD) return convert_out<OT>(safe_mod(a, b));
+    else if constexpr (OP == AQG_OP_AND || OP == AQG_OP_OR || OP == AQG_OP_XOR) {
+        if constexpr (std::is_integral_v<C>) {
+            if constexpr (OP == AQG_OP_AND) return convert_out<OT>((C)(a & b));
+            else if constexpr (OP == AQG_OP_OR) return convert_out<OT>((C)(a | b));
+            else return convert_out<OT>((C)(a ^ b));
+        } else return convert_out<OT>(0);
+    }
+    else if constexpr (OP == AQG_OP_GT) return convert_out<OT>((int)(a > b));
+    else if constexpr (OP == AQG_OP_LT) return convert_out<OT>((int)(a < b));
+    else if constexpr (OP == AQG_OP_GE) return convert_out<OT>((int)(a >= b));
+    else if constexpr (OP == AQG_OP_LE) return convert_out<OT>((int)(a <= b));
+    else if constexpr (OP == AQG_OP_EQ) return convert_out<OT>((int)(a == b));
+    else return convert_out<OT>((int)(a != b));
+}
+
+template <int OP, class C, class OT>
+__device__ inline void ewise_body(int kind, int lt, const void* l, int rt, const void* r, C sc, OT* out, uint32_t n) {
+    uint32_t nchunk = n / E;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+        C a[E], b[E];
+        size_t base = (size_t)c * E;
+        if (kind == AQG_SCALAR_VEC) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) a[j] = sc;
+        } else load_chunk<C>(l, lt, base, a);
+        if (kind == AQG_VEC_SCALAR) {
+#pragma unroll
+            for (int j = 0; j < E; ++j) b[j] = sc;
+        } else load_chunk<C>(r, rt, base, b);
+        pack<OT, E> o;
+#pragma unroll
+        for (int j = 0; j < E; ++j) o.v[j] = apply<OP, C, OT>(a[j], b[j]);
+        *reinterpret_cast<pack<OT, E>*>(out + base) = o;
+    }
+    if (blockIdx.x == 0) {
+        uint32_t i = nchunk * E + threadIdx.x;
+        if (i < n) {
+            C a = kind == AQG_SCALAR_VEC ? sc : load_one<C>(l, lt, i);
+            C b = kind == AQG_VEC_SCALAR ? sc : load_one<C>(r, rt, i);
+            out[i] = apply<OP, C, OT>(a, b);
+        }
+    }
+}
+
+template <class C, class OT>
+__global__ void __launch_bounds__(256) ewise_kernel(int op, int kind, int lt, const void* __restrict__ l, int rt,
+                                                    const void* __restrict__ r, C sc, OT* __restrict__ out, uint32_t n) {
+    switch (op) { // wave-uniform
+    case AQG_OP_ADD: ewise_body<AQG_OP_ADD>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_SUB: ewise_body<AQG_OP_SUB>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_MUL: ewise_body<AQG_OP_MUL>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_DIV: ewise_body<AQG_OP_DIV>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_MOD: ewise_body<AQG_OP_MOD>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_AND: ewise_body<AQG_OP_AND>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_OR: ewise_body<AQG_OP_OR>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_XOR: ewise_body<AQG_OP_XOR>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_GT: ewise_body<AQG_OP_GT>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_LT: ewise_body<AQG_OP_LT>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_GE: ewise_body<AQG_OP_GE>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_LE: ewise_body<AQG_OP_LE>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_EQ: ewise_body<AQG_OP_EQ>(kind, lt, l, rt, r, sc, out, n); break;
+    default: ewise_body<AQG_OP_NE>(kind, lt, l, rt, r, sc, out, n); break;
+    }
+}
+
+// host: C++ integer promotion + usual arithmetic conversions -> compute class tag
+int promote1(int dt) {
+    switch (dt) {
+    case AQG_FLOAT: case AQG_DOUBLE: case AQG_INT64: case AQG_UINT64: case AQG_UINT32: return dt;
+    default: return AQG_INT32;
+    }
+}
+int usual_conv(int lt, int rt) {
+    int a = promote1(lt), b = promote1(rt);
+    if (a == AQG_DOUBLE || b == AQG_DOUBLE) return AQG_DOUBLE;
+    if (a == AQG_FLOAT || b == AQG_FLOAT) return AQG_FLOAT;
+    if (a == AQG_UINT64 || b == AQG_UINT64) return AQG_UINT64;
+    if (a == AQG_INT64 || b == AQG_INT64) return AQG_INT64;
+    if (a == AQG_UINT32 || b == AQG_UINT32) return AQG_UINT32;
+    return AQG_INT32;
+}
+template <class C> C host_scalar(int dt, const void* p) {
+    switch (dt) {
+    case AQG_INT8: return (C) * static_cast<const int8_t*>(p);
+    case AQG_INT16: return (C) * static_cast<const int16_t*>(p);
+    case AQG_INT32: return (C) * static_cast<const int32_t*>(p);
+    case AQG_INT64: return (C) * static_cast<const int64_t*>(p);
+    case AQG_BOOL: case AQG_UINT8: return (C) * static_cast<const uint8_t*>(p);
+    case AQG_UINT16: return (C) * static_cast<const uint16_t*>(p);
+    case AQG_UINT32: return (C) * static_cast<const uint32_t*>(p);
+    case AQG_UINT64: return (C) * static_cast<const uint64_t*>(p);
+    case AQG_FLOAT: return (C) * static_cast<const float*>(p);
+    default: return (C) * static_cast<const double*>(p);
+    }
+}
+
+template <class C, class OT>
+int launch_ewise(aqg_ctx* ctx, int op, int kind, int lt, const void* l, int rt, const void* r, void* out, uint32_t n) {
+    if constexpr (std::is_same_v<OT, aqg_i128> && std::is_floating_point_v<C>) {
+        return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_ewise: 128-bit result from floating arithmetic");
+    } else {
+        C sc = 0;
+        if (kind == AQG_VEC_SCALAR) sc = host_scalar<C>(rt, r);
+        if (kind == AQG_SCALAR_VEC) sc = host_scalar<C>(lt, l);
+        unsigned grid = aqg_grid(ctx, n / E + 1, 256, 1, 16);
+        hipLaunchKernelGGL((ewise_kernel<C, OT>), dim3(grid), dim3(256), 0, ctx->stream, op, kind, lt,
+                           kind == AQG_SCALAR_VEC ? nullptr : l, rt, kind == AQG_VEC_SCALAR ? nullptr : r, sc,
+                           static_cast<OT*>(out), n);
+        return aqg_check_launch(ctx, "ewise_kernel");
+    }
+}
+
+template <class C> int dispatch_ot(aqg_ctx* ctx, int ot, int op, int kind, int lt, const void* l, int rt, const void* r, void* out, uint32_t n) {
+    switch (ot) {
+    case AQG_INT8: return launch_ewise<C, int8_t>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_INT16: return launch_ewise<C, int16_t>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_INT32: return launch_ewise<C, int32_t>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_INT64: return launch_ewise<C, int64_t>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_UINT8: return launch_ewise<C, uint8_t>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_UINT16: return launch_ewise<C, uint16_t>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_UINT32: return launch_ewise<C, uint32_t>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_UINT64: return launch_ewise<C, uint64_t>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_FLOAT: return launch_ewise<C, float>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_DOUBLE: return launch_ewise<C, double>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_BOOL: return launch_ewise<C, bool>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_INT128: case AQG_UINT128: return launch_ewise<C, aqg_i128>(ctx, op, kind, lt, l, rt, r, out, n);
+    }
+    return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_ewise: unsupported result dtype");
+}
+
+// ---- unary -----------------------------------------------------------------------------------
+// sqrt: `ret[i] = sqrt(v[i])` resolves to ::sqrt(double) for every T (aggregations.h:34-39)
+template <class T> __global__ void __launch_bounds__(256) sqrt_kernel(const T* __restrict__ x, double* __restrict__ out, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = sqrt((double)x[i]);
+}
+// truncate (aggregations.h:57-69): round(v * 10^p) / 10^p in double, unless v >= max/10^p
+template <class T> __global__ void __launch_bounds__(256) truncate_kernel(const T* __restrict__ x, T* __restrict__ out, uint32_t n,
+                                                                           double multiplier, double max_truncate) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        T v = x[i];
+        out[i] = (double)v < max_truncate ? (T)(round((double)v * multiplier) / multiplier) : v;
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+int aqg_ewise_out_dtype(int op, int lt, int rt) {
+    int c = aqg_coercion(lt, rt);
+    if (c == AQG_ERROR || c == AQG_STR) return AQG_ERROR;
+    switch (op) {
+    case AQG_OP_ADD: case AQG_OP_SUB: return c;                 // get_autoext_type  table.h:779-782
+    case AQG_OP_MUL: return aqg_long_type(c);                   // get_long_type     :784-787
+    case AQG_OP_DIV: return aqg_fp_type(c);                     // get_fp_type       :789-792
+    case AQG_OP_MOD: case AQG_OP_AND: case AQG_OP_OR: case AQG_OP_XOR: return c;
+    default: return AQG_BOOL;
+    }
+}
+
+int aqg_ewise(aqg_ctx* ctx, int op, int kind, int lt, const void* l, int rt, const void* r, int ot, void* out, uint32_t n) {
+    if (!ctx || op < 0 || op > AQG_OP_NE || kind < 0 || kind > 2) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_ewise: bad argument");
+    if (!l || !r || (!out && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_ewise: null operand");
+    if (!(dt_is_num(lt) || lt == AQG_BOOL) || !(dt_is_num(rt) || rt == AQG_BOOL)) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_ewise: operand dtype");
+    if (n == 0) return AQG_OK;
+    int c = usual_conv(lt, rt);
+    if ((c == AQG_FLOAT || c == AQG_DOUBLE) && (op == AQG_OP_MOD || op == AQG_OP_AND || op == AQG_OP_OR || op == AQG_OP_XOR))
+        return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_ewise: bitwise/mod on floating operands");
+    // chunk loads need E*sizeof(T)-aligned bases (capped at 16): device allocations always are
+    auto aligned = [](const void* p, int dt) { size_t a = E * aqg_dtype_size(dt); if (a > 16) a = 16; return ((uintptr_t)p & (a - 1)) == 0; };
+    if ((kind != AQG_SCALAR_VEC && !aligned(l, lt)) || (kind != AQG_VEC_SCALAR && !aligned(r, rt)) || !aligned(out, ot))
+        return aqg_fail(ctx, AQG_ERR_ARG, "aqg_ewise: operands must be 16-byte aligned");
+    switch (c) {
+    case AQG_INT32: return dispatch_ot<int32_t>(ctx, ot, op, kind, lt, l, rt, r, out, n);
+    case AQG_UINT32: return dispatch_ot<uint32_t>(ctx, ot, op, kind, lt, l, rt, r, out, n);
+    case AQG_INT64: return dispatch_ot<int64_t>(ctx, ot, op, kind, lt, l, rt, r, out, n);
+    case AQG_UINT64: return dispatch_ot<uint64_t>(ctx, ot, op, kind, lt, l, rt, r, out, n);
+    case AQG_FLOAT: return dispatch_ot<float>(ctx, ot, op, kind, lt, l, rt, r, out, n);
+    default: return dispatch_ot<double>(ctx, ot, op, kind, lt, l, rt, r, out, n);
+    }
+}
+
+int aqg_unary(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, uint32_t param, int ot, void* out) {
+    if (!ctx || (!x && n) || (!out && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_unary: bad argument");
+    if (n == 0) return AQG_OK;
+    unsigned grid = aqg_grid(ctx, n, 256, 4, 16);
+    if (op == AQG_UN_SQRT) {
+        if (ot != AQG_DOUBLE) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_unary: sqrt yields double");
+        return aqg_dispatch_num(t, [&](auto tt) -> int {
+            using T = typename decltype(tt)::type;
+            hipLaunchKernelGGL(sqrt_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, (const T*)x, (double*)out, n);
+            return aqg_check_launch(ctx, "sqrt_kernel");
+        });
+    }
+    if (op == AQG_UN_TRUNCATE) {
+        if (ot != t || !dt_is_fp(t)) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_unary: truncate is floating only");
+        uint32_t prec = t == AQG_FLOAT ? 7 : 16;   // aq_fp_precision (server/types.h:464-475)
+        if (prec <= param) {                        // :59-60 returns a copy
+            AQG_HIP(ctx, hipMemcpyAsync(out, x, (size_t)n * aqg_dtype_size(t), hipMemcpyDeviceToDevice, ctx->stream));
+            return AQG_OK;
+        }
+        double multiplier = pow(10, param);
+        if (t == AQG_FLOAT) {
+            hipLaunchKernelGGL(truncate_kernel<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)x, (float*)out, n,
+                               multiplier, (double)3.40282347e+38f / multiplier);
+        } else {
+            hipLaunchKernelGGL(truncate_kernel<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)x, (double*)out, n,
+                               multiplier, 1.7976931348623157e+308 / multiplier);
+        }
+        return aqg_check_launch(ctx, "truncate_kernel");
+    }
+    return aqg_fail(ctx, AQG_ERR_ARG, "aqg_unary: bad op");
+}
+
+} // extern "C"

@@ -1,0 +1,876 @@
+// groupby.hip -- hash group-by and grouped aggregation.
+//
+// Replaces AQHashTable (reference server/hasher.h:146-199), set::hashtable_push
+// (server/unordered_dense.h:1117-1147), ht_postproc (:181-198) and the generated per-group loop
+// `out[g] = op(col[vecs[g]])` (engine/ast.py:722-789).
+//
+// Contract kept from the only executable path of the reference: group ids are dense and numbered by
+// FIRST OCCURRENCE of the key tuple; row-id lists are DESCENDING inside a group.  The hash function
+// is not observable in results (only dense ids are), so the device uses its own.
+//
+// Kernels
+//   agg_kernel<LDS>   one pass over keys (+ value columns).  Low cardinality: every workgroup keeps a
+//                     {key, first_row, accumulators} open-addressing table in LDS (LDS atomics, no
+//                     HBM traffic beyond the 16-byte column loads), then merges it into the global
+//                     table with device-scope atomics.  High cardinality: rows go straight to the
+//                     global table in HBM.
+//   collect / rank / emit   occupied slots -> dense ids ordered by first row -> output columns.
+//   assign_kernel     second pass for aqg_groupby_build: reversemap[i] = dense id, counts.
+//   grouped_kernel    aqg_grouped_reduce: accumulators indexed by dense id.
+//   radix passes      aqg_groupby_postproc: stable partition of row ids by group id.
+// HBM roofline: agg = sum of key and value bytes per row (h2o Q1: 8 B/row); build = 12 B/row.
+#include "aqg_internal.hpp"
+#include "dev_common.hpp"
+
+namespace {
+
+constexpr int MAXKEYS = 8, MAXACC = 8, MAXAGG = 8;
+constexpr uint64_t EMPTY64 = ~0ull;
+constexpr uint32_t EMPTY32 = 0x80000000u;   // nullval<int> (server/types.h:458) doubles as the LDS empty mark
+constexpr uint32_t NOROW = 0xFFFFFFFFu;
+constexpr uint32_t FAIL = 0xFFFFFFFFu;
+
+enum : int { ACC_ADD_I = 0, ACC_ADD_F = 1, ACC_MIN = 2, ACC_MAX = 3 };
+enum : int { VC_I = 0, VC_U = 1, VC_F = 2 };   // value class of a column: signed / unsigned / floating
+
+struct KeySpec { int nkeys; int dt[MAXKEYS]; const void* col[MAXKEYS]; int shift[MAXKEYS]; int total_bytes; };
+struct AccSpec { int nacc; int kind[MAXACC]; int dt[MAXACC]; const void* col[MAXACC]; int square[MAXACC]; };
+struct GTable {
+    uint64_t* keys;      // [cap+1]  EMPTY64; slot `cap` holds the group whose packed key equals EMPTY64
+    uint32_t* first;     // [cap+1]  NOROW
+    uint32_t* count;     // [cap+1]  0 (may be null)
+    uint64_t* acc[MAXACC];
+    uint32_t cap;        // power of two
+    uint32_t* flags;     // [0] overflow, [1] number of occupied slots (after collect)
+};
+
+__host__ __device__ inline int aqg_dtype_size_dev(int dt) {
+    switch (dt) {
+    case AQG_INT8: case AQG_UINT8: case AQG_BOOL: return 1;
+    case AQG_INT16: case AQG_UINT16: return 2;
+    case AQG_INT32: case AQG_UINT32: case AQG_FLOAT: return 4;
+    default: return 8;
+    }
+}
+__device__ inline uint32_t hash32(uint32_t k) { return (k * 0x9E3779B1u) ^ (k >> 15); }
+__device__ inline uint32_t hash64(uint64_t k) { k *= 0x9E3779B97F4A7C15ull; return (uint32_t)(k >> 32) ^ (uint32_t)k; }
+
+// order-preserving maps into uint64 so that MIN/MAX of every class are unsigned integer atomics
+__device__ inline uint64_t map_i(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; }
+__device__ inline int64_t unmap_i(uint64_t u) { return (int64_t)(u ^ 0x8000000000000000ull); }
+__device__ inline uint64_t map_f(double d) { uint64_t b = __builtin_bit_cast(uint64_t, d); return (b >> 63) ? ~b : (b | 0x8000000000000000ull); }
+__device__ inline double unmap_f(uint64_t u) { uint64_t b = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u; return __builtin_bit_cast(double, b); }
+
+__host__ __device__ inline int vclass(int dt) {
+    switch (dt) {
+    case AQG_FLOAT: case AQG_DOUBLE: return VC_F;
+    case AQG_UINT8: case AQG_UINT16: case AQG_UINT32: case AQG_UINT64: case AQG_BOOL: return VC_U;
+    default: return VC_I;
+    }
+}
+
+// raw bits of element i, zero-extended (key packing)
+__device__ inline uint64_t load_bits(int dt, const void* col, size_t i) {
+    switch (dt) {
+    case AQG_INT8: case AQG_UINT8: case AQG_BOOL: return static_cast<const uint8_t*>(col)[i];
+    case AQG_INT16: case AQG_UINT16: return static_cast<const uint16_t*>(col)[i];
+    case AQG_INT32: case AQG_UINT32: case AQG_FLOAT: return static_cast<const uint32_t*>(col)[i];
+    default: return static_cast<const uint64_t*>(col)[i];
+    }
+}
+__device__ inline uint64_t pack_key(const KeySpec& ks, size_t i) {
+    uint64_t k = load_bits(ks.dt[0], ks.col[0], i);
+    for (int j = 1; j < ks.nkeys; ++j) k |= load_bits(ks.dt[j], ks.col[j], i) << ks.shift[j];
+    return k;
+}
+
+// value of element i as the 64-bit operand of its accumulator
+//   ADD_I: two's complement int64 (unsigned inputs zero-extended), `x*x` in the promoted type if square
+//   ADD_F: double bits; MIN/MAX: order-preserving map
+template <class T> __device__ inline uint64_t val_operand_t(T v, int kind, int square) {
+    if constexpr (std::is_floating_point_v<T>) {
+        double d = square ? (double)(v * v) : (double)v;
+        return kind == ACC_ADD_F ? __builtin_bit_cast(uint64_t, d) : map_f(d);
+    } else {
+        if (kind == ACC_ADD_I) {
+            if (square) {
+                using P = decltype(v * v);
+                using UP = std::make_unsigned_t<P>;
+                P p = (P)((UP)(P)v * (UP)(P)v);
+                if constexpr (std::is_unsigned_v<P>) return (uint64_t)p; else return (uint64_t)(int64_t)p;
+            }
+            if constexpr (std::is_unsigned_v<T>) return (uint64_t)v; else return (uint64_t)(int64_t)v;
+        }
+        if constexpr (std::is_unsigned_v<T>) return (uint64_t)v; else return map_i((int64_t)v);
+    }
+}
+__device__ inline uint64_t val_operand(int dt, const void* col, size_t i, int kind, int square) {
+    switch (dt) {
+    case AQG_INT8: return val_operand_t(static_cast<const int8_t*>(col)[i], kind, square);
+    case AQG_INT16: return val_operand_t(static_cast<const int16_t*>(col)[i], kind, square);
+    case AQG_INT32: return val_operand_t(static_cast<const int32_t*>(col)[i], kind, square);
+    case AQG_INT64: return val_operand_t(static_cast<const int64_t*>(col)[i], kind, square);
+    case AQG_UINT8: case AQG_BOOL: return val_operand_t(static_cast<const uint8_t*>(col)[i], kind, square);
+    case AQG_UINT16: return val_operand_t(static_cast<const uint16_t*>(col)[i], kind, square);
+    case AQG_UINT32: return val_operand_t(static_cast<const uint32_t*>(col)[i], kind, square);
+    case AQG_UINT64: return val_operand_t(static_cast<const uint64_t*>(col)[i], kind, square);
+    case AQG_FLOAT: return val_operand_t(static_cast<const float*>(col)[i], kind, square);
+    default: return val_operand_t(static_cast<const double*>(col)[i], kind, square);
+    }
+}
+// four consecutive rows of a 4-byte column with one 16-byte load
+template <class T> __device__ inline void val_operand4_t(const void* col, size_t base, int kind, int square, uint64_t (&o)[4]) {
+    pack<T, 4> v = *reinterpret_cast<const pack<T, 4>*>(static_cast<const T*>(col) + base);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = val_operand_t(v.v[j], kind, square);
+}
+__device__ inline void val_operand4(int dt, const void* col, size_t base, int kind, int square, uint64_t (&o)[4]) {
+    switch (dt) {
+    case AQG_INT8: val_operand4_t<int8_t>(col, base, kind, square, o); break;
+    case AQG_INT16: val_operand4_t<int16_t>(col, base, kind, square, o); break;
+    case AQG_INT32: val_operand4_t<int32_t>(col, base, kind, square, o); break;
+    case AQG_INT64: val_operand4_t<int64_t>(col, base, kind, square, o); break;
+    case AQG_UINT8: case AQG_BOOL: val_operand4_t<uint8_t>(col, base, kind, square, o); break;
+    case AQG_UINT16: val_operand4_t<uint16_t>(col, base, kind, square, o); break;
+    case AQG_UINT32: val_operand4_t<uint32_t>(col, base, kind, square, o); break;
+    case AQG_UINT64: val_operand4_t<uint64_t>(col, base, kind, square, o); break;
+    case AQG_FLOAT: val_operand4_t<float>(col, base, kind, square, o); break;
+    default: val_operand4_t<double>(col, base, kind, square, o); break;
+    }
+}
+
+__device__ inline void acc_apply(uint64_t* p, int kind, uint64_t v) {
+    switch (kind) {
+    case ACC_ADD_I: atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); break;
+    case ACC_ADD_F: atomicAdd(reinterpret_cast<double*>(p), __builtin_bit_cast(double, v)); break;
+    case ACC_MIN: atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); break;
+    default: atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); break;
+    }
+}
+__host__ __device__ inline uint64_t acc_init(int kind) { return kind == ACC_MIN ? ~0ull : 0ull; }
+
+// ---- global table ---------------------------------------------------------------------------
+// Slots only ever change EMPTY -> key, so a plain (possibly stale) load is safe: a stale EMPTY is
+// corrected by the device-scope compare-and-swap that follows.
+__device__ inline uint32_t gt_find_or_insert(const GTable& gt, uint64_t key) {
+    if (key == EMPTY64) return gt.cap;
+    uint32_t mask = gt.cap - 1, s = hash64(key) & mask;
+    for (uint32_t p = 0; p < gt.cap; ++p) {
+        uint64_t cur = gt.keys[s];
+        if (cur == key) return s;
+        if (cur == EMPTY64) {
+            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&gt.keys[s]), EMPTY64, key);
+            if (old == EMPTY64 || old == key) return s;
+        }
+        s = (s + 1) & mask;
+    }
+    gt.flags[0] = 1;   // table full
+    return FAIL;
+}
+__device__ inline uint32_t gt_find(const GTable& gt, uint64_t key) {
+    if (key == EMPTY64) return gt.cap;
+    uint32_t mask = gt.cap - 1, s = hash64(key) & mask;
+    for (uint32_t p = 0; p < gt.cap; ++p) {
+        uint64_t cur = gt.keys[s];
+        if (cur == key) return s;
+        if (cur == EMPTY64) return FAIL;
+        s = (s + 1) & mask;
+    }
+    return FAIL;
+}
+__device__ inline void gt_touch_first(const GTable& gt, uint32_t s, uint32_t row) {
+    // gt.first[s] only decreases: a stale (larger) value just costs one redundant atomic
+    if (row < gt.first[s]) atomicMin(&gt.first[s], row);
+}
+
+// ---- the single-pass aggregation kernel -------------------------------------------------------
+// K32: one 4-byte key column (h2o Q1/Q3/Q4/Q5).  LDS slot = {key32, first_row32} in one 8-byte
+// word, so a hit costs one ds_read_b64 + one LDS atomic per accumulator.
+template <bool USE_LDS, bool K32>
+__global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable gt, uint32_t n, uint32_t lcap, int need_count) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    // LDS layout (USE_LDS): lkey u64[lcap+1] | lacc[a] u64[lcap+1] ... | lfirst u32[lcap+1] (wide keys) | lcount u32[lcap+1] | lused u32
+    uint64_t* lkey = reinterpret_cast<uint64_t*>(smem_raw);
+    uint64_t* lacc = lkey + (lcap + 1);
+    uint32_t* lfirst = reinterpret_cast<uint32_t*>(lacc + (size_t)as.nacc * (lcap + 1));
+    uint32_t* lcount = lfirst + (K32 ? 0 : (lcap + 1));
+    uint32_t* lused = lcount + (need_count ? (lcap + 1) : 0);
+    const uint32_t lmask = lcap - 1;
+    const uint32_t llimit = lcap - (lcap >> 2);   // stop inserting at 75 % load; further new keys go to HBM
+
+    if constexpr (USE_LDS) {
+        for (uint32_t s = threadIdx.x; s <= lcap; s += blockDim.x) {
+            if constexpr (K32) lkey[s] = ((uint64_t)NOROW << 32) | EMPTY32; else { lkey[s] = EMPTY64; lfirst[s] = NOROW; }
+            for (int a = 0; a < as.nacc; ++a) lacc[(size_t)a * (lcap + 1) + s] = acc_init(as.kind[a]);
+            if (need_count) lcount[s] = 0;
+        }
+        if (threadIdx.x == 0) *lused = 0;
+        __syncthreads();
+    }
+
+    // returns the LDS slot of `key` (inserting it), or FAIL when the table is at its load limit
+    auto lds_slot = [&](uint64_t key) -> uint32_t {
+        if constexpr (K32) {
+            uint32_t k = (uint32_t)key;
+            if (k == EMPTY32) return lcap;
+            uint32_t* kw = reinterpret_cast<uint32_t*>(lkey);
+            uint32_t s = hash32(k) & lmask;
+            for (uint32_t p = 0; p <= lmask; ++p) {
+                uint32_t cur = kw[2 * s];
+                if (cur == k) return s;
+                if (cur == EMPTY32) {
+                    if (*lused >= llimit) return FAIL;
+                    uint32_t old = atomicCAS(&kw[2 * s], EMPTY32, k);
+                    if (old == EMPTY32) { atomicAdd(lused, 1u); return s; }
+                    if (old == k) return s;
+                }
+                s = (s + 1) & lmask;
+            }
+            return FAIL;
+        } else {
+            if (key == EMPTY64) return lcap;
+            uint32_t s = hash64(key) & lmask;
+            for (uint32_t p = 0; p <= lmask; ++p) {
+                uint64_t cur = lkey[s];
+                if (cur == key) return s;
+                if (cur == EMPTY64) {
+                    if (*lused >= llimit) return FAIL;
+                    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&lkey[s]), EMPTY64, key);
+                    if (old == EMPTY64) { atomicAdd(lused, 1u); return s; }
+                    if (old == key) return s;
+                }
+                s = (s + 1) & lmask;
+            }
+            return FAIL;
+        }
+    };
+    auto lds_touch_first = [&](uint32_t s, uint32_t row) {
+        uint32_t* f = K32 ? reinterpret_cast<uint32_t*>(lkey) + 2 * s + 1 : lfirst + s;
+        if (row < *f) atomicMin(f, row);
+    };
+
+    // one row whose slot is known
+    auto to_global = [&](uint64_t key, uint32_t row, const uint64_t* vals) {
+        uint32_t g = gt_find_or_insert(gt, key);
+        if (g == FAIL) return;
+        gt_touch_first(gt, g, row);
+        if (need_count) atomicAdd(&gt.count[g], 1u);
+        for (int a = 0; a < as.nacc; ++a) acc_apply(&gt.acc[a][g], as.kind[a], vals[a]);
+    };
+
+    const uint32_t nchunk = n >> 2;   // 4 consecutive rows per lane per step
+    const bool vec_ok = K32 && ks.nkeys == 1;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+        const size_t base = (size_t)c * 4;
+        uint64_t key[4];
+        if (vec_ok) {
+            pack<uint32_t, 4> kv = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(ks.col[0]) + base);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) key[j] = kv.v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) key[j] = pack_key(ks, base + j);
+        }
+        uint64_t vals[MAXACC][4];
+        for (int a = 0; a < as.nacc; ++a) val_operand4(as.dt[a], as.col[a], base, as.kind[a], as.square[a], vals[a]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t row = (uint32_t)base + j;
+            uint32_t s = FAIL;
+            if constexpr (USE_LDS) s = lds_slot(key[j]);
+            if (s != FAIL) {
+                lds_touch_first(s, row);
+                if (need_count) atomicAdd(&lcount[s], 1u);
+                for (int a = 0; a < as.nacc; ++a) acc_apply(&lacc[(size_t)a * (lcap + 1) + s], as.kind[a], vals[a][j]);
+            } else {
+                uint64_t v1[MAXACC];
+                for (int a = 0; a < as.nacc; ++a) v1[a] = vals[a][j];
+                to_global(key[j], row, v1);
+            }
+        }
+    }
+    // tail rows (< 4) by the first lanes of block 0
+    if (blockIdx.x == 0) {
+        uint32_t row = (nchunk << 2) + threadIdx.x;
+        if (row < n) {
+            uint64_t k = pack_key(ks, row);
+            uint64_t v1[MAXACC];
+            for (int a = 0; a < as.nacc; ++a) v1[a] = val_operand(as.dt[a], as.col[a], row, as.kind[a], as.square[a]);
+            to_global(k, row, v1);
+        }
+    }
+
+    if constexpr (USE_LDS) {
+        __syncthreads();
+        // merge this workgroup's table into the global one
+        for (uint32_t s = threadIdx.x; s <= lcap; s += blockDim.x) {
+            uint64_t key; uint32_t first;
+            if constexpr (K32) {
+                uint64_t w = lkey[s];
+                first = (uint32_t)(w >> 32);
+                key = (uint32_t)w;
+            } else { key = lkey[s]; first = lfirst[s]; }
+            if (first == NOROW) continue;          // never touched (covers the sentinel slot too)
+            uint32_t g = gt_find_or_insert(gt, key);
+            if (g == FAIL) continue;
+            atomicMin(&gt.first[g], first);
+            if (need_count) atomicAdd(&gt.count[g], lcount[s]);
+            for (int a = 0; a < as.nacc; ++a) acc_apply(&gt.acc[a][g], as.kind[a], lacc[(size_t)a * (lcap + 1) + s]);
+        }
+    }
+}
+
+// ---- dense ids in first-occurrence order --------------------------------------------------------
+__global__ void __launch_bounds__(256) collect_kernel(GTable gt, uint32_t* __restrict__ occ) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s <= gt.cap; s += gridDim.x * blockDim.x)
+        if (gt.first[s] != NOROW) occ[atomicAdd(&gt.flags[1], 1u)] = s;
+}
+// G <= 4096: rank by counting inside one workgroup
+__global__ void __launch_bounds__(1024) rank_small_kernel(GTable gt, const uint32_t* __restrict__ occ, uint32_t* __restrict__ gid_of_occ,
+                                                          uint32_t* __restrict__ slot_gid) {
+    __shared__ uint32_t f[4096];
+    uint32_t G = gt.flags[1];
+    if (G > 4096) return;
+    for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) f[i] = gt.first[occ[i]];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) {
+        uint32_t mine = f[i], r = 0;
+        for (uint32_t j = 0; j < G; ++j) r += f[j] < mine;
+        gid_of_occ[i] = r;
+        slot_gid[occ[i]] = r;
+    }
+}
+// any G: mark first rows in a bitmap over the n rows, prefix-count it, look the rank up
+__global__ void __launch_bounds__(256) bitmap_set_kernel(GTable gt, const uint32_t* __restrict__ occ, uint32_t* __restrict__ bitmap) {
+    uint32_t G = gt.flags[1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) {
+        uint32_t r = gt.first[occ[i]];
+        atomicOr(&bitmap[r >> 5], 1u << (r & 31));
+    }
+}
+// tile = 1024 words (one per thread... 256 threads x 4 words): per-word exclusive prefix inside the tile + tile total
+__global__ void __launch_bounds__(256) bitmap_tile_kernel(const uint32_t* __restrict__ bitmap, uint32_t nwords,
+                                                          uint32_t* __restrict__ word_prefix, uint32_t* __restrict__ tile_total) {
+    __shared__ uint32_t wsum[4];
+    uint32_t tile = blockIdx.x;
+    uint32_t w0 = tile * 1024 + threadIdx.x * 4;
+    uint32_t c[4], tot = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { uint32_t w = w0 + j; c[j] = w < nwords ? __popc(bitmap[w]) : 0; tot += c[j]; }
+    uint32_t incl = wave_scan_incl(tot, OpAdd{}, lane_id());
+    if (lane_id() == 63) wsum[wave_id()] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave_id(); ++w) wbase += wsum[w];
+    uint32_t excl = wbase + incl - tot;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { uint32_t w = w0 + j; if (w < nwords) word_prefix[w] = excl; excl += c[j]; }
+    if (threadIdx.x == 255) tile_total[tile] = wbase + incl;
+}
+__global__ void __launch_bounds__(1024) tile_scan_kernel(uint32_t* __restrict__ tile_total, uint32_t ntiles) {
+    // single workgroup exclusive scan, in place
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < ntiles; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < ntiles ? tile_total[i] : 0;
+        uint32_t incl = wave_scan_incl(v, OpAdd{}, lane_id());
+        if (lane_id() == 63) wsum[wave_id()] = incl;
+        __syncthreads();
+        uint32_t wbase = carry;
+        for (int w = 0; w < wave_id(); ++w) wbase += wsum[w];
+        if (i < ntiles) tile_total[i] = wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = wbase + incl;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) rank_bitmap_kernel(GTable gt, const uint32_t* __restrict__ occ, const uint32_t* __restrict__ bitmap,
+                                                          const uint32_t* __restrict__ word_prefix, const uint32_t* __restrict__ tile_prefix,
+                                                          uint32_t* __restrict__ gid_of_occ, uint32_t* __restrict__ slot_gid) {
+    uint32_t G = gt.flags[1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) {
+        uint32_t r = gt.first[occ[i]], w = r >> 5;
+        uint32_t rank = tile_prefix[w >> 10] + word_prefix[w] + __popc(bitmap[w] & ((1u << (r & 31)) - 1u));
+        gid_of_occ[i] = rank;
+        slot_gid[occ[i]] = rank;
+    }
+}
+
+// ---- 128-bit helpers for the emit epilogue ------------------------------------------------------
+__device__ inline double u128_to_double(uint64_t hi, uint64_t lo) {   // round to nearest even
+    if (hi == 0) return (double)lo;
+    int lz = __clzll((long long)hi);
+    // keep the top 64 bits, fold everything below into a sticky bit
+    uint64_t top = lz ? ((hi << lz) | (lo >> (64 - lz))) : hi;
+    uint64_t rest = lz ? (lo << lz) : lo;
+    if (rest) top |= 1;
+    return ldexp((double)top, 64 - lz);
+}
+__device__ inline double i128_to_double(aqg_i128 v) {
+    if ((int64_t)v.hi < 0) {
+        uint64_t lo = ~v.lo + 1, hi = ~v.hi + (lo == 0 ? 1 : 0);
+        return -u128_to_double(hi, lo);
+    }
+    return u128_to_double(v.hi, v.lo);
+}
+__device__ inline aqg_i128 mul_i64(int64_t a, int64_t b) {   // exact signed 64x64 -> 128
+    aqg_i128 r;
+    r.lo = (uint64_t)a * (uint64_t)b;
+    r.hi = (uint64_t)__mul64hi(a, b);
+    return r;
+}
+__device__ inline aqg_i128 mul_u64(uint64_t a, uint64_t b) {
+    aqg_i128 r;
+    r.lo = a * b;
+    r.hi = __umul64hi(a, b);
+    return r;
+}
+
+// what each requested aggregate reads from the accumulators
+struct AggOut { int op; int dt; int acc0; int acc1; void* out; };
+struct EmitSpec { int nagg; AggOut agg[MAXAGG]; int nkeys; int key_dt[MAXKEYS]; int key_shift[MAXKEYS]; void* key_out[MAXKEYS];
+                  uint32_t* first_out; uint32_t* count_out; };
+
+template <class T> __device__ inline void store_minmax(void* out, uint32_t g, uint64_t mapped, bool is_max) {
+    T v;
+    if constexpr (std::is_floating_point_v<T>) {
+        double d = unmap_f(mapped);
+        v = (T)d;
+        if (is_max) { T seed = dlimits<T>::min(); v = seed > v ? seed : v; }   // max seeds with numeric_limits<T>::min() (D8)
+    } else if constexpr (std::is_unsigned_v<T>) v = (T)mapped;
+    else v = (T)unmap_i(mapped);
+    static_cast<T*>(out)[g] = v;
+}
+
+__global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __restrict__ occ, const uint32_t* __restrict__ gid_of_occ, EmitSpec es) {
+    uint32_t G = gt.flags[1];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) {
+        uint32_t s = occ[i], g = gid_of_occ[i];
+        uint64_t key = s == gt.cap ? EMPTY64 : gt.keys[s];
+        for (int k = 0; k < es.nkeys; ++k) {
+            uint64_t bits = key >> es.key_shift[k];
+            switch (aqg_dtype_size_dev(es.key_dt[k])) {
+            case 1: static_cast<uint8_t*>(es.key_out[k])[g] = (uint8_t)bits; break;
+            case 2: static_cast<uint16_t*>(es.key_out[k])[g] = (uint16_t)bits; break;
+            case 4: static_cast<uint32_t*>(es.key_out[k])[g] = (uint32_t)bits; break;
+            default: static_cast<uint64_t*>(es.key_out[k])[g] = bits; break;
+            }
+        }
+        es.first_out[g] = gt.first[s];
+        uint32_t cnt = gt.count ? gt.count[s] : 0;
+        if (es.count_out) es.count_out[g] = cnt;
+        for (int j = 0; j < es.nagg; ++j) {
+            const AggOut& a = es.agg[j];
+            int vc = vclass(a.dt);
+            uint64_t v0 = a.acc0 >= 0 ? gt.acc[a.acc0][s] : 0, v1 = a.acc1 >= 0 ? gt.acc[a.acc1][s] : 0;
+            switch (a.op) {
+            case AQG_RED_SUM:                                               // -> GetLongType
+                if (vc == VC_F) static_cast<double*>(a.out)[g] = __builtin_bit_cast(double, v0);
+                else static_cast<aqg_i128*>(a.out)[g] = vc == VC_U ? i128_from_u64(v0) : i128_from_i64((int64_t)v0);
+                break;
+            case AQG_RED_COUNT: static_cast<uint64_t*>(a.out)[g] = cnt; break;
+            case AQG_RED_AVG: {                                             // sum / (double)size
+                double sd = vc == VC_F ? __builtin_bit_cast(double, v0) : vc == VC_U ? (double)v0 : (double)(int64_t)v0;
+                static_cast<double*>(a.out)[g] = sd / (double)cnt;
+            } break;
+            case AQG_RED_VAR: case AQG_RED_STDDEV: {                        // (ssq - s*s/(double)(n+1)) / (double)(n+1)
+                double np1 = (double)(uint32_t)(cnt + 1), d;
+                if (vc == VC_F) {
+                    double sd = __builtin_bit_cast(double, v0), q = __builtin_bit_cast(double, v1);
+                    d = (q - sd * sd / np1) / np1;
+                } else if (vc == VC_U) {
+                    aqg_i128 ss = mul_u64(v0, v0);
+                    d = ((double)v1 - u128_to_double(ss.hi, ss.lo) / np1) / np1;
+                } else {
+                    d = ((double)(int64_t)v1 - i128_to_double(mul_i64((int64_t)v0, (int64_t)v0)) / np1) / np1;
+                }
+                static_cast<double*>(a.out)[g] = a.op == AQG_RED_STDDEV ? sqrt(d) : d;
+            } break;
+            case AQG_RED_MIN: case AQG_RED_MAX: {
+                bool mx = a.op == AQG_RED_MAX;
+                switch (a.dt) {
+                case AQG_INT8: store_minmax<int8_t>(a.out, g, v0, mx); break;
+                case AQG_INT16: store_minmax<int16_t>(a.out, g, v0, mx); break;
+                case AQG_INT32: store_minmax<int32_t>(a.out, g, v0, mx); break;
+                case AQG_INT64: store_minmax<int64_t>(a.out, g, v0, mx); break;
+                case AQG_UINT8: store_minmax<uint8_t>(a.out, g, v0, mx); break;
+                case AQG_UINT16: store_minmax<uint16_t>(a.out, g, v0, mx); break;
+                case AQG_UINT32: store_minmax<uint32_t>(a.out, g, v0, mx); break;
+                case AQG_UINT64: store_minmax<uint64_t>(a.out, g, v0, mx); break;
+                case AQG_FLOAT: store_minmax<float>(a.out, g, v0, mx); break;
+                default: store_minmax<double>(a.out, g, v0, mx); break;
+                }
+            } break;
+            }
+        }
+    }
+}
+
+// ---- second pass of aqg_groupby_build: reversemap + counts ---------------------------------------
+template <bool LDS_COUNTS>
+__global__ void __launch_bounds__(256) assign_kernel(KeySpec ks, GTable gt, const uint32_t* __restrict__ slot_gid, uint32_t n,
+                                                     uint32_t G, uint32_t* __restrict__ reversemap, uint32_t* __restrict__ counts) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint32_t* lc = reinterpret_cast<uint32_t*>(smem_raw);
+    if constexpr (LDS_COUNTS) {
+        for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) lc[g] = 0;
+        __syncthreads();
+    }
+    const uint32_t nchunk = n >> 2;
+    const bool vec_ok = ks.nkeys == 1 && ks.total_bytes == 4;
+    auto one = [&](uint64_t key) -> uint32_t {
+        uint32_t s = gt_find(gt, key);
+        uint32_t g = s == FAIL ? 0u : slot_gid[s];
+        if constexpr (LDS_COUNTS) atomicAdd(&lc[g], 1u); else atomicAdd(&counts[g], 1u);
+        return g;
+    };
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+        const size_t base = (size_t)c * 4;
+        uint64_t key[4];
+        if (vec_ok) {
+            pack<uint32_t, 4> kv = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(ks.col[0]) + base);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) key[j] = kv.v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) key[j] = pack_key(ks, base + j);
+        }
+        pack<uint32_t, 4> o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.v[j] = one(key[j]);
+        *reinterpret_cast<pack<uint32_t, 4>*>(reversemap + base) = o;
+    }
+    if (blockIdx.x == 0) {
+        uint32_t row = (nchunk << 2) + threadIdx.x;
+        if (row < n) reversemap[row] = one(pack_key(ks, row));
+    }
+    if constexpr (LDS_COUNTS) {
+        __syncthreads();
+        for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) { uint32_t c = lc[g]; if (c) atomicAdd(&counts[g], c); }
+    }
+}
+
+} // namespace
+
+// =================================================================================================
+// host side
+// =================================================================================================
+struct aqg_groupby {
+    aqg_ctx* ctx = nullptr;
+    uint32_t n = 0, ngroups = 0;
+    int nkeys = 0;
+    int key_dt[MAXKEYS] = {0};
+    bool has_counts = false, has_reversemap = false;
+    // device buffers owned by the handle (grow-only)
+    void* keys_out[MAXKEYS] = {nullptr};
+    uint32_t* first_rows = nullptr;
+    uint32_t* counts = nullptr;
+    uint32_t* reversemap = nullptr;
+    void* results[MAXAGG] = {nullptr};
+    int nagg = 0;
+    int res_dt[MAXAGG] = {0};
+    size_t cap_groups = 0, cap_rows = 0, cap_results[MAXAGG] = {0};
+    uint32_t hint_used = 0;
+};
+
+namespace {
+
+uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (uint32_t)(p > 0x80000000ull ? 0x80000000ull : p); }
+
+int dev_realloc(aqg_ctx* ctx, void** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return AQG_OK;
+    if (*p) { AQG_HIP(ctx, hipStreamSynchronize(ctx->stream)); AQG_HIP(ctx, hipFree(*p)); *p = nullptr; *cap = 0; }
+    size_t want = need < 256 ? 256 : need;
+    hipError_t e = hipMalloc(p, want);
+    if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return AQG_ERR_NOMEM; }
+    *cap = want;
+    return AQG_OK;
+}
+
+int make_keyspec(aqg_ctx* ctx, int nkeys, const int* dts, const void* const* keys, uint32_t n, KeySpec* ks) {
+    if (nkeys < 1 || nkeys > MAXKEYS) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: 1..8 key columns");
+    int bits = 0;
+    ks->nkeys = nkeys;
+    for (int j = 0; j < nkeys; ++j) {
+        if (!(dt_is_num(dts[j]) || dts[j] == AQG_BOOL)) return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: key dtype");
+        if (dt_is_fp(dts[j])) return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: floating key columns are not supported (tuple == on NaN / -0.0)");
+        if (!keys[j] && n) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: null key column");
+        ks->dt[j] = dts[j]; ks->col[j] = keys[j]; ks->shift[j] = bits;
+        bits += 8 * (int)aqg_dtype_size(dts[j]);
+    }
+    if (bits > 64) return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: key tuples wider than 8 bytes are not supported yet");
+    ks->total_bytes = bits / 8;
+    return AQG_OK;
+}
+
+struct Plan {
+    AccSpec as;
+    int need_count;
+    int nagg;
+    AggOut agg[MAXAGG];
+};
+
+int add_acc(Plan* p, int kind, int dt, const void* col, int square) {
+    for (int a = 0; a < p->as.nacc; ++a)
+        if (p->as.kind[a] == kind && p->as.dt[a] == dt && p->as.col[a] == col && p->as.square[a] == square) return a;
+    if (p->as.nacc >= MAXACC) return -1;
+    int a = p->as.nacc++;
+    p->as.kind[a] = kind; p->as.dt[a] = dt; p->as.col[a] = col; p->as.square[a] = square;
+    return a;
+}
+
+int make_plan(aqg_ctx* ctx, int naggs, const int* ops, const int* dts, const void* const* vals, uint32_t n, Plan* p) {
+    memset(p, 0, sizeof *p);
+    if (naggs < 0 || naggs > MAXAGG) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: 0..8 aggregates");
+    p->nagg = naggs;
+    for (int j = 0; j < naggs; ++j) {
+        int op = ops[j], dt = dts[j];
+        if (!dt_is_num(dt)) return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: value dtype");
+        if (!vals[j] && n && op != AQG_RED_COUNT) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: null value column");
+        bool fp = dt_is_fp(dt);
+        AggOut& a = p->agg[j];
+        a.op = op; a.dt = dt; a.acc0 = a.acc1 = -1; a.out = nullptr;
+        switch (op) {
+        case AQG_RED_SUM: a.acc0 = add_acc(p, fp ? ACC_ADD_F : ACC_ADD_I, dt, vals[j], 0); break;
+        case AQG_RED_AVG: a.acc0 = add_acc(p, fp ? ACC_ADD_F : ACC_ADD_I, dt, vals[j], 0); p->need_count = 1; break;
+        case AQG_RED_VAR: case AQG_RED_STDDEV:
+            a.acc0 = add_acc(p, fp ? ACC_ADD_F : ACC_ADD_I, dt, vals[j], 0);
+            a.acc1 = add_acc(p, fp ? ACC_ADD_F : ACC_ADD_I, dt, vals[j], 1);
+            p->need_count = 1;
+            if (a.acc1 < 0) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: too many accumulators");
+            break;
+        case AQG_RED_MIN: a.acc0 = add_acc(p, ACC_MIN, dt, vals[j], 0); break;
+        case AQG_RED_MAX: a.acc0 = add_acc(p, ACC_MAX, dt, vals[j], 0); break;
+        case AQG_RED_COUNT: p->need_count = 1; break;
+        default: return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: FIRST/LAST need row lists (use aqg_grouped_reduce)");
+        }
+        if (op != AQG_RED_COUNT && a.acc0 < 0) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: too many accumulators");
+        if ((dt == AQG_INT64 || dt == AQG_UINT64) && (op == AQG_RED_SUM || op == AQG_RED_AVG || op == AQG_RED_VAR || op == AQG_RED_STDDEV))
+            return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: sums of 8-byte integers need 128-bit accumulators (not on device yet)");
+    }
+    return AQG_OK;
+}
+
+// One attempt at a given global capacity.  Returns AQG_ERR_OVERFLOW when the table filled up.
+int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
+            GTable* gt_out, uint32_t** slot_gid_out) {
+    const AccSpec& as = plan.as;
+    const bool use_lds = hint <= 3072;
+    const bool k32 = ks.nkeys == 1 && ks.total_bytes == 4;
+    uint32_t gcap = next_pow2((uint64_t)(hint < 512 ? 512 : hint) * 2);
+    uint32_t lcap = use_lds ? next_pow2((uint64_t)(hint < 64 ? 64 : hint) * 4 / 3 + 1) : 0;
+    if (use_lds && lcap < 256) lcap = 256;
+    const bool small_rank = hint <= 4096;
+    const uint32_t nwords = (n + 31) / 32, ntiles = (nwords + 1023) / 1024;
+
+    // ---- workspace ----------------------------------------------------------------------------
+    size_t slots = (size_t)gcap + 1;
+    size_t need = slots * (8 + 4 + 4 + 8 * (size_t)as.nacc + 4 + 4 + 4) + 4096 + 256 * 16;
+    if (!small_rank) need += (size_t)nwords * 8 + (size_t)ntiles * 4 + 4096;
+    AQG_TRY(aqg_ws_reset(ctx));
+    AQG_TRY(aqg_ws_ensure(ctx, need));
+    GTable gt;
+    memset(&gt, 0, sizeof gt);
+    gt.cap = gcap;
+    uint32_t *occ, *gid_of_occ, *slot_gid, *bitmap = nullptr, *word_prefix = nullptr, *tile_total = nullptr;
+    AQG_TRY(aqg_ws_get(ctx, slots, &gt.keys));
+    AQG_TRY(aqg_ws_get(ctx, slots, &gt.first));
+    if (plan.need_count) AQG_TRY(aqg_ws_get(ctx, slots, &gt.count));
+    for (int a = 0; a < as.nacc; ++a) AQG_TRY(aqg_ws_get(ctx, slots, &gt.acc[a]));
+    AQG_TRY(aqg_ws_get(ctx, 64, &gt.flags));
+    AQG_TRY(aqg_ws_get(ctx, slots, &occ));
+    AQG_TRY(aqg_ws_get(ctx, slots, &gid_of_occ));
+    AQG_TRY(aqg_ws_get(ctx, slots, &slot_gid));
+    if (!small_rank) {
+        AQG_TRY(aqg_ws_get(ctx, nwords, &bitmap));
+        AQG_TRY(aqg_ws_get(ctx, nwords, &word_prefix));
+        AQG_TRY(aqg_ws_get(ctx, ntiles + 1, &tile_total));
+    }
+    AQG_HIP(ctx, hipMemsetAsync(gt.keys, 0xFF, slots * 8, ctx->stream));
+    AQG_HIP(ctx, hipMemsetAsync(gt.first, 0xFF, slots * 4, ctx->stream));
+    if (gt.count) AQG_HIP(ctx, hipMemsetAsync(gt.count, 0, slots * 4, ctx->stream));
+    for (int a = 0; a < as.nacc; ++a) AQG_HIP(ctx, hipMemsetAsync(gt.acc[a], as.kind[a] == ACC_MIN ? 0xFF : 0, slots * 8, ctx->stream));
+    AQG_HIP(ctx, hipMemsetAsync(gt.flags, 0, 64 * 4, ctx->stream));
+    if (bitmap) AQG_HIP(ctx, hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, ctx->stream));
+
+    // ---- pass over the rows ---------------------------------------------------------------------
+    if (n) {
+        if (use_lds) {
+            size_t lds = (size_t)(lcap + 1) * (8 + 8 * (size_t)as.nacc + (k32 ? 0 : 4) + (plan.need_count ? 4 : 0)) + 16;
+            unsigned bpc = lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : lds <= 80 * 1024 ? 2 : 1;
+            unsigned grid = aqg_grid(ctx, n / 4 + 1, 256, 2, bpc);
+            if (k32) {
+                AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((agg_kernel<true, true>), dim3(grid), dim3(256), lds, ctx->stream, ks, as, gt, n, lcap, plan.need_count);
+            } else {
+                AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((agg_kernel<true, false>), dim3(grid), dim3(256), lds, ctx->stream, ks, as, gt, n, lcap, plan.need_count);
+            }
+        } else {
+            unsigned grid = aqg_grid(ctx, n / 4 + 1, 256, 2, 8);
+            if (k32) hipLaunchKernelGGL((agg_kernel<false, true>), dim3(grid), dim3(256), 0, ctx->stream, ks, as, gt, n, 0u, plan.need_count);
+            else hipLaunchKernelGGL((agg_kernel<false, false>), dim3(grid), dim3(256), 0, ctx->stream, ks, as, gt, n, 0u, plan.need_count);
+        }
+        AQG_TRY(aqg_check_launch(ctx, "agg_kernel"));
+    }
+    // ---- dense ids ---------------------------------------------------------------------------------
+    unsigned cgrid = aqg_grid(ctx, slots, 256, 1, 8);
+    hipLaunchKernelGGL(collect_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, gt, occ);
+    uint32_t fl[2] = {0, 0};
+    AQG_HIP(ctx, hipMemcpyAsync(fl, gt.flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (fl[0]) return AQG_ERR_OVERFLOW;
+    uint32_t G = fl[1];
+    if (small_rank && G > 4096) return AQG_ERR_OVERFLOW;
+    if (use_lds && G > 3072 && G > hint) return AQG_ERR_OVERFLOW;   // correct but slow: re-plan in HBM mode
+    if (G) {
+        if (small_rank) {
+            hipLaunchKernelGGL(rank_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, gt, occ, gid_of_occ, slot_gid);
+        } else {
+            unsigned g1 = aqg_grid(ctx, G, 256, 1, 8);
+            hipLaunchKernelGGL(bitmap_set_kernel, dim3(g1), dim3(256), 0, ctx->stream, gt, occ, bitmap);
+            hipLaunchKernelGGL(bitmap_tile_kernel, dim3(ntiles), dim3(256), 0, ctx->stream, bitmap, nwords, word_prefix, tile_total);
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, tile_total, ntiles);
+            hipLaunchKernelGGL(rank_bitmap_kernel, dim3(g1), dim3(256), 0, ctx->stream, gt, occ, bitmap, word_prefix, tile_total, gid_of_occ, slot_gid);
+        }
+    }
+    // ---- outputs --------------------------------------------------------------------------------------
+    h->ngroups = G;
+    h->nkeys = ks.nkeys;
+    size_t gcapn = G ? G : 1;
+    EmitSpec es;
+    memset(&es, 0, sizeof es);
+    es.nkeys = ks.nkeys;
+    {
+        size_t kc[MAXKEYS];
+        for (int k = 0; k < ks.nkeys; ++k) {
+            h->key_dt[k] = ks.dt[k];
+            kc[k] = h->cap_groups * aqg_dtype_size(ks.dt[k]);
+            if (h->cap_groups < gcapn || !h->keys_out[k]) { size_t c = h->keys_out[k] ? kc[k] : 0; AQG_TRY(dev_realloc(ctx, &h->keys_out[k], &c, gcapn * 8)); }
+            es.key_dt[k] = ks.dt[k]; es.key_shift[k] = ks.shift[k]; es.key_out[k] = h->keys_out[k];
+        }
+        if (h->cap_groups < gcapn || !h->first_rows) {
+            size_t c = h->first_rows ? h->cap_groups * 4 : 0; AQG_TRY(dev_realloc(ctx, (void**)&h->first_rows, &c, gcapn * 4));
+            c = h->counts ? h->cap_groups * 4 : 0; AQG_TRY(dev_realloc(ctx, (void**)&h->counts, &c, gcapn * 4));
+            if (h->cap_groups < gcapn) h->cap_groups = gcapn;
+        }
+    }
+    es.first_out = h->first_rows;
+    h->has_counts = plan.need_count && !for_build;
+    es.count_out = h->has_counts ? h->counts : nullptr;
+    es.nagg = plan.nagg;
+    h->nagg = plan.nagg;
+    for (int j = 0; j < plan.nagg; ++j) {
+        es.agg[j] = plan.agg[j];
+        h->res_dt[j] = aqg_reduce_out_dtype(plan.agg[j].op, plan.agg[j].dt);
+        AQG_TRY(dev_realloc(ctx, &h->results[j], &h->cap_results[j], gcapn * 16));
+        es.agg[j].out = h->results[j];
+    }
+    if (G) {
+        unsigned eg = aqg_grid(ctx, G, 256, 1, 8);
+        hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt, occ, gid_of_occ, es);
+        AQG_TRY(aqg_check_launch(ctx, "emit_kernel"));
+    }
+    if (gt_out) *gt_out = gt;
+    if (slot_gid_out) *slot_gid_out = slot_gid;
+    return AQG_OK;
+}
+
+int run_with_retry(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
+                   GTable* gt_out, uint32_t** slot_gid_out) {
+    uint64_t cur = hint ? hint : (h->hint_used ? h->hint_used : 1024);
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        if (cur > n && n) cur = n;
+        int rc = run_agg(ctx, ks, plan, n, (uint32_t)cur, for_build, h, gt_out, slot_gid_out);
+        if (rc != AQG_ERR_OVERFLOW) { if (rc == AQG_OK) h->hint_used = (uint32_t)cur; return rc; }
+        if (n && cur >= n) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "group-by: table overflow at full capacity");
+        cur *= 16;
+    }
+    return aqg_fail(ctx, AQG_ERR_OVERFLOW, "group-by: table overflow");
+}
+
+} // namespace
+
+extern "C" {
+
+void aqg_groupby_destroy(aqg_groupby* g) {
+    if (!g) return;
+    if (g->ctx) hipStreamSynchronize(g->ctx->stream);
+    for (int k = 0; k < MAXKEYS; ++k) if (g->keys_out[k]) hipFree(g->keys_out[k]);
+    for (int j = 0; j < MAXAGG; ++j) if (g->results[j]) hipFree(g->results[j]);
+    if (g->first_rows) hipFree(g->first_rows);
+    if (g->counts) hipFree(g->counts);
+    if (g->reversemap) hipFree(g->reversemap);
+    delete g;
+}
+uint32_t aqg_groupby_ngroups(const aqg_groupby* g) { return g ? g->ngroups : 0; }
+uint32_t aqg_groupby_nrows(const aqg_groupby* g) { return g ? g->n : 0; }
+const uint32_t* aqg_groupby_reversemap(const aqg_groupby* g) { return g && g->has_reversemap ? g->reversemap : nullptr; }
+const uint32_t* aqg_groupby_counts(const aqg_groupby* g) { return g && g->has_counts ? g->counts : nullptr; }
+const uint32_t* aqg_groupby_first_rows(const aqg_groupby* g) { return g ? g->first_rows : nullptr; }
+const void* aqg_groupby_agg_result(const aqg_groupby* g, int j) { return g && j >= 0 && j < g->nagg ? g->results[j] : nullptr; }
+
+int aqg_groupby_keys(aqg_groupby* g, int k, void* out_dev) {
+    if (!g || k < 0 || k >= g->nkeys || !out_dev) return AQG_ERR_ARG;
+    aqg_ctx* ctx = g->ctx;
+    if (!g->ngroups) return AQG_OK;
+    AQG_HIP(ctx, hipMemcpyAsync(out_dev, g->keys_out[k], (size_t)g->ngroups * aqg_dtype_size(g->key_dt[k]), hipMemcpyDeviceToDevice, ctx->stream));
+    return AQG_OK;
+}
+
+int aqg_groupby_agg(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* const* keys, int naggs, const int* ops,
+                    const int* val_dtypes, const void* const* vals, uint32_t n, uint32_t max_groups_hint, aqg_groupby** out) {
+    if (!ctx || !out || !key_dtypes || !keys) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_agg: bad argument");
+    KeySpec ks;
+    AQG_TRY(make_keyspec(ctx, nkeys, key_dtypes, keys, n, &ks));
+    Plan plan;
+    AQG_TRY(make_plan(ctx, naggs, ops, val_dtypes, vals, n, &plan));
+    aqg_groupby* h = *out ? *out : new aqg_groupby();
+    h->ctx = ctx; h->n = n; h->has_reversemap = false;
+    int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, false, h, nullptr, nullptr);
+    if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
+    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = h;
+    return AQG_OK;
+}
+
+int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* const* keys, uint32_t n,
+                      uint32_t max_groups_hint, aqg_groupby** out) {
+    if (!ctx || !out || !key_dtypes || !keys) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_build: bad argument");
+    KeySpec ks;
+    AQG_TRY(make_keyspec(ctx, nkeys, key_dtypes, keys, n, &ks));
+    Plan plan;
+    memset(&plan, 0, sizeof plan);
+    aqg_groupby* h = *out ? *out : new aqg_groupby();
+    h->ctx = ctx; h->n = n;
+    GTable gt; uint32_t* slot_gid = nullptr;
+    int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, true, h, &gt, &slot_gid);
+    if (rc == AQG_OK) {
+        size_t c = h->reversemap ? h->cap_rows * 4 : 0;
+        rc = dev_realloc(ctx, (void**)&h->reversemap, &c, ((size_t)n + 4) * 4);
+        if (rc == AQG_OK) h->cap_rows = c / 4;
+    }
+    if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
+    uint32_t G = h->ngroups;
+    if (n) {
+        hipMemsetAsync(h->counts, 0, (size_t)(G ? G : 1) * 4, ctx->stream);
+        unsigned grid = aqg_grid(ctx, n / 4 + 1, 256, 2, 8);
+        if (G <= 8192) {
+            size_t lds = (size_t)G * 4 + 16;
+            hipLaunchKernelGGL((assign_kernel<true>), dim3(grid), dim3(256), lds, ctx->stream, ks, gt, slot_gid, n, G, h->reversemap, h->counts);
+        } else {
+            hipLaunchKernelGGL((assign_kernel<false>), dim3(grid), dim3(256), 0, ctx->stream, ks, gt, slot_gid, n, G, h->reversemap, h->counts);
+        }
+        rc = aqg_check_launch(ctx, "assign_kernel");
+        if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
+    }
+    h->has_counts = true; h->has_reversemap = true;
+    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = h;
+    return AQG_OK;
+}
+
+} // extern "C"

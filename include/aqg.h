@@ -160,10 +160,10 @@ int aqg_mask_to_index(aqg_ctx* ctx, const uint8_t* mask, uint32_t n, uint32_t* i
  * Contract (the only executable one in the reference):
  *   group ids are dense, numbered by FIRST OCCURRENCE of the key tuple;
  *   ht_postproc row-id lists are DESCENDING row id within each group.
- * `row_base` is added to row ids (row-range shards keep global ids).           */
+ * Key tuples of up to 8 bytes in total (e.g. two int32 columns) are supported.   */
 typedef struct aqg_groupby aqg_groupby;
 int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* const* keys,
-                      uint32_t n, aqg_groupby** out);
+                      uint32_t n, uint32_t max_groups_hint, aqg_groupby** out);
 void aqg_groupby_destroy(aqg_groupby* g);
 uint32_t aqg_groupby_ngroups(const aqg_groupby* g);
 uint32_t aqg_groupby_nrows(const aqg_groupby* g);
@@ -182,13 +182,19 @@ int aqg_groupby_postproc(aqg_groupby* g, uint32_t* offsets_dev, uint32_t* row_id
  * (engine/ast.py:722-789, mem_opt.cpp:50-65).  Output dtype as aqg_reduce.     */
 int aqg_grouped_reduce(aqg_ctx* ctx, const aqg_groupby* g, int op, int t, const void* x, void* out_dev);
 
-/* fused single-pass group-by + aggregates (h2o Q1..Q5 shape): reads each key and
- * value column exactly once.  outs[j] has ngroups elements of
- * aqg_reduce_out_dtype(ops[j], val_dtypes[j]); group order = first occurrence.
- * On return *out holds keys/counts/first_rows (no reversemap / postproc).       */
+/* fused single-pass group-by + aggregates (h2o Q1..Q5 shape): reads each key and value
+ * column exactly once.  Group order = first occurrence, as aqg_groupby_build.  Result j
+ * (aqg_groupby_agg_result) has ngroups elements of aqg_reduce_out_dtype(ops[j], val_dtypes[j])
+ * and lives in the handle, like keys / first_rows (and counts when an op needs them); no
+ * reversemap / postproc on such a handle.  ops: SUM MIN MAX COUNT AVG VAR STDDEV.
+ * `*out` is in/out: pass NULL to create a handle, or an earlier handle to reuse its buffers
+ * (steady-state calls then allocate nothing).  max_groups_hint sizes the hash tables
+ * (0 = unknown: start small and grow); the call retries internally when the hint is too low.
+ * Synchronous: on return the handle's ngroups is final.                                         */
 int aqg_groupby_agg(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* const* keys,
                     int naggs, const int* ops, const int* val_dtypes, const void* const* vals,
-                    uint32_t n, uint32_t max_groups_hint, aqg_groupby** out, void* const* outs_dev);
+                    uint32_t n, uint32_t max_groups_hint, aqg_groupby** out);
+const void* aqg_groupby_agg_result(const aqg_groupby* g, int j);
 
 /* ---- hash join (new functionality; reference runs joins in MonetDB)
  * inner equi-join on one integer key: build on (build_keys, nb), probe with
