@@ -4,6 +4,7 @@ There is NO fallback: if libaqg.so is missing or no GPU is visible, construction
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -73,6 +74,14 @@ class DevBuf:
     def tag(self):
         return NP2TAG[self.dtype] if self.dtype in NP2TAG else (INT128 if self.dtype == I128 else UINT128)
 
+    @property
+    def __cuda_array_interface__(self):
+        """zero-copy view for torch.as_tensor(buf, device="cuda") (bench.py's RCCL merge); 128-bit
+        columns are exposed as 2n int64 words"""
+        if self.dtype.names:
+            return {"shape": (2 * self.n,), "typestr": "<i8", "data": (int(self.ptr), False), "version": 3}
+        return {"shape": (self.n,), "typestr": self.dtype.str, "data": (int(self.ptr), False), "version": 3}
+
     def to_host(self):
         out = np.empty(self.n, dtype=self.dtype)
         if self.n:
@@ -81,9 +90,9 @@ class DevBuf:
         return out
 
     def free(self):
-        if self.owned and self.ptr:
+        if self.owned and self.ptr and self.dev.ctx:
             self.dev.lib.aqg_free(self.dev.ctx, C.c_void_p(self.ptr))
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -95,6 +104,7 @@ class DevBuf:
 class GroupBy:
     def __init__(self, dev, handle):
         self.dev, self.h = dev, handle
+        dev._handles.add(self)
 
     @property
     def ngroups(self):
@@ -134,9 +144,9 @@ class GroupBy:
         return off.to_host(), rows.to_host()[:n]
 
     def destroy(self):
-        if self.h:
+        if self.h and self.dev.ctx:
             self.dev.lib.aqg_groupby_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -155,9 +165,12 @@ class Device:
         if rc != 0:
             raise AqgError("aqg_ctx_create (no MI355X visible? the HIP path has no CPU fallback)", rc)
         self.ctx = ctx
+        self._handles = weakref.WeakSet()
 
     def close(self):
         if self.ctx:
+            for h in list(self._handles):   # handles hold device memory of this context: release them first
+                h.destroy()
             self.lib.aqg_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -336,6 +349,11 @@ class Device:
     # -- timing
     def timer_start(self):
         self._chk(self.lib.aqg_timer_start(self.ctx), "aqg_timer_start")
+
+    def last_kernel_ms(self):
+        ms = C.c_float()
+        self._chk(self.lib.aqg_last_kernel_ms(self.ctx, C.byref(ms)), "aqg_last_kernel_ms")
+        return ms.value
 
     def timer_stop_ms(self):
         ms = C.c_float()

@@ -24,6 +24,8 @@ struct aqg_ctx {
     char* ws = nullptr;
     size_t ws_cap = 0, ws_off = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t evk0 = nullptr, evk1 = nullptr;   // bracket the dominant kernel of the last call
+    bool evk_valid = false;
     std::unordered_map<const void*, aqg_pin> pins;
     // pinned host staging for small results
     void* host_stage = nullptr;
@@ -63,6 +65,10 @@ template <class T> static inline int aqg_ws_get(aqg_ctx* ctx, size_t count, T** 
     return rc;
 }
 int aqg_host_stage(aqg_ctx* ctx, size_t bytes, void** out);
+
+// HIP events around the dominant kernel of a call (read back by aqg_last_kernel_ms)
+static inline void aqg_kernel_timer_begin(aqg_ctx* ctx) { (void)hipEventRecord(ctx->evk0, ctx->stream); }
+static inline void aqg_kernel_timer_end(aqg_ctx* ctx) { (void)hipEventRecord(ctx->evk1, ctx->stream); ctx->evk_valid = true; }
 
 // launch check
 static inline int aqg_check_launch(aqg_ctx* ctx, const char* what) {

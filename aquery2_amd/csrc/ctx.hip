@@ -81,6 +81,8 @@ int aqg_ctx_create(int device, void* hip_stream, aqg_ctx** out) {
     }
     hipEventCreate(&ctx->ev0);
     hipEventCreate(&ctx->ev1);
+    hipEventCreate(&ctx->evk0);
+    hipEventCreate(&ctx->evk1);
     *out = ctx;
     return AQG_OK;
 }
@@ -94,6 +96,8 @@ void aqg_ctx_destroy(aqg_ctx* ctx) {
     if (ctx->host_stage) hipHostFree(ctx->host_stage);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->evk0) hipEventDestroy(ctx->evk0);
+    if (ctx->evk1) hipEventDestroy(ctx->evk1);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -187,6 +191,14 @@ int aqg_timer_stop_ms(aqg_ctx* ctx, float* ms) {
     AQG_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     AQG_HIP(ctx, hipEventSynchronize(ctx->ev1));
     AQG_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return AQG_OK;
+}
+
+int aqg_last_kernel_ms(aqg_ctx* ctx, float* ms) {
+    if (!ctx || !ms) return AQG_ERR_ARG;
+    if (!ctx->evk_valid) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_last_kernel_ms: no timed kernel yet");
+    AQG_HIP(ctx, hipEventSynchronize(ctx->evk1));
+    AQG_HIP(ctx, hipEventElapsedTime(ms, ctx->evk0, ctx->evk1));
     return AQG_OK;
 }
 

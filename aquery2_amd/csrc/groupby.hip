@@ -34,7 +34,9 @@ enum : int { ACC_ADD_I = 0, ACC_ADD_F = 1, ACC_MIN = 2, ACC_MAX = 3 };
 enum : int { VC_I = 0, VC_U = 1, VC_F = 2 };   // value class of a column: signed / unsigned / floating
 
 struct KeySpec { int nkeys; int dt[MAXKEYS]; const void* col[MAXKEYS]; int shift[MAXKEYS]; int total_bytes; };
-struct AccSpec { int nacc; int kind[MAXACC]; int dt[MAXACC]; const void* col[MAXACC]; int square[MAXACC]; };
+// square: accumulate x*x (in the promoted type).  part: 0 whole value; 1 / 2 = low / high 32 bits of an 8-byte
+// integer, so that sums of 8-byte integers stay exact (the two 64-bit accumulators cannot overflow for n < 2^32)
+struct AccSpec { int nacc; int kind[MAXACC]; int dt[MAXACC]; const void* col[MAXACC]; int square[MAXACC]; int part[MAXACC]; };
 struct GTable {
     uint64_t* keys;      // [cap+1]  EMPTY64; slot `cap` holds the group whose packed key equals EMPTY64
     uint32_t* first;     // [cap+1]  NOROW
@@ -87,7 +89,14 @@ __device__ inline uint64_t pack_key(const KeySpec& ks, size_t i) {
 // value of element i as the 64-bit operand of its accumulator
 //   ADD_I: two's complement int64 (unsigned inputs zero-extended), `x*x` in the promoted type if square
 //   ADD_F: double bits; MIN/MAX: order-preserving map
-template <class T> __device__ inline uint64_t val_operand_t(T v, int kind, int square) {
+template <class T> __device__ inline uint64_t val_operand_t(T v, int kind, int square, int part = 0) {
+    if constexpr (sizeof(T) == 8 && std::is_integral_v<T>) {
+        if (kind == ACC_ADD_I && part) {
+            uint64_t b = square ? (uint64_t)v * (uint64_t)v : (uint64_t)v;
+            if (part == 1) return b & 0xFFFFFFFFull;
+            if constexpr (std::is_unsigned_v<T>) return b >> 32; else return (uint64_t)((int64_t)b >> 32);
+        }
+    }
     if constexpr (std::is_floating_point_v<T>) {
         double d = square ? (double)(v * v) : (double)v;
         return kind == ACC_ADD_F ? __builtin_bit_cast(uint64_t, d) : map_f(d);
@@ -104,38 +113,38 @@ template <class T> __device__ inline uint64_t val_operand_t(T v, int kind, int s
         if constexpr (std::is_unsigned_v<T>) return (uint64_t)v; else return map_i((int64_t)v);
     }
 }
-__device__ inline uint64_t val_operand(int dt, const void* col, size_t i, int kind, int square) {
+__device__ inline uint64_t val_operand(int dt, const void* col, size_t i, int kind, int square, int part) {
     switch (dt) {
     case AQG_INT8: return val_operand_t(static_cast<const int8_t*>(col)[i], kind, square);
     case AQG_INT16: return val_operand_t(static_cast<const int16_t*>(col)[i], kind, square);
     case AQG_INT32: return val_operand_t(static_cast<const int32_t*>(col)[i], kind, square);
-    case AQG_INT64: return val_operand_t(static_cast<const int64_t*>(col)[i], kind, square);
+    case AQG_INT64: return val_operand_t(static_cast<const int64_t*>(col)[i], kind, square, part);
     case AQG_UINT8: case AQG_BOOL: return val_operand_t(static_cast<const uint8_t*>(col)[i], kind, square);
     case AQG_UINT16: return val_operand_t(static_cast<const uint16_t*>(col)[i], kind, square);
     case AQG_UINT32: return val_operand_t(static_cast<const uint32_t*>(col)[i], kind, square);
-    case AQG_UINT64: return val_operand_t(static_cast<const uint64_t*>(col)[i], kind, square);
+    case AQG_UINT64: return val_operand_t(static_cast<const uint64_t*>(col)[i], kind, square, part);
     case AQG_FLOAT: return val_operand_t(static_cast<const float*>(col)[i], kind, square);
     default: return val_operand_t(static_cast<const double*>(col)[i], kind, square);
     }
 }
 // four consecutive rows of a 4-byte column with one 16-byte load
-template <class T> __device__ inline void val_operand4_t(const void* col, size_t base, int kind, int square, uint64_t (&o)[4]) {
+template <class T> __device__ inline void val_operand4_t(const void* col, size_t base, int kind, int square, int part, uint64_t (&o)[4]) {
     pack<T, 4> v = *reinterpret_cast<const pack<T, 4>*>(static_cast<const T*>(col) + base);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = val_operand_t(v.v[j], kind, square);
+    for (int j = 0; j < 4; ++j) o[j] = val_operand_t(v.v[j], kind, square, part);
 }
-__device__ inline void val_operand4(int dt, const void* col, size_t base, int kind, int square, uint64_t (&o)[4]) {
+__device__ inline void val_operand4(int dt, const void* col, size_t base, int kind, int square, int part, uint64_t (&o)[4]) {
     switch (dt) {
-    case AQG_INT8: val_operand4_t<int8_t>(col, base, kind, square, o); break;
-    case AQG_INT16: val_operand4_t<int16_t>(col, base, kind, square, o); break;
-    case AQG_INT32: val_operand4_t<int32_t>(col, base, kind, square, o); break;
-    case AQG_INT64: val_operand4_t<int64_t>(col, base, kind, square, o); break;
-    case AQG_UINT8: case AQG_BOOL: val_operand4_t<uint8_t>(col, base, kind, square, o); break;
-    case AQG_UINT16: val_operand4_t<uint16_t>(col, base, kind, square, o); break;
-    case AQG_UINT32: val_operand4_t<uint32_t>(col, base, kind, square, o); break;
-    case AQG_UINT64: val_operand4_t<uint64_t>(col, base, kind, square, o); break;
-    case AQG_FLOAT: val_operand4_t<float>(col, base, kind, square, o); break;
-    default: val_operand4_t<double>(col, base, kind, square, o); break;
+    case AQG_INT8: val_operand4_t<int8_t>(col, base, kind, square, part, o); break;
+    case AQG_INT16: val_operand4_t<int16_t>(col, base, kind, square, part, o); break;
+    case AQG_INT32: val_operand4_t<int32_t>(col, base, kind, square, part, o); break;
+    case AQG_INT64: val_operand4_t<int64_t>(col, base, kind, square, part, o); break;
+    case AQG_UINT8: case AQG_BOOL: val_operand4_t<uint8_t>(col, base, kind, square, part, o); break;
+    case AQG_UINT16: val_operand4_t<uint16_t>(col, base, kind, square, part, o); break;
+    case AQG_UINT32: val_operand4_t<uint32_t>(col, base, kind, square, part, o); break;
+    case AQG_UINT64: val_operand4_t<uint64_t>(col, base, kind, square, part, o); break;
+    case AQG_FLOAT: val_operand4_t<float>(col, base, kind, square, part, o); break;
+    default: val_operand4_t<double>(col, base, kind, square, part, o); break;
     }
 }
 
@@ -186,25 +195,29 @@ __device__ inline void gt_touch_first(const GTable& gt, uint32_t s, uint32_t row
 // ---- the single-pass aggregation kernel -------------------------------------------------------
 // K32: one 4-byte key column (h2o Q1/Q3/Q4/Q5).  LDS slot = {key32, first_row32} in one 8-byte
 // word, so a hit costs one ds_read_b64 + one LDS atomic per accumulator.
-template <bool USE_LDS, bool K32>
-__global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable gt, uint32_t n, uint32_t lcap, int need_count) {
+template <bool USE_LDS, bool K32, int NACC>
+__global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable gt, uint32_t n, uint32_t lcap, int need_count, uint32_t lrep) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS layout (USE_LDS): lkey u64[lcap+1] | lacc[a] u64[lcap+1] ... | lfirst u32[lcap+1] (wide keys) | lcount u32[lcap+1] | lused u32
+    // `lrep` replicas of the table (lane l uses replica l % lrep) cut same-address / same-bank conflicts
+    // of the LDS atomics when there are fewer groups than lanes
+    const uint32_t LT = USE_LDS ? lrep * (lcap + 1) : 0;   // total LDS slots
     uint64_t* lkey = reinterpret_cast<uint64_t*>(smem_raw);
-    uint64_t* lacc = lkey + (lcap + 1);
-    uint32_t* lfirst = reinterpret_cast<uint32_t*>(lacc + (size_t)as.nacc * (lcap + 1));
-    uint32_t* lcount = lfirst + (K32 ? 0 : (lcap + 1));
-    uint32_t* lused = lcount + (need_count ? (lcap + 1) : 0);
+    uint64_t* lacc = lkey + LT;
+    uint32_t* lfirst = reinterpret_cast<uint32_t*>(lacc + (size_t)NACC * LT);
+    uint32_t* lcount = lfirst + (K32 ? 0 : LT);
+    uint32_t* lused = lcount + (need_count ? LT : 0);
+    const uint32_t rbase = USE_LDS ? (threadIdx.x & (lrep - 1)) * (lcap + 1) : 0;
     const uint32_t lmask = lcap - 1;
     const uint32_t llimit = lcap - (lcap >> 2);   // stop inserting at 75 % load; further new keys go to HBM
 
     if constexpr (USE_LDS) {
-        for (uint32_t s = threadIdx.x; s <= lcap; s += blockDim.x) {
+        for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) {
             if constexpr (K32) lkey[s] = ((uint64_t)NOROW << 32) | EMPTY32; else { lkey[s] = EMPTY64; lfirst[s] = NOROW; }
-            for (int a = 0; a < as.nacc; ++a) lacc[(size_t)a * (lcap + 1) + s] = acc_init(as.kind[a]);
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) lacc[(size_t)a * LT + s] = acc_init(as.kind[a]);
             if (need_count) lcount[s] = 0;
         }
-        if (threadIdx.x == 0) *lused = 0;
+        if (threadIdx.x < lrep) lused[threadIdx.x] = 0;
         __syncthreads();
     }
 
@@ -212,32 +225,35 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
     auto lds_slot = [&](uint64_t key) -> uint32_t {
         if constexpr (K32) {
             uint32_t k = (uint32_t)key;
-            if (k == EMPTY32) return lcap;
-            uint32_t* kw = reinterpret_cast<uint32_t*>(lkey);
+            if (k == EMPTY32) return rbase + lcap;
+            uint32_t* kw = reinterpret_cast<uint32_t*>(lkey + rbase);
+            uint32_t* used = lused + (threadIdx.x & (lrep - 1));
             uint32_t s = hash32(k) & lmask;
             for (uint32_t p = 0; p <= lmask; ++p) {
                 uint32_t cur = kw[2 * s];
-                if (cur == k) return s;
+                if (cur == k) return rbase + s;
                 if (cur == EMPTY32) {
-                    if (*lused >= llimit) return FAIL;
+                    if (*used >= llimit) return FAIL;
                     uint32_t old = atomicCAS(&kw[2 * s], EMPTY32, k);
-                    if (old == EMPTY32) { atomicAdd(lused, 1u); return s; }
-                    if (old == k) return s;
+                    if (old == EMPTY32) { atomicAdd(used, 1u); return rbase + s; }
+                    if (old == k) return rbase + s;
                 }
                 s = (s + 1) & lmask;
             }
             return FAIL;
         } else {
-            if (key == EMPTY64) return lcap;
+            if (key == EMPTY64) return rbase + lcap;
+            uint64_t* kw = lkey + rbase;
+            uint32_t* used = lused + (threadIdx.x & (lrep - 1));
             uint32_t s = hash64(key) & lmask;
             for (uint32_t p = 0; p <= lmask; ++p) {
-                uint64_t cur = lkey[s];
-                if (cur == key) return s;
+                uint64_t cur = kw[s];
+                if (cur == key) return rbase + s;
                 if (cur == EMPTY64) {
-                    if (*lused >= llimit) return FAIL;
-                    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&lkey[s]), EMPTY64, key);
-                    if (old == EMPTY64) { atomicAdd(lused, 1u); return s; }
-                    if (old == key) return s;
+                    if (*used >= llimit) return FAIL;
+                    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&kw[s]), EMPTY64, key);
+                    if (old == EMPTY64) { atomicAdd(used, 1u); return rbase + s; }
+                    if (old == key) return rbase + s;
                 }
                 s = (s + 1) & lmask;
             }
@@ -255,7 +271,7 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
         if (g == FAIL) return;
         gt_touch_first(gt, g, row);
         if (need_count) atomicAdd(&gt.count[g], 1u);
-        for (int a = 0; a < as.nacc; ++a) acc_apply(&gt.acc[a][g], as.kind[a], vals[a]);
+        _Pragma("unroll") for (int a = 0; a < NACC; ++a) acc_apply(&gt.acc[a][g], as.kind[a], vals[a]);
     };
 
     const uint32_t nchunk = n >> 2;   // 4 consecutive rows per lane per step
@@ -271,21 +287,69 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
 #pragma unroll
             for (int j = 0; j < 4; ++j) key[j] = pack_key(ks, base + j);
         }
-        uint64_t vals[MAXACC][4];
-        for (int a = 0; a < as.nacc; ++a) val_operand4(as.dt[a], as.col[a], base, as.kind[a], as.square[a], vals[a]);
+        uint64_t vals[NACC ? NACC : 1][4];
+        _Pragma("unroll") for (int a = 0; a < NACC; ++a) val_operand4(as.dt[a], as.col[a], base, as.kind[a], as.square[a], as.part[a], vals[a]);
+        uint32_t slot[4];
+        if constexpr (USE_LDS) {
+            // speculative first probe of all four rows at once: one LDS round trip in the common (hit) case
+            uint64_t w[4];
+            if constexpr (K32) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { slot[j] = rbase + (hash32((uint32_t)key[j]) & lmask); w[j] = lkey[slot[j]]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t row = (uint32_t)base + j;
+                    if ((uint32_t)w[j] == (uint32_t)key[j] && (uint32_t)key[j] != EMPTY32) {
+                        if (row < (uint32_t)(w[j] >> 32)) atomicMin(reinterpret_cast<uint32_t*>(lkey) + 2 * slot[j] + 1, row);
+                    } else {
+                        slot[j] = lds_slot(key[j]);
+                        if (slot[j] != FAIL) lds_touch_first(slot[j], row);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { slot[j] = rbase + (hash64(key[j]) & lmask); w[j] = lkey[slot[j]]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (!(w[j] == key[j] && key[j] != EMPTY64)) slot[j] = lds_slot(key[j]);
+                    if (slot[j] != FAIL) lds_touch_first(slot[j], (uint32_t)base + j);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slot[j] = FAIL;
+        }
+        if (need_count) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (slot[j] != FAIL) atomicAdd(&lcount[slot[j]], 1u);
+        }
+        _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+            uint64_t* la = lacc + (size_t)a * LT;
+            switch (as.kind[a]) {   // wave-uniform: one branch per accumulator per four rows
+            case ACC_ADD_I:
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)vals[a][j]);
+                break;
+            case ACC_ADD_F:
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<double*>(&la[slot[j]]), __builtin_bit_cast(double, vals[a][j]));
+                break;
+            case ACC_MIN:
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (slot[j] != FAIL) atomicMin(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)vals[a][j]);
+                break;
+            default:
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (slot[j] != FAIL) atomicMax(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)vals[a][j]);
+                break;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            uint32_t row = (uint32_t)base + j;
-            uint32_t s = FAIL;
-            if constexpr (USE_LDS) s = lds_slot(key[j]);
-            if (s != FAIL) {
-                lds_touch_first(s, row);
-                if (need_count) atomicAdd(&lcount[s], 1u);
-                for (int a = 0; a < as.nacc; ++a) acc_apply(&lacc[(size_t)a * (lcap + 1) + s], as.kind[a], vals[a][j]);
-            } else {
-                uint64_t v1[MAXACC];
-                for (int a = 0; a < as.nacc; ++a) v1[a] = vals[a][j];
-                to_global(key[j], row, v1);
+            if (slot[j] == FAIL) {   // LDS table full (or HBM mode): straight to the global table
+                uint64_t v1[NACC ? NACC : 1];
+                _Pragma("unroll") for (int a = 0; a < NACC; ++a) v1[a] = vals[a][j];
+                to_global(key[j], (uint32_t)base + j, v1);
             }
         }
     }
@@ -294,8 +358,8 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
         uint32_t row = (nchunk << 2) + threadIdx.x;
         if (row < n) {
             uint64_t k = pack_key(ks, row);
-            uint64_t v1[MAXACC];
-            for (int a = 0; a < as.nacc; ++a) v1[a] = val_operand(as.dt[a], as.col[a], row, as.kind[a], as.square[a]);
+            uint64_t v1[NACC ? NACC : 1];
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) v1[a] = val_operand(as.dt[a], as.col[a], row, as.kind[a], as.square[a], as.part[a]);
             to_global(k, row, v1);
         }
     }
@@ -303,7 +367,7 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
     if constexpr (USE_LDS) {
         __syncthreads();
         // merge this workgroup's table into the global one
-        for (uint32_t s = threadIdx.x; s <= lcap; s += blockDim.x) {
+        for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) {
             uint64_t key; uint32_t first;
             if constexpr (K32) {
                 uint64_t w = lkey[s];
@@ -315,7 +379,7 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
             if (g == FAIL) continue;
             atomicMin(&gt.first[g], first);
             if (need_count) atomicAdd(&gt.count[g], lcount[s]);
-            for (int a = 0; a < as.nacc; ++a) acc_apply(&gt.acc[a][g], as.kind[a], lacc[(size_t)a * (lcap + 1) + s]);
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) acc_apply(&gt.acc[a][g], as.kind[a], lacc[(size_t)a * LT + s]);
         }
     }
 }
@@ -422,6 +486,12 @@ __device__ inline aqg_i128 mul_i64(int64_t a, int64_t b) {   // exact signed 64x
     r.hi = (uint64_t)__mul64hi(a, b);
     return r;
 }
+__device__ inline aqg_i128 mul_128(aqg_i128 a, aqg_i128 b) {   // low 128 bits of the product (two's complement: sign-agnostic)
+    aqg_i128 r;
+    r.lo = a.lo * b.lo;
+    r.hi = __umul64hi(a.lo, b.lo) + a.lo * b.hi + a.hi * b.lo;
+    return r;
+}
 __device__ inline aqg_i128 mul_u64(uint64_t a, uint64_t b) {
     aqg_i128 r;
     r.lo = a * b;
@@ -430,7 +500,7 @@ __device__ inline aqg_i128 mul_u64(uint64_t a, uint64_t b) {
 }
 
 // what each requested aggregate reads from the accumulators
-struct AggOut { int op; int dt; int acc0; int acc1; void* out; };
+struct AggOut { int op; int dt; int acc0; int acc1; int acc2; int acc3; void* out; };   // wide (8-byte integer) sums: acc0/acc2 = low, acc1/acc3 = high halves
 struct EmitSpec { int nagg; AggOut agg[MAXAGG]; int nkeys; int key_dt[MAXKEYS]; int key_shift[MAXKEYS]; void* key_out[MAXKEYS];
                   uint32_t* first_out; uint32_t* count_out; };
 
@@ -465,27 +535,37 @@ __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __
         for (int j = 0; j < es.nagg; ++j) {
             const AggOut& a = es.agg[j];
             int vc = vclass(a.dt);
-            uint64_t v0 = a.acc0 >= 0 ? gt.acc[a.acc0][s] : 0, v1 = a.acc1 >= 0 ? gt.acc[a.acc1][s] : 0;
+            uint64_t v0 = a.acc0 >= 0 ? gt.acc[a.acc0][s] : 0;
+            const bool wide = a.dt == AQG_INT64 || a.dt == AQG_UINT64;
+            // exact 128-bit sum (and sum of squares) of an integer column
+            auto sum128 = [&](int lo_acc, int hi_acc) -> aqg_i128 {
+                uint64_t lo = gt.acc[lo_acc][s];
+                if (!wide) return vc == VC_U ? i128_from_u64(lo) : i128_from_i64((int64_t)lo);
+                uint64_t hi = gt.acc[hi_acc][s];                       // sum of the high halves, to be shifted by 32
+                aqg_i128 h = vc == VC_U ? i128_from_u64(hi) : i128_from_i64((int64_t)hi);
+                aqg_i128 sh = {h.lo << 32, (h.hi << 32) | (h.lo >> 32)};
+                return i128_add(sh, i128_from_u64(lo));
+            };
+            auto to_double = [&](aqg_i128 v) -> double { return vc == VC_U ? u128_to_double(v.hi, v.lo) : i128_to_double(v); };
             switch (a.op) {
             case AQG_RED_SUM:                                               // -> GetLongType
                 if (vc == VC_F) static_cast<double*>(a.out)[g] = __builtin_bit_cast(double, v0);
-                else static_cast<aqg_i128*>(a.out)[g] = vc == VC_U ? i128_from_u64(v0) : i128_from_i64((int64_t)v0);
+                else static_cast<aqg_i128*>(a.out)[g] = sum128(a.acc0, a.acc1);
                 break;
             case AQG_RED_COUNT: static_cast<uint64_t*>(a.out)[g] = cnt; break;
             case AQG_RED_AVG: {                                             // sum / (double)size
-                double sd = vc == VC_F ? __builtin_bit_cast(double, v0) : vc == VC_U ? (double)v0 : (double)(int64_t)v0;
+                double sd = vc == VC_F ? __builtin_bit_cast(double, v0) : to_double(sum128(a.acc0, a.acc1));
                 static_cast<double*>(a.out)[g] = sd / (double)cnt;
             } break;
             case AQG_RED_VAR: case AQG_RED_STDDEV: {                        // (ssq - s*s/(double)(n+1)) / (double)(n+1)
                 double np1 = (double)(uint32_t)(cnt + 1), d;
                 if (vc == VC_F) {
-                    double sd = __builtin_bit_cast(double, v0), q = __builtin_bit_cast(double, v1);
+                    double sd = __builtin_bit_cast(double, v0), q = __builtin_bit_cast(double, gt.acc[a.acc2][s]);
                     d = (q - sd * sd / np1) / np1;
-                } else if (vc == VC_U) {
-                    aqg_i128 ss = mul_u64(v0, v0);
-                    d = ((double)v1 - u128_to_double(ss.hi, ss.lo) / np1) / np1;
                 } else {
-                    d = ((double)(int64_t)v1 - i128_to_double(mul_i64((int64_t)v0, (int64_t)v0)) / np1) / np1;
+                    aqg_i128 sm = sum128(a.acc0, a.acc1), q = sum128(a.acc2, a.acc3);
+                    aqg_i128 ss = mul_128(sm, sm);                          // s * s in the 128-bit LongType (wraps like the reference)
+                    d = (to_double(q) - to_double(ss) / np1) / np1;
                 }
                 static_cast<double*>(a.out)[g] = a.op == AQG_RED_STDDEV ? sqrt(d) : d;
             } break;
@@ -613,12 +693,12 @@ struct Plan {
     AggOut agg[MAXAGG];
 };
 
-int add_acc(Plan* p, int kind, int dt, const void* col, int square) {
+int add_acc(Plan* p, int kind, int dt, const void* col, int square, int part = 0) {
     for (int a = 0; a < p->as.nacc; ++a)
-        if (p->as.kind[a] == kind && p->as.dt[a] == dt && p->as.col[a] == col && p->as.square[a] == square) return a;
+        if (p->as.kind[a] == kind && p->as.dt[a] == dt && p->as.col[a] == col && p->as.square[a] == square && p->as.part[a] == part) return a;
     if (p->as.nacc >= MAXACC) return -1;
     int a = p->as.nacc++;
-    p->as.kind[a] = kind; p->as.dt[a] = dt; p->as.col[a] = col; p->as.square[a] = square;
+    p->as.kind[a] = kind; p->as.dt[a] = dt; p->as.col[a] = col; p->as.square[a] = square; p->as.part[a] = part;
     return a;
 }
 
@@ -632,24 +712,26 @@ int make_plan(aqg_ctx* ctx, int naggs, const int* ops, const int* dts, const voi
         if (!vals[j] && n && op != AQG_RED_COUNT) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: null value column");
         bool fp = dt_is_fp(dt);
         AggOut& a = p->agg[j];
-        a.op = op; a.dt = dt; a.acc0 = a.acc1 = -1; a.out = nullptr;
+        a.op = op; a.dt = dt; a.acc0 = a.acc1 = a.acc2 = a.acc3 = -1; a.out = nullptr;
+        const bool wide = dt == AQG_INT64 || dt == AQG_UINT64;
+        const int addk = fp ? ACC_ADD_F : ACC_ADD_I;
+        bool ok = true;
         switch (op) {
-        case AQG_RED_SUM: a.acc0 = add_acc(p, fp ? ACC_ADD_F : ACC_ADD_I, dt, vals[j], 0); break;
-        case AQG_RED_AVG: a.acc0 = add_acc(p, fp ? ACC_ADD_F : ACC_ADD_I, dt, vals[j], 0); p->need_count = 1; break;
-        case AQG_RED_VAR: case AQG_RED_STDDEV:
-            a.acc0 = add_acc(p, fp ? ACC_ADD_F : ACC_ADD_I, dt, vals[j], 0);
-            a.acc1 = add_acc(p, fp ? ACC_ADD_F : ACC_ADD_I, dt, vals[j], 1);
-            p->need_count = 1;
-            if (a.acc1 < 0) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: too many accumulators");
+        case AQG_RED_SUM: case AQG_RED_AVG: case AQG_RED_VAR: case AQG_RED_STDDEV:
+            if (wide) { a.acc0 = add_acc(p, addk, dt, vals[j], 0, 1); a.acc1 = add_acc(p, addk, dt, vals[j], 0, 2); ok = a.acc0 >= 0 && a.acc1 >= 0; }
+            else { a.acc0 = add_acc(p, addk, dt, vals[j], 0); ok = a.acc0 >= 0; }
+            if (op == AQG_RED_VAR || op == AQG_RED_STDDEV) {
+                if (wide) { a.acc2 = add_acc(p, addk, dt, vals[j], 1, 1); a.acc3 = add_acc(p, addk, dt, vals[j], 1, 2); ok = ok && a.acc2 >= 0 && a.acc3 >= 0; }
+                else { a.acc2 = add_acc(p, addk, dt, vals[j], 1); ok = ok && a.acc2 >= 0; }
+            }
+            if (op != AQG_RED_SUM) p->need_count = 1;
             break;
-        case AQG_RED_MIN: a.acc0 = add_acc(p, ACC_MIN, dt, vals[j], 0); break;
-        case AQG_RED_MAX: a.acc0 = add_acc(p, ACC_MAX, dt, vals[j], 0); break;
+        case AQG_RED_MIN: a.acc0 = add_acc(p, ACC_MIN, dt, vals[j], 0); ok = a.acc0 >= 0; break;
+        case AQG_RED_MAX: a.acc0 = add_acc(p, ACC_MAX, dt, vals[j], 0); ok = a.acc0 >= 0; break;
         case AQG_RED_COUNT: p->need_count = 1; break;
         default: return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: FIRST/LAST need row lists (use aqg_grouped_reduce)");
         }
-        if (op != AQG_RED_COUNT && a.acc0 < 0) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: too many accumulators");
-        if ((dt == AQG_INT64 || dt == AQG_UINT64) && (op == AQG_RED_SUM || op == AQG_RED_AVG || op == AQG_RED_VAR || op == AQG_RED_STDDEV))
-            return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: sums of 8-byte integers need 128-bit accumulators (not on device yet)");
+        if (!ok) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: too many accumulators (8 per call)");
     }
     return AQG_OK;
 }
@@ -698,22 +780,38 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
 
     // ---- pass over the rows ---------------------------------------------------------------------
     if (n) {
-        if (use_lds) {
-            size_t lds = (size_t)(lcap + 1) * (8 + 8 * (size_t)as.nacc + (k32 ? 0 : 4) + (plan.need_count ? 4 : 0)) + 16;
-            unsigned bpc = lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : lds <= 80 * 1024 ? 2 : 1;
-            unsigned grid = aqg_grid(ctx, n / 4 + 1, 256, 2, bpc);
-            if (k32) {
-                AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((agg_kernel<true, true>), dim3(grid), dim3(256), lds, ctx->stream, ks, as, gt, n, lcap, plan.need_count);
-            } else {
-                AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL((agg_kernel<true, false>), dim3(grid), dim3(256), lds, ctx->stream, ks, as, gt, n, lcap, plan.need_count);
-            }
-        } else {
-            unsigned grid = aqg_grid(ctx, n / 4 + 1, 256, 2, 8);
-            if (k32) hipLaunchKernelGGL((agg_kernel<false, true>), dim3(grid), dim3(256), 0, ctx->stream, ks, as, gt, n, 0u, plan.need_count);
-            else hipLaunchKernelGGL((agg_kernel<false, false>), dim3(grid), dim3(256), 0, ctx->stream, ks, as, gt, n, 0u, plan.need_count);
+        uint32_t lrep = 1;
+        if (use_lds) {   // replicate small tables: conflicts fall, LDS stays under ~32 KB per workgroup
+            size_t per = (size_t)(lcap + 1) * (8 + 8 * (size_t)as.nacc + (k32 ? 0 : 4) + (plan.need_count ? 4 : 0));
+            uint32_t want = 1;   // measured on MI355X (h2o Q1, 100 groups): 1 replica 1.98 ms, 4 replicas 2.12 ms per 1e9 rows
+            while (lrep < want && per * lrep * 2 <= 64 * 1024) lrep *= 2;
         }
+        size_t lds = use_lds ? (size_t)lrep * (lcap + 1) * (8 + 8 * (size_t)as.nacc + (k32 ? 0 : 4) + (plan.need_count ? 4 : 0)) + 4 * 64 : 0;
+        unsigned bpc = !use_lds ? 8 : lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : lds <= 80 * 1024 ? 2 : 1;
+        unsigned grid = aqg_grid(ctx, n / 4 + 1, 256, 2, bpc);
+        auto launch = [&](auto kern) -> int {
+            if (lds) AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, ks, as, gt, n, lcap, plan.need_count, lrep);
+            return AQG_OK;
+        };
+        auto by_nacc = [&](auto lds_tag, auto k32_tag) -> int {
+            constexpr bool L = decltype(lds_tag)::value, K = decltype(k32_tag)::value;
+            switch (as.nacc) {
+            case 0: return launch(&agg_kernel<L, K, 0>);
+            case 1: return launch(&agg_kernel<L, K, 1>);
+            case 2: return launch(&agg_kernel<L, K, 2>);
+            case 3: return launch(&agg_kernel<L, K, 3>);
+            case 4: return launch(&agg_kernel<L, K, 4>);
+            case 5: return launch(&agg_kernel<L, K, 5>);
+            case 6: return launch(&agg_kernel<L, K, 6>);
+            case 7: return launch(&agg_kernel<L, K, 7>);
+            default: return launch(&agg_kernel<L, K, 8>);
+            }
+        };
+        aqg_kernel_timer_begin(ctx);
+        if (use_lds) { if (k32) AQG_TRY(by_nacc(std::true_type{}, std::true_type{})); else AQG_TRY(by_nacc(std::true_type{}, std::false_type{})); }
+        else { if (k32) AQG_TRY(by_nacc(std::false_type{}, std::true_type{})); else AQG_TRY(by_nacc(std::false_type{}, std::false_type{})); }
+        aqg_kernel_timer_end(ctx);
         AQG_TRY(aqg_check_launch(ctx, "agg_kernel"));
     }
     // ---- dense ids ---------------------------------------------------------------------------------

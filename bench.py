@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py -- rows/sec of the h2o group-by hot path on MI355X, against the HBM roofline.
+
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json metric "rows/sec on h2o groupby 1e9-row"): h2o Q1
+`SELECT id1, sum(v1) FROM source GROUP BY id1` (reference benchmark/h2o/groupby.sql:1) on 1e9 synthetic
+h2o-shaped rows PER GPU (K=100, seed 42, generated in HBM by the library's counter-based generator;
+SURVEY.md 8d).  One step = one pass of the hot path over the resident columns: fused hash group-by +
+sum (aqg_groupby_agg through the C-ABI) and, for N>1, the one RCCL exchange that merges the per-shard
+group tables (all_gather of {key, partial sum}, re-aggregated by the same kernel) -- weak scaling.
+The JSON line carries `roofline` (algorithmic 8 B/row over the HIP-event duration of the dominant
+kernel) and, on rank 0 at N=1, `cpu_baseline` (the reference's own headers, or the oracle port, timed
+on a bounded sample of the same workload on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable copy)
+Q1_BYTES_PER_ROW = 8           # id1 int32 + v1 int32
+
+
+def cpu_baseline(sample_rows):
+    """The reference CPU path (hash build -> ht_postproc -> per-group gather + sum), single thread --
+    the post-processor is single-threaded in the reference (omp simd only).  Checker code: timed, never shipped."""
+    import checker as ck
+    oracle = ck.load_oracle()
+    ref = ck.load_ref(fast=True)
+    id1 = oracle.gen_column(ck.GEN_ID1, 42, 0, sample_rows, 10**9, 100)
+    v1 = oracle.gen_column(ck.GEN_V1, 42, 0, sample_rows, 10**9, 100)
+    kind, lib = ("reference", ref) if ref is not None else ("port", oracle)
+    secs, groups, split = lib.time_groupby_sum([id1], [v1])
+    if secs <= 0:
+        kind, lib = "port", oracle
+        secs, groups, split = lib.time_groupby_sum([id1], [v1])
+    return {"value": sample_rows / secs, "unit": "rows/s", "cores": 1, "kind": kind,
+            "sample": f"h2o Q1 on the first {sample_rows:.0e} rows of the same synthetic table "
+                      f"(build {split[0]:.2f}s / ht_postproc {split[1]:.2f}s / gather+sum {split[2]:.2f}s; "
+                      f"{groups} groups; host has {os.cpu_count()} cores, reference post-processor is single-threaded)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=float, default=1e9, help="rows per GPU")
+    ap.add_argument("--cpu-sample", type=float, default=1e8, help="rows of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n = int(args.rows)
+    n_total = n * world
+
+    import torch
+    import aquery2_amd
+    from aquery2_amd import shard
+    import checker as ck
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    # the library runs on torch's current stream so that torch.cuda.synchronize / RCCL order with it
+    stream = torch.cuda.current_stream().cuda_stream
+    dev = aquery2_amd.Device(local_rank, stream=stream)
+    id1 = dev.gen_column(ck.GEN_ID1, 42, rank * n, n, n_total, 100)
+    v1 = dev.gen_column(ck.GEN_V1, 42, rank * n, n, n_total, 100)
+    dev.sync()
+
+    state = {"gb": None, "merged": None}
+    kernel_ms = []
+
+    def step(record):
+        gb = dev.groupby_agg([id1], [ck.RED_SUM], [v1], hint=128, handle=state["gb"])
+        state["gb"] = gb
+        if record:
+            kernel_ms.append(dev.last_kernel_ms())
+        if world > 1:
+            # one exchange: gather every shard's {key, partial sum} (<= a few KB), then re-aggregate;
+            # shards are contiguous row ranges in rank order, so first occurrence in the concatenation
+            # is the global first occurrence
+            G = gb.ngroups
+            kbuf = dev.empty(G, np.int32)
+            dev._chk(dev.lib.aqg_groupby_keys(gb.h, 0, kbuf.ptr), "aqg_groupby_keys")
+            keys_t = torch.as_tensor(kbuf, device="cuda").to(torch.int64)
+            sums = aquery2_amd.DevBuf(dev, dev.lib.aqg_groupby_agg_result(gb.h, 0), ck.I128, G, owned=False)
+            sums_lo = torch.as_tensor(sums, device="cuda").reshape(G, 2)[:, 0].contiguous()   # partial sums fit 63 bits
+            mk, ms = shard.gather_group_tables(dist, [keys_t, sums_lo], G)
+            mk = mk.to(torch.int32).contiguous()
+            kd = aquery2_amd.DevBuf(dev, mk.data_ptr(), np.int32, mk.numel(), owned=False)
+            sd = aquery2_amd.DevBuf(dev, ms.data_ptr(), np.int64, ms.numel(), owned=False)
+            state["merged"] = dev.groupby_agg([kd], [ck.RED_SUM], [sd], hint=128, handle=state["merged"])
+            state["keep"] = (mk, ms, kbuf)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dev.sync()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the merged / local result is the exact sum of v1 (checked against a second HIP reduction)
+    final = state["merged"] if world > 1 else state["gb"]
+    total = sum(ck.i128_to_int(final.result(0, ck.RED_SUM, ck.INT64 if world > 1 else ck.INT32)))
+    local_sum = int(dev.reduce(ck.RED_SUM, v1))
+    if world > 1:
+        t = torch.tensor([local_sum], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t)
+        local_sum = int(t.item())
+    assert total == local_sum, (total, local_sum)
+    assert final.ngroups == 100
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        k_ms = float(np.mean(kernel_ms))
+        achieved = Q1_BYTES_PER_ROW * n / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "rows/sec on h2o groupby 1e9-row", "value": n_total * args.steps / elapsed, "unit": "rows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"h2o_groupby_q1_sum_v1_by_id1_{n:.0e}_rows_per_gpu", "rows_per_gpu": n, "K": 100,
+                       "seed": 42, "groups": int(final.ngroups), "parallelism": f"row-range shards x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "agg_kernel<LDS,K32,1>", "kernel_ms": k_ms, "algorithmic_bytes": Q1_BYTES_PER_ROW * n},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            line["cpu_baseline"] = cpu_baseline(int(args.cpu_sample))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    dev.close()
+
+
+if __name__ == "__main__":
+    main()

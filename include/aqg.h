@@ -224,6 +224,9 @@ int aqg_gen_column(aqg_ctx* ctx, int col, uint64_t seed, uint64_t row_base, uint
 /* ---- HIP-event timing on the context's stream (bench.py roofline leg) ------ */
 int aqg_timer_start(aqg_ctx* ctx);
 int aqg_timer_stop_ms(aqg_ctx* ctx, float* ms_host);
+/* duration of the DOMINANT kernel of the most recent call (group-by: the pass over the rows;
+ * scans: the scan pass), bracketed by HIP events on the context's stream inside the library */
+int aqg_last_kernel_ms(aqg_ctx* ctx, float* ms_host);
 
 const char* aqg_version(void);
 
