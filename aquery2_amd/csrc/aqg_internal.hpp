@@ -37,6 +37,7 @@ struct aqg_ctx {
         hipError_t _e = (call);                                                                \
         if (_e != hipSuccess) {                                                                \
             (ctx)->err = std::string(#call) + ": " + hipGetErrorString(_e);                    \
+            (void)hipGetLastError(); /* do not leave a sticky error for the next launch check */ \
             return AQG_ERR_HIP;                                                                \
         }                                                                                      \
     } while (0)
@@ -65,6 +66,8 @@ template <class T> static inline int aqg_ws_get(aqg_ctx* ctx, size_t count, T** 
     return rc;
 }
 int aqg_host_stage(aqg_ctx* ctx, size_t bytes, void** out);
+// in-place exclusive scan of `count` uint32 words; bsum: scratch of ceil(count/2048) words (postproc.hip)
+int aqg_exclusive_scan_u32(aqg_ctx* ctx, uint32_t* d, uint64_t count, uint32_t* bsum);
 
 // HIP events around the dominant kernel of a call (read back by aqg_last_kernel_ms)
 static inline void aqg_kernel_timer_begin(aqg_ctx* ctx) { (void)hipEventRecord(ctx->evk0, ctx->stream); }

@@ -21,6 +21,23 @@ __host__ __device__ static inline aqg_i128 i128_add(aqg_i128 a, aqg_i128 b) {
     return r;
 }
 
+// correctly rounded (nearest-even) conversions of 128-bit integers to double
+__device__ static inline double u128_to_double(uint64_t hi, uint64_t lo) {
+    if (hi == 0) return (double)lo;
+    int lz = __clzll((long long)hi);
+    uint64_t top = lz ? ((hi << lz) | (lo >> (64 - lz))) : hi;   // top 64 bits; everything below folds into a sticky bit
+    uint64_t rest = lz ? (lo << lz) : lo;
+    if (rest) top |= 1;
+    return ldexp((double)top, 64 - lz);
+}
+__device__ static inline double i128_to_double(aqg_i128 v) {
+    if ((int64_t)v.hi < 0) {
+        uint64_t lo = ~v.lo + 1, hi = ~v.hi + (lo == 0 ? 1 : 0);
+        return -u128_to_double(hi, lo);
+    }
+    return u128_to_double(v.hi, v.lo);
+}
+
 // 16-byte vector of T for coalesced dwordx4 loads/stores
 template <class T> struct alignas(16) vec16 {
     static constexpr int N = 16 / sizeof(T);

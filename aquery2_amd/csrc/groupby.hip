@@ -21,10 +21,10 @@
 // HBM roofline: agg = sum of key and value bytes per row (h2o Q1: 8 B/row); build = 12 B/row.
 #include "aqg_internal.hpp"
 #include "dev_common.hpp"
+#include "groupby_handle.hpp"
 
 namespace {
 
-constexpr int MAXKEYS = 8, MAXACC = 8, MAXAGG = 8;
 constexpr uint64_t EMPTY64 = ~0ull;
 constexpr uint32_t EMPTY32 = 0x80000000u;   // nullval<int> (server/types.h:458) doubles as the LDS empty mark
 constexpr uint32_t NOROW = 0xFFFFFFFFu;
@@ -113,7 +113,9 @@ template <class T> __device__ inline uint64_t val_operand_t(T v, int kind, int s
         if constexpr (std::is_unsigned_v<T>) return (uint64_t)v; else return map_i((int64_t)v);
     }
 }
+// dt == AQG_NONE: the operand is the row index itself (arg-max of the row id for FIRST; see aqg_grouped_reduce)
 __device__ inline uint64_t val_operand(int dt, const void* col, size_t i, int kind, int square, int part) {
+    if (dt == AQG_NONE) return (uint64_t)i;
     switch (dt) {
     case AQG_INT8: return val_operand_t(static_cast<const int8_t*>(col)[i], kind, square);
     case AQG_INT16: return val_operand_t(static_cast<const int16_t*>(col)[i], kind, square);
@@ -134,6 +136,7 @@ template <class T> __device__ inline void val_operand4_t(const void* col, size_t
     for (int j = 0; j < 4; ++j) o[j] = val_operand_t(v.v[j], kind, square, part);
 }
 __device__ inline void val_operand4(int dt, const void* col, size_t base, int kind, int square, int part, uint64_t (&o)[4]) {
+    if (dt == AQG_NONE) { o[0] = base; o[1] = base + 1; o[2] = base + 2; o[3] = base + 3; return; }
     switch (dt) {
     case AQG_INT8: val_operand4_t<int8_t>(col, base, kind, square, part, o); break;
     case AQG_INT16: val_operand4_t<int16_t>(col, base, kind, square, part, o); break;
@@ -464,22 +467,6 @@ __global__ void __launch_bounds__(256) rank_bitmap_kernel(GTable gt, const uint3
 }
 
 // ---- 128-bit helpers for the emit epilogue ------------------------------------------------------
-__device__ inline double u128_to_double(uint64_t hi, uint64_t lo) {   // round to nearest even
-    if (hi == 0) return (double)lo;
-    int lz = __clzll((long long)hi);
-    // keep the top 64 bits, fold everything below into a sticky bit
-    uint64_t top = lz ? ((hi << lz) | (lo >> (64 - lz))) : hi;
-    uint64_t rest = lz ? (lo << lz) : lo;
-    if (rest) top |= 1;
-    return ldexp((double)top, 64 - lz);
-}
-__device__ inline double i128_to_double(aqg_i128 v) {
-    if ((int64_t)v.hi < 0) {
-        uint64_t lo = ~v.lo + 1, hi = ~v.hi + (lo == 0 ? 1 : 0);
-        return -u128_to_double(hi, lo);
-    }
-    return u128_to_double(v.hi, v.lo);
-}
 __device__ inline aqg_i128 mul_i64(int64_t a, int64_t b) {   // exact signed 64x64 -> 128
     aqg_i128 r;
     r.lo = (uint64_t)a * (uint64_t)b;
@@ -638,24 +625,6 @@ __global__ void __launch_bounds__(256) assign_kernel(KeySpec ks, GTable gt, cons
 // =================================================================================================
 // host side
 // =================================================================================================
-struct aqg_groupby {
-    aqg_ctx* ctx = nullptr;
-    uint32_t n = 0, ngroups = 0;
-    int nkeys = 0;
-    int key_dt[MAXKEYS] = {0};
-    bool has_counts = false, has_reversemap = false;
-    // device buffers owned by the handle (grow-only)
-    void* keys_out[MAXKEYS] = {nullptr};
-    uint32_t* first_rows = nullptr;
-    uint32_t* counts = nullptr;
-    uint32_t* reversemap = nullptr;
-    void* results[MAXAGG] = {nullptr};
-    int nagg = 0;
-    int res_dt[MAXAGG] = {0};
-    size_t cap_groups = 0, cap_rows = 0, cap_results[MAXAGG] = {0};
-    uint32_t hint_used = 0;
-};
-
 namespace {
 
 uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (uint32_t)(p > 0x80000000ull ? 0x80000000ull : p); }
@@ -740,11 +709,14 @@ int make_plan(aqg_ctx* ctx, int naggs, const int* ops, const int* dts, const voi
 int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
             GTable* gt_out, uint32_t** slot_gid_out) {
     const AccSpec& as = plan.as;
-    const bool use_lds = hint <= 3072;
     const bool k32 = ks.nkeys == 1 && ks.total_bytes == 4;
     uint32_t gcap = next_pow2((uint64_t)(hint < 512 ? 512 : hint) * 2);
+    // LDS mode while one workgroup's table (75 % load) fits 64 KB; otherwise rows go straight to HBM
+    bool use_lds = hint <= 3072;
     uint32_t lcap = use_lds ? next_pow2((uint64_t)(hint < 64 ? 64 : hint) * 4 / 3 + 1) : 0;
     if (use_lds && lcap < 256) lcap = 256;
+    const size_t lds_slot_bytes = 8 + 8 * (size_t)as.nacc + (k32 ? 0 : 4) + (plan.need_count ? 4 : 0);
+    if (use_lds && (size_t)(lcap + 1) * lds_slot_bytes > 64 * 1024) { use_lds = false; lcap = 0; }
     const bool small_rank = hint <= 4096;
     const uint32_t nwords = (n + 31) / 32, ntiles = (nwords + 1023) / 1024;
 
@@ -902,6 +874,7 @@ void aqg_groupby_destroy(aqg_groupby* g) {
     if (g->first_rows) hipFree(g->first_rows);
     if (g->counts) hipFree(g->counts);
     if (g->reversemap) hipFree(g->reversemap);
+    if (g->scratch) aqg_groupby_destroy(g->scratch);
     delete g;
 }
 uint32_t aqg_groupby_ngroups(const aqg_groupby* g) { return g ? g->ngroups : 0; }
@@ -968,6 +941,53 @@ int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void
     h->has_counts = true; h->has_reversemap = true;
     AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out = h;
+    return AQG_OK;
+}
+
+
+namespace {
+__global__ void __launch_bounds__(256) take_rows_kernel(const uint64_t* __restrict__ acc_rows, uint32_t G, uint32_t* __restrict__ rows) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x) rows[g] = (uint32_t)acc_rows[g];
+}
+} // namespace
+
+// out[g] = op(col[vecs[g]]) for every group in one pass (generated loop engine/ast.py:722-789).
+// The group id column (reversemap) is itself a dense first-occurrence key, so grouping by it
+// reproduces the group order; the value column is read once.  vecs[g] is in DESCENDING row order
+// (hasher.h:192-196), hence first(col[vecs[g]]) is the LAST row of the group and last(...) its first row.
+int aqg_grouped_reduce(aqg_ctx* ctx, const aqg_groupby* gc, int op, int t, const void* x, void* out_dev) {
+    aqg_groupby* g = const_cast<aqg_groupby*>(gc);
+    if (!ctx || !g || (!x && g->n) || !out_dev) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_reduce: bad argument");
+    if (!g->has_reversemap) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_reduce: handle has no reversemap (use aqg_groupby_build)");
+    if (!dt_is_num(t)) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_grouped_reduce: value dtype");
+    const uint32_t G = g->ngroups, n = g->n;
+    if (G == 0) return AQG_OK;
+    const int kdt = AQG_UINT32;
+    const void* kcol = g->reversemap;
+    if (op == AQG_RED_LAST) return aqg_gather(ctx, t, x, g->first_rows, G, out_dev);
+    KeySpec ks;
+    AQG_TRY(make_keyspec(ctx, 1, &kdt, &kcol, n, &ks));
+    if (!g->scratch) g->scratch = new aqg_groupby();
+    aqg_groupby* h = g->scratch;
+    h->ctx = ctx; h->n = n; h->has_reversemap = false;
+    if (op == AQG_RED_FIRST) {
+        Plan plan;
+        memset(&plan, 0, sizeof plan);
+        plan.nagg = 1;
+        plan.agg[0].op = AQG_RED_MAX; plan.agg[0].dt = AQG_UINT64; plan.agg[0].acc1 = plan.agg[0].acc2 = plan.agg[0].acc3 = -1;
+        plan.agg[0].acc0 = add_acc(&plan, ACC_MAX, AQG_NONE, nullptr, 0);
+        AQG_TRY(run_with_retry(ctx, ks, plan, n, G, false, h, nullptr, nullptr));
+        uint32_t* rows = nullptr;
+        AQG_TRY(aqg_ws_reset(ctx));
+        AQG_TRY(aqg_ws_get(ctx, G, &rows));
+        hipLaunchKernelGGL(take_rows_kernel, dim3(aqg_grid(ctx, G, 256, 1, 8)), dim3(256), 0, ctx->stream, (const uint64_t*)h->results[0], G, rows);
+        return aqg_gather(ctx, t, x, rows, G, out_dev);
+    }
+    Plan plan;
+    AQG_TRY(make_plan(ctx, 1, &op, &t, &x, n, &plan));
+    AQG_TRY(run_with_retry(ctx, ks, plan, n, G, false, h, nullptr, nullptr));
+    if (h->ngroups != G) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_reduce: group ids are not dense");
+    AQG_HIP(ctx, hipMemcpyAsync(out_dev, h->results[0], (size_t)G * aqg_dtype_size(aqg_reduce_out_dtype(op, t)), hipMemcpyDeviceToDevice, ctx->stream));
     return AQG_OK;
 }
 

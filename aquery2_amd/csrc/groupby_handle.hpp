@@ -1,0 +1,27 @@
+// groupby_handle.hpp -- the opaque aqg_groupby handle (shared by groupby.hip and postproc.hip)
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+struct aqg_ctx;
+constexpr int MAXKEYS = 8, MAXACC = 8, MAXAGG = 8;
+
+struct aqg_groupby {
+    aqg_ctx* ctx = nullptr;
+    uint32_t n = 0, ngroups = 0;
+    int nkeys = 0;
+    int key_dt[MAXKEYS] = {0};
+    bool has_counts = false, has_reversemap = false;
+    // device buffers owned by the handle (grow-only)
+    void* keys_out[MAXKEYS] = {nullptr};
+    uint32_t* first_rows = nullptr;
+    uint32_t* counts = nullptr;
+    uint32_t* reversemap = nullptr;
+    void* results[MAXAGG] = {nullptr};
+    int nagg = 0;
+    int res_dt[MAXAGG] = {0};
+    size_t cap_groups = 0, cap_rows = 0, cap_results[MAXAGG] = {0};
+    uint32_t hint_used = 0;
+    aqg_groupby* scratch = nullptr;   // reusable handle for aqg_grouped_reduce
+};
+

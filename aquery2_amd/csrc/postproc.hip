@@ -1,0 +1,198 @@
+// postproc.hip -- aqg_groupby_postproc: the device form of AQHashTable::ht_postproc
+// (reference server/hasher.h:181-198): a counting sort of row ids by group id that leaves the rows of
+// every group in DESCENDING order, plus the group start offsets (ht_base after postproc).
+//
+// Stable LSD radix sort, 8 bits per pass, over the sequence p -> (key = reversemap[n-1-p], value = n-1-p):
+// a stable sort of that reversed sequence yields descending row ids inside each group.  Per pass:
+//   digit histogram per 4096-row tile -> exclusive scan of the (digit-major, tile-minor) counts ->
+//   stable scatter: 256 rows per round, wavefront match-any by 8 ballots gives the rank among equal
+//   digits inside a wave, LDS per-wave counts order the 4 waves, running counts order the rounds.
+// One pass when G <= 256 (h2o Q1): 12 B/row (4 B histogram read + 4 B read + 4 B write).
+#include "aqg_internal.hpp"
+#include "dev_common.hpp"
+#include "groupby_handle.hpp"
+
+namespace {
+
+constexpr int RB = 256;            // lanes per workgroup
+constexpr int ROUNDS = 16;
+constexpr int RT = RB * ROUNDS;    // rows per tile
+
+// ---- exclusive scan of a uint32 array (in place), three kernels ----------------------------------
+__global__ void __launch_bounds__(256) u32_block_sum_kernel(const uint32_t* __restrict__ d, uint64_t count, uint32_t* __restrict__ bsum) {
+    __shared__ uint32_t ws[4];
+    uint64_t base = (uint64_t)blockIdx.x * 2048 + threadIdx.x * 8;
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) if (base + j < count) c += d[base + j];
+    c = wave_reduce(c, OpAdd{});
+    if (lane_id() == 0) ws[wave_id()] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+__global__ void __launch_bounds__(1024) u32_scan_small_kernel(uint32_t* __restrict__ d, uint32_t count) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < count; base += 1024) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < count ? d[i] : 0;
+        uint32_t incl = wave_scan_incl(v, OpAdd{}, lane_id());
+        if (lane_id() == 63) wsum[wave_id()] = incl;
+        __syncthreads();
+        uint32_t wbase = carry;
+        for (int w = 0; w < wave_id(); ++w) wbase += wsum[w];
+        if (i < count) d[i] = wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = wbase + incl;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(256) u32_block_scan_kernel(uint32_t* __restrict__ d, uint64_t count, const uint32_t* __restrict__ bsum_excl) {
+    __shared__ uint32_t ws[4];
+    uint64_t base = (uint64_t)blockIdx.x * 2048 + threadIdx.x * 8;
+    uint32_t v[8], c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = base + j < count ? d[base + j] : 0; c += v[j]; }
+    uint32_t incl = wave_scan_incl(c, OpAdd{}, lane_id());
+    if (lane_id() == 63) ws[wave_id()] = incl;
+    __syncthreads();
+    uint32_t run = bsum_excl[blockIdx.x] + incl - c;
+    for (int w = 0; w < wave_id(); ++w) run += ws[w];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { if (base + j < count) d[base + j] = run; run += v[j]; }
+}
+} // namespace
+// bsum must hold ceil(count/2048) words (declared in aqg_internal.hpp; also used by join.hip)
+int aqg_exclusive_scan_u32(aqg_ctx* ctx, uint32_t* d, uint64_t count, uint32_t* bsum) {
+    if (count == 0) return AQG_OK;
+    uint32_t nb = (uint32_t)((count + 2047) / 2048);
+    hipLaunchKernelGGL(u32_block_sum_kernel, dim3(nb), dim3(256), 0, ctx->stream, d, count, bsum);
+    hipLaunchKernelGGL(u32_scan_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, bsum, nb);
+    hipLaunchKernelGGL(u32_block_scan_kernel, dim3(nb), dim3(256), 0, ctx->stream, d, count, bsum);
+    return aqg_check_launch(ctx, "exclusive_scan_u32");
+}
+namespace {
+
+// element p of the pass input: FIRST pass reads the group-id column backwards and synthesises the row id
+template <bool FIRST> __device__ inline void load_pair(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n, uint32_t p,
+                                                       uint32_t& k, uint32_t& v) {
+    if constexpr (FIRST) { v = n - 1 - p; k = keys[v]; } else { k = keys[p]; v = vals[p]; }
+}
+
+template <bool FIRST>
+__global__ void __launch_bounds__(RB) radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t ntiles,
+                                                        uint32_t* __restrict__ hist /* [256][ntiles] */) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tbase = blockIdx.x * RT;
+    for (int r = 0; r < ROUNDS; ++r) {
+        uint32_t p = tbase + r * RB + threadIdx.x;
+        if (p < n) {
+            uint32_t k = FIRST ? keys[n - 1 - p] : keys[p];
+            atomicAdd(&h[(k >> shift) & 255], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+}
+
+template <bool FIRST, bool LAST>
+__global__ void __launch_bounds__(RB) radix_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n, uint32_t shift,
+                                                           uint32_t ntiles, const uint32_t* __restrict__ hist_scanned,
+                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+    __shared__ uint32_t gbase[256];      // where this tile's rows of each digit start in the output
+    __shared__ uint32_t run[256];        // rows of each digit already placed by earlier rounds
+    __shared__ uint32_t wcnt[4][256];    // rows of each digit in each wave, this round
+    gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * ntiles + blockIdx.x];
+    run[threadIdx.x] = 0;
+    const uint32_t tbase = blockIdx.x * RT;
+    const int lane = lane_id(), wid = wave_id();
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    for (int r = 0; r < ROUNDS; ++r) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t p = tbase + r * RB + threadIdx.x;
+        const bool live = p < n;
+        uint32_t k = 0, v = 0;
+        if (live) load_pair<FIRST>(keys, vals, n, p, k, v);
+        const uint32_t d = (k >> shift) & 255;
+        // lanes of this wave holding the same digit
+        uint64_t peers = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            uint64_t bal = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        const uint32_t rank_in_wave = __popcll(peers & lt_mask);
+        if (live && rank_in_wave == 0) wcnt[wid][d] = __popcll(peers);
+        __syncthreads();
+        if (live) {
+            uint32_t off = run[d] + rank_in_wave;
+            for (int w = 0; w < wid; ++w) off += wcnt[w][d];
+            const uint32_t dst = gbase[d] + off;
+            if constexpr (!LAST) keys_out[dst] = k;
+            vals_out[dst] = v;
+        }
+        __syncthreads();
+        run[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
+        // the next round's zeroing of wcnt is ordered behind this read by the barrier after it
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256) copy_counts_kernel(const uint32_t* __restrict__ counts, uint32_t G, uint32_t* __restrict__ offsets) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g <= G; g += gridDim.x * blockDim.x) offsets[g] = g < G ? counts[g] : 0;
+}
+
+} // namespace
+
+extern "C" int aqg_groupby_postproc(aqg_groupby* g, uint32_t* offsets_dev, uint32_t* row_ids_dev) {
+    if (!g || !offsets_dev || (!row_ids_dev && g->n)) return AQG_ERR_ARG;
+    aqg_ctx* ctx = g->ctx;
+    if (!g->has_reversemap || !g->has_counts) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_postproc: handle was not made by aqg_groupby_build");
+    const uint32_t n = g->n, G = g->ngroups;
+    const uint32_t ntiles = (n + RT - 1) / RT;
+    uint32_t bits = 0;
+    while (bits < 32 && (1ull << bits) < G) ++bits;
+    const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;
+    const uint64_t hcount = (uint64_t)256 * ntiles;
+
+    AQG_TRY(aqg_ws_reset(ctx));
+    size_t need = hcount * 4 + ((hcount + 2047) / 2048 + (G + 2048) / 2048 + 16) * 4 + 8192;
+    if (passes > 1) need += (size_t)n * 16 + 4096;
+    AQG_TRY(aqg_ws_ensure(ctx, need));
+    uint32_t *hist, *bsum, *k0 = nullptr, *v0 = nullptr, *k1 = nullptr, *v1 = nullptr;
+    AQG_TRY(aqg_ws_get(ctx, hcount ? hcount : 1, &hist));
+    AQG_TRY(aqg_ws_get(ctx, (hcount + 2047) / 2048 + (G + 2048) / 2048 + 16, &bsum));
+    if (passes > 1) {
+        AQG_TRY(aqg_ws_get(ctx, n, &k0)); AQG_TRY(aqg_ws_get(ctx, n, &v0));
+        AQG_TRY(aqg_ws_get(ctx, n, &k1)); AQG_TRY(aqg_ws_get(ctx, n, &v1));
+    }
+    // offsets = exclusive scan of counts, offsets[G] = n
+    hipLaunchKernelGGL(copy_counts_kernel, dim3(aqg_grid(ctx, G + 1, 256, 1, 8)), dim3(256), 0, ctx->stream, g->counts, G, offsets_dev);
+    AQG_TRY(aqg_exclusive_scan_u32(ctx, offsets_dev, (uint64_t)G + 1, bsum));
+    if (n == 0) return AQG_OK;
+
+    const uint32_t* kin = g->reversemap;
+    const uint32_t* vin = nullptr;
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        const bool first = pass == 0, last = pass + 1 == passes;
+        const uint32_t shift = pass * 8;
+        uint32_t* kout = last ? nullptr : ((pass & 1) ? k1 : k0);
+        uint32_t* vout = last ? row_ids_dev : ((pass & 1) ? v1 : v0);
+        if (first) hipLaunchKernelGGL((radix_hist_kernel<true>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
+        else hipLaunchKernelGGL((radix_hist_kernel<false>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
+        AQG_TRY(aqg_exclusive_scan_u32(ctx, hist, hcount, bsum));
+        if (first && last) { aqg_kernel_timer_begin(ctx); hipLaunchKernelGGL((radix_scatter_kernel<true, true>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout); aqg_kernel_timer_end(ctx); }
+        else if (first) hipLaunchKernelGGL((radix_scatter_kernel<true, false>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
+        else if (last) hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
+        else hipLaunchKernelGGL((radix_scatter_kernel<false, false>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
+        AQG_TRY(aqg_check_launch(ctx, "radix pass"));
+        kin = kout; vin = vout;
+    }
+    return AQG_OK;
+}

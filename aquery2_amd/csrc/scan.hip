@@ -1,0 +1,547 @@
+// scan.hip -- prefix scans, sliding windows and shifts of a column
+// (reference server/aggregations.h: mins/maxs :89-125, minw/maxw :127-167, ratiow :169-201,
+//  sums/avgs :203-236, sumw/avgw :238-281, vars/stddevs :350-381, varw/stddevw :283-330,
+//  deltas/prev/aggnext :439-485).
+//
+// Prefix scans: reduce-then-scan over 2048-element tiles (tile reduce -> one-workgroup scan of the
+// tile aggregates -> tile scan with carry-in); inside a tile: 8 consecutive elements per lane,
+// wavefront inclusive scan (__shfl_up over 64 lanes), LDS combine of the 4 waves.
+// Windows: every tile stages its elements plus a (w-1)-element halo in LDS; sums use the tile-local
+// prefix difference S[i]-S[i-w] (exact for integers), min/max use log2(w) LDS doubling steps.
+// Integer results are exact (bit-identical to the reference); floating sums follow a tree order.
+// HBM-bound; algorithmic bytes per row = sizeof(T) + sizeof(out).
+#include "aqg_internal.hpp"
+#include "dev_common.hpp"
+
+namespace {
+
+constexpr int SB = 256;        // lanes per workgroup
+constexpr int IT = 8;          // consecutive elements per lane
+constexpr int TS = SB * IT;    // tile
+constexpr uint32_t HALO_MAX_BYTES = 96 * 1024;
+
+// ---- accumulator algebra ----------------------------------------------------------------------
+template <class A> __device__ inline A shfl_up_any(A x, int off) {
+    if constexpr (std::is_same_v<A, aqg_i128>) {
+        aqg_i128 r;
+        r.lo = __shfl_up((unsigned long long)x.lo, off, 64);
+        r.hi = __shfl_up((unsigned long long)x.hi, off, 64);
+        return r;
+    } else return shfl_up_t(x, off);
+}
+template <class A> __device__ inline A shfl_idx_any(A x, int src) {
+    if constexpr (std::is_same_v<A, aqg_i128>) {
+        aqg_i128 r;
+        r.lo = __shfl((unsigned long long)x.lo, src, 64);
+        r.hi = __shfl((unsigned long long)x.hi, src, 64);
+        return r;
+    } else return shfl_idx_t(x, src);
+}
+
+// sum accumulator of T: exact integers (64 bits for <=4-byte inputs, 128 for 8-byte), double for fp
+template <class T> struct sum_alg {
+    using A = std::conditional_t<std::is_floating_point_v<T>, double,
+              std::conditional_t<sizeof(T) == 8, aqg_i128, std::conditional_t<std::is_unsigned_v<T>, uint64_t, int64_t>>>;
+    __device__ static A identity() { if constexpr (std::is_same_v<A, aqg_i128>) return {0, 0}; else return (A)0; }
+    __device__ static A lift(T v) {
+        if constexpr (std::is_same_v<A, aqg_i128>) { if constexpr (std::is_unsigned_v<T>) return i128_from_u64(v); else return i128_from_i64(v); }
+        else return (A)v;
+    }
+    __device__ static A op(A a, A b) { if constexpr (std::is_same_v<A, aqg_i128>) return i128_add(a, b); else return a + b; }
+    __device__ static A sub(A a, A b) {
+        if constexpr (std::is_same_v<A, aqg_i128>) { aqg_i128 nb = {~b.lo + 1, ~b.hi + (b.lo == 0 ? 1ull : 0ull)}; return i128_add(a, nb); }
+        else return a - b;
+    }
+    __device__ static aqg_i128 to_i128(A a) {
+        if constexpr (std::is_same_v<A, aqg_i128>) return a;
+        else if constexpr (std::is_unsigned_v<A>) return i128_from_u64(a);
+        else return i128_from_i64((int64_t)a);
+    }
+    __device__ static double to_double(A a) {
+        if constexpr (std::is_same_v<A, aqg_i128>) {
+            if constexpr (std::is_unsigned_v<T>) return u128_to_double(a.hi, a.lo); else return i128_to_double(a);
+        } else return (double)a;
+    }
+};
+template <class T> struct min_alg {
+    using A = T;
+    __device__ static A identity() { return dlimits<T>::max(); }
+    __device__ static A lift(T v) { return v; }
+    __device__ static A op(A a, A b) { return b < a ? b : a; }
+};
+template <class T> struct max_alg {
+    using A = T;
+    // true lowest value, not the reference's seed (the seed is applied when writing `maxs`)
+    __device__ static A identity() { if constexpr (std::is_floating_point_v<T>) return -dlimits<T>::max(); else return dlimits<T>::min(); }
+    __device__ static A lift(T v) { return v; }
+    __device__ static A op(A a, A b) { return b > a ? b : a; }
+};
+
+// exclusive scan of one value per lane across the workgroup; `total` = fold of all lanes
+template <class ALG, class A> __device__ inline A block_scan_excl(A v, A* lds_w /* >= 5 */, A& total) {
+    const int lane = lane_id(), wid = wave_id();
+    A incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        A y = shfl_up_any(incl, off);
+        if (lane >= off) incl = ALG::op(y, incl);
+    }
+    if (lane == 63) lds_w[wid] = incl;
+    __syncthreads();
+    A base = ALG::identity();
+    for (int w = 0; w < wid; ++w) base = ALG::op(base, lds_w[w]);
+    A tot = ALG::identity();
+    for (int w = 0; w < SB / 64; ++w) tot = ALG::op(tot, lds_w[w]);
+    total = tot;
+    A prev = shfl_up_any(incl, 1);
+    if (lane == 0) prev = ALG::identity();
+    __syncthreads();
+    return ALG::op(base, prev);
+}
+
+template <class T> __device__ inline void load_tile_items(const T* __restrict__ x, uint32_t n, uint32_t base, T (&v)[IT], uint32_t& cnt) {
+    cnt = base >= n ? 0 : (n - base < (uint32_t)IT ? n - base : IT);
+    if (cnt == IT && (((uintptr_t)(x + base)) & (sizeof(T) * IT > 16 ? 15 : sizeof(T) * IT - 1)) == 0) {
+        pack<T, IT> p = *reinterpret_cast<const pack<T, IT>*>(x + base);
+#pragma unroll
+        for (int j = 0; j < IT; ++j) v[j] = p.v[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < IT; ++j) if ((uint32_t)j < cnt) v[j] = x[base + j];
+    }
+}
+
+// K1: aggregate of each tile
+template <class T, class ALG> __global__ void __launch_bounds__(SB) tile_reduce_kernel(const T* __restrict__ x, uint32_t n, typename ALG::A* __restrict__ tile_agg) {
+    using A = typename ALG::A;
+    __shared__ A lds_w[8];
+    uint32_t base = blockIdx.x * TS + threadIdx.x * IT, cnt;
+    T v[IT];
+    load_tile_items(x, n, base, v, cnt);
+    A a = ALG::identity();
+#pragma unroll
+    for (int j = 0; j < IT; ++j) if ((uint32_t)j < cnt) a = ALG::op(a, ALG::lift(v[j]));
+    A total;
+    block_scan_excl<ALG>(a, lds_w, total);
+    if (threadIdx.x == 0) tile_agg[blockIdx.x] = total;
+}
+// K2: exclusive scan of the tile aggregates by one workgroup
+template <class ALG> __global__ void __launch_bounds__(SB) agg_scan_kernel(typename ALG::A* __restrict__ tile_agg, uint32_t ntiles) {
+    using A = typename ALG::A;
+    __shared__ A lds_w[8];
+    __shared__ A carry_s;
+    if (threadIdx.x == 0) carry_s = ALG::identity();
+    __syncthreads();
+    for (uint32_t base = 0; base < ntiles; base += SB * IT) {
+        uint32_t b = base + threadIdx.x * IT;
+        A v[IT];
+        A a = ALG::identity();
+#pragma unroll
+        for (int j = 0; j < IT; ++j) { v[j] = (b + j < ntiles) ? tile_agg[b + j] : ALG::identity(); a = ALG::op(a, v[j]); }
+        A total;
+        A excl = block_scan_excl<ALG>(a, lds_w, total);
+        A run = ALG::op(carry_s, excl);
+#pragma unroll
+        for (int j = 0; j < IT; ++j) { if (b + j < ntiles) tile_agg[b + j] = run; run = ALG::op(run, v[j]); }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = ALG::op(carry_s, total);
+        __syncthreads();
+    }
+}
+
+// K3: scan inside the tile with the carry-in; WRITER(out, i, inclusive_value)
+enum : int { W_SUMS = 0, W_AVGS = 1, W_MINS = 2, W_MAXS = 3, W_MAXP = 4 /* running max without the reference's seed (maxw, w >= n) */ };
+
+template <class T, class ALG, int WR>
+__global__ void __launch_bounds__(SB) tile_scan_kernel(const T* __restrict__ x, uint32_t n, const typename ALG::A* __restrict__ tile_prefix,
+                                                       void* __restrict__ out) {
+    using A = typename ALG::A;
+    __shared__ A lds_w[8];
+    uint32_t base = blockIdx.x * TS + threadIdx.x * IT, cnt;
+    T v[IT];
+    load_tile_items(x, n, base, v, cnt);
+    A a = ALG::identity();
+#pragma unroll
+    for (int j = 0; j < IT; ++j) if ((uint32_t)j < cnt) a = ALG::op(a, ALG::lift(v[j]));
+    A total;
+    A run = ALG::op(tile_prefix[blockIdx.x], block_scan_excl<ALG>(a, lds_w, total));
+    if constexpr (WR == W_SUMS) {
+        using O = std::conditional_t<std::is_floating_point_v<T>, double, aqg_i128>;
+        pack<O, IT> o;
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            if ((uint32_t)j < cnt) run = ALG::op(run, ALG::lift(v[j]));
+            if constexpr (std::is_floating_point_v<T>) o.v[j] = run; else o.v[j] = sum_alg<T>::to_i128(run);
+        }
+        if (cnt == IT) *reinterpret_cast<pack<O, IT>*>(static_cast<O*>(out) + base) = o;
+        else for (uint32_t j = 0; j < cnt; ++j) static_cast<O*>(out)[base + j] = o.v[j];
+    } else if constexpr (WR == W_AVGS) {
+        pack<double, IT> o;
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            if ((uint32_t)j < cnt) run = ALG::op(run, ALG::lift(v[j]));
+            o.v[j] = sum_alg<T>::to_double(run) / (double)(base + j + 1);            // (s += arr[i]) / (double)(i + 1)
+        }
+        if (cnt == IT) *reinterpret_cast<pack<double, IT>*>(static_cast<double*>(out) + base) = o;
+        else for (uint32_t j = 0; j < cnt; ++j) static_cast<double*>(out)[base + j] = o.v[j];
+    } else {
+        pack<T, IT> o;
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            if ((uint32_t)j < cnt) run = ALG::op(run, ALG::lift(v[j]));
+            T r = run;
+            if constexpr (WR == W_MAXS) { T seed = dlimits<T>::min(); r = seed > r ? seed : r; }  // maxs seeds with numeric_limits<T>::min()
+            o.v[j] = r;
+        }
+        if (cnt == IT) *reinterpret_cast<pack<T, IT>*>(static_cast<T*>(out) + base) = o;
+        else for (uint32_t j = 0; j < cnt; ++j) static_cast<T*>(out)[base + j] = o.v[j];
+    }
+}
+
+// ---- shifts / ratios: neighbour element-wise ------------------------------------------------------
+template <class T, int OP>
+__global__ void __launch_bounds__(SB) shift_kernel(const T* __restrict__ x, uint32_t n, uint32_t w, void* __restrict__ out) {
+    using FP = std::conditional_t<sizeof(T) == 4, float, double>;           // GetFPType
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        if constexpr (OP == AQG_SCAN_DELTAS) static_cast<T*>(out)[i] = i ? (T)(x[i] - x[i - 1]) : (T)0;
+        else if constexpr (OP == AQG_SCAN_PREV) static_cast<T*>(out)[i] = i ? x[i - 1] : x[0];
+        else if constexpr (OP == AQG_SCAN_NEXT) static_cast<T*>(out)[i] = i + 1 < n ? x[i + 1] : x[n - 1];
+        else static_cast<FP*>(out)[i] = (FP)(x[i] / (FP)(i < w ? x[0] : x[i - w]));   // ratiow: arr[i] / (FPType)arr[i-w]
+    }
+}
+
+// ---- sliding sums: tile + halo in LDS, prefix difference -------------------------------------------
+// MODE 0 sumw (LongType out) / 1 avgw (double) / 2 varw / 3 stddevw (intended population variance; see D9)
+template <class T> struct dsum_alg {
+    using A = double;
+    __device__ static double identity() { return 0; }
+    __device__ static double lift(T v) { return (double)v; }
+    __device__ static double op(double a, double b) { return a + b; }
+    __device__ static double sub(double a, double b) { return a - b; }
+    __device__ static double to_double(double a) { return a; }
+    __device__ static aqg_i128 to_i128(double) { return {0, 0}; }
+};
+template <class T, int MODE>
+__global__ void __launch_bounds__(SB) window_sum_kernel(const T* __restrict__ x, uint32_t n, uint32_t w, void* __restrict__ out) {
+    using ALG = std::conditional_t<(MODE >= 2), dsum_alg<T>, sum_alg<T>>;
+    using A = typename ALG::A;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    __shared__ A lds_w[8];
+    __shared__ A lds_w2[8];
+    const uint32_t tile_start = blockIdx.x * TS, tile_end = tile_start + TS < n ? tile_start + TS : n;
+    const uint32_t ext_start = tile_start >= w - 1 ? tile_start - (w - 1) : 0;
+    const uint32_t ext_len = tile_end - ext_start;
+    A* S = reinterpret_cast<A*>(smem_raw);                       // inclusive prefix of x over the extended tile
+    A* Q = S + (MODE >= 2 ? ext_len : 0);                        // inclusive prefix of x*x (variance modes)
+    const uint32_t per = (ext_len + SB - 1) / SB;                // consecutive elements per lane
+    const uint32_t b = threadIdx.x * per, e = b + per < ext_len ? b + per : ext_len;
+    A a = ALG::identity(), q = ALG::identity();
+    for (uint32_t k = b; k < e; ++k) {
+        T v = x[ext_start + k];
+        a = ALG::op(a, ALG::lift(v)); S[k] = a;
+        if constexpr (MODE >= 2) { q = q + (double)v * (double)v; Q[k] = q; }
+    }
+    A tot, tot2;
+    A excl = block_scan_excl<ALG>(a, lds_w, tot);
+    A excl2 = ALG::identity();
+    if constexpr (MODE >= 2) excl2 = block_scan_excl<ALG>(q, lds_w2, tot2);
+    for (uint32_t k = b; k < e; ++k) { S[k] = ALG::op(excl, S[k]); if constexpr (MODE >= 2) Q[k] = ALG::op(excl2, Q[k]); }
+    __syncthreads();
+    for (uint32_t i = tile_start + threadIdx.x; i < tile_end; i += SB) {
+        const uint32_t idx = i - ext_start;
+        const uint32_t len = i + 1 < w ? i + 1 : w;               // growing prefix for i < w
+        A s = idx >= len ? ALG::sub(S[idx], S[idx - len]) : S[idx];
+        if constexpr (MODE == 0) {
+            if constexpr (std::is_floating_point_v<T>) static_cast<double*>(out)[i] = s;
+            else static_cast<aqg_i128*>(out)[i] = ALG::to_i128(s);
+        } else if constexpr (MODE == 1) {
+            static_cast<double*>(out)[i] = ALG::to_double(s) / (double)len;
+        } else {
+            A sq = idx >= len ? ALG::sub(Q[idx], Q[idx - len]) : Q[idx];
+            double m = ALG::to_double(s) / (double)len;
+            double var = ALG::to_double(sq) / (double)len - m * m;
+            if (var < 0) var = 0;
+            static_cast<double*>(out)[i] = MODE == 3 ? sqrt(var) : var;
+        }
+    }
+}
+
+// floating inputs, short windows: add the window's elements directly (oldest first) -- no prefix cancellation
+template <class T, int MODE>
+__global__ void __launch_bounds__(SB) window_direct_kernel(const T* __restrict__ x, uint32_t n, uint32_t w, double* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t len = i + 1 < w ? i + 1 : w;
+        double s = 0;
+        for (uint32_t j = i + 1 - len; j <= i; ++j) s += (double)x[j];
+        out[i] = MODE == 0 ? s : s / (double)len;
+    }
+}
+
+// ---- sliding min / max: tile + halo in LDS, doubling ---------------------------------------------------
+template <class T, bool IS_MAX>
+__global__ void __launch_bounds__(SB) window_minmax_kernel(const T* __restrict__ x, uint32_t n, uint32_t w, T* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const uint32_t tile_start = blockIdx.x * TS, tile_end = tile_start + TS < n ? tile_start + TS : n;
+    const uint32_t ext_start = tile_start >= w - 1 ? tile_start - (w - 1) : 0;
+    const uint32_t ext_len = tile_end - ext_start;
+    T* M0 = reinterpret_cast<T*>(smem_raw);
+    T* M1 = M0 + ext_len;
+    auto better = [](T a, T b) { if constexpr (IS_MAX) return b > a ? b : a; else return b < a ? b : a; };
+    for (uint32_t k = threadIdx.x; k < ext_len; k += SB) M0[k] = x[ext_start + k];
+    __syncthreads();
+    uint32_t K = 0;
+    while ((2u << K) <= w) ++K;                                    // 2^K <= w < 2^(K+1)
+    T* cur = M0; T* nxt = M1;
+    for (uint32_t k = 0; k < K; ++k) {
+        const uint32_t d = 1u << k;
+        for (uint32_t p = threadIdx.x; p < ext_len; p += SB) nxt[p] = p >= d ? better(cur[p], cur[p - d]) : cur[p];
+        __syncthreads();
+        T* t = cur; cur = nxt; nxt = t;
+    }
+    const uint32_t span = 1u << K;                                 // cur[p] = best of the last min(span, p+1) elements
+    for (uint32_t i = tile_start + threadIdx.x; i < tile_end; i += SB) {
+        const uint32_t idx = i - ext_start;
+        const uint32_t len = i + 1 < w ? i + 1 : w;
+        out[i] = len > span ? better(cur[idx], cur[idx - (len - span)]) : cur[idx];
+    }
+}
+
+// large-window fallback for min/max: doubling passes through HBM (ping-pong), then the two-span combine
+template <class T, bool IS_MAX>
+__global__ void __launch_bounds__(SB) doubling_pass_kernel(const T* __restrict__ src, T* __restrict__ dst, uint32_t n, uint32_t d) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        T a = src[i];
+        if (i >= d) { T b = src[i - d]; if constexpr (IS_MAX) a = b > a ? b : a; else a = b < a ? b : a; }
+        dst[i] = a;
+    }
+}
+template <class T, bool IS_MAX>
+__global__ void __launch_bounds__(SB) doubling_final_kernel(const T* __restrict__ m, T* __restrict__ out, uint32_t n, uint32_t w, uint32_t span) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t len = i + 1 < w ? i + 1 : w;
+        T a = m[i];
+        if (len > span) { T b = m[i - (len - span)]; if constexpr (IS_MAX) a = b > a ? b : a; else a = b < a ? b : a; }
+        out[i] = a;
+    }
+}
+// large-window fallback for sums: out[i] = S[i] - S[i-len] over a global inclusive prefix (8-byte accumulators)
+template <class T, int MODE>
+__global__ void __launch_bounds__(SB) prefix_diff_kernel(const typename sum_alg<T>::A* __restrict__ S, uint32_t n, uint32_t w, void* __restrict__ out) {
+    using ALG = sum_alg<T>;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t len = i + 1 < w ? i + 1 : w;
+        auto s = i >= len ? ALG::sub(S[i], S[i - len]) : S[i];
+        if constexpr (MODE == 0) {
+            if constexpr (std::is_floating_point_v<T>) static_cast<double*>(out)[i] = s; else static_cast<aqg_i128*>(out)[i] = ALG::to_i128(s);
+        } else static_cast<double*>(out)[i] = ALG::to_double(s) / (double)len;
+    }
+}
+// inclusive prefix in accumulator form (used by the fallback above)
+template <class T>
+__global__ void __launch_bounds__(SB) tile_scan_raw_kernel(const T* __restrict__ x, uint32_t n, const typename sum_alg<T>::A* __restrict__ tile_prefix,
+                                                           typename sum_alg<T>::A* __restrict__ out) {
+    using ALG = sum_alg<T>;
+    using A = typename ALG::A;
+    __shared__ A lds_w[8];
+    uint32_t base = blockIdx.x * TS + threadIdx.x * IT, cnt;
+    T v[IT];
+    load_tile_items(x, n, base, v, cnt);
+    A a = ALG::identity();
+#pragma unroll
+    for (int j = 0; j < IT; ++j) if ((uint32_t)j < cnt) a = ALG::op(a, ALG::lift(v[j]));
+    A total;
+    A run = ALG::op(tile_prefix[blockIdx.x], block_scan_excl<ALG>(a, lds_w, total));
+    for (uint32_t j = 0; j < cnt; ++j) { run = ALG::op(run, ALG::lift(v[j])); out[base + j] = run; }
+}
+
+// running variance (vars / stddevs): MnX_i = ssq_i - s_i^2/(i+1), value = MnX_i/(i+1) -- from exact prefix sums of
+// x and x*x (the reference updates MnX with a floating recurrence, aggregations.h:364-372)
+template <class T, bool SD>
+__global__ void __launch_bounds__(SB) vars_kernel(const T* __restrict__ x, uint32_t n, const double* __restrict__ tp_s, const double* __restrict__ tp_q,
+                                                  double* __restrict__ out) {
+    using dalg = dsum_alg<T>;
+    __shared__ double lds_w[8];
+    __shared__ double lds_w2[8];
+    uint32_t base = blockIdx.x * TS + threadIdx.x * IT, cnt;
+    T v[IT];
+    load_tile_items(x, n, base, v, cnt);
+    double a = 0, q = 0;
+#pragma unroll
+    for (int j = 0; j < IT; ++j) if ((uint32_t)j < cnt) { double d = (double)v[j]; a += d; q += d * d; }
+    double t1, t2;
+    double rs = tp_s[blockIdx.x] + block_scan_excl<dalg>(a, lds_w, t1);
+    double rq = tp_q[blockIdx.x] + block_scan_excl<dalg>(q, lds_w2, t2);
+    for (uint32_t j = 0; j < cnt; ++j) {
+        double d = (double)v[j];
+        rs += d; rq += d * d;
+        double cntd = (double)(base + j + 1);
+        double var = (rq - rs * rs / cntd) / cntd;
+        if (var < 0) var = 0;
+        out[base + j] = SD ? sqrt(var) : var;
+    }
+}
+template <class T> struct sq_alg {   // tile aggregate of x*x in double
+    using A = double;
+    __device__ static double identity() { return 0; }
+    __device__ static double lift(T v) { return (double)v * (double)v; }
+    __device__ static double op(double a, double b) { return a + b; }
+};
+
+template <class T, class ALG, int WR>
+int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out) {
+    using A = typename ALG::A;
+    uint32_t ntiles = (n + TS - 1) / TS;
+    AQG_TRY(aqg_ws_reset(ctx));
+    AQG_TRY(aqg_ws_ensure(ctx, (size_t)ntiles * sizeof(A) + 4096));
+    A* agg;
+    AQG_TRY(aqg_ws_get(ctx, ntiles, &agg));
+    hipLaunchKernelGGL((tile_reduce_kernel<T, ALG>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, agg);
+    hipLaunchKernelGGL((agg_scan_kernel<ALG>), dim3(1), dim3(SB), 0, ctx->stream, agg, ntiles);
+    aqg_kernel_timer_begin(ctx);
+    hipLaunchKernelGGL((tile_scan_kernel<T, ALG, WR>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, agg, out);
+    aqg_kernel_timer_end(ctx);
+    return aqg_check_launch(ctx, "prefix scan");
+}
+
+} // namespace
+
+extern "C" {
+
+int aqg_scan_out_dtype(int op, int t) {
+    if (!dt_is_num(t)) return AQG_ERROR;
+    switch (op) {
+    case AQG_SCAN_SUMS: case AQG_SCAN_SUMW: return aqg_long_type(t);
+    case AQG_SCAN_AVGS: case AQG_SCAN_AVGW: case AQG_SCAN_VARS: case AQG_SCAN_STDDEVS: case AQG_SCAN_VARW: case AQG_SCAN_STDDEVW: return AQG_DOUBLE;
+    case AQG_SCAN_MINS: case AQG_SCAN_MAXS: case AQG_SCAN_MINW: case AQG_SCAN_MAXW: case AQG_SCAN_DELTAS: case AQG_SCAN_PREV: case AQG_SCAN_NEXT: return t;
+    case AQG_SCAN_RATIOW: return aqg_fp_type(t);
+    }
+    return AQG_ERROR;
+}
+
+int aqg_scan(aqg_ctx* ctx, int op, int t, const void* xv, uint32_t n, uint32_t w, void* out) {
+    if (!ctx || (!xv && n) || (!out && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_scan: bad argument");
+    if (op < 0 || op > AQG_SCAN_STDDEVW) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_scan: bad op");
+    // w == 0 is undefined in the reference for sumw/avgw/varw (reads ret[-1], divides by zero)
+    if (w == 0 && (op == AQG_SCAN_SUMW || op == AQG_SCAN_AVGW || op == AQG_SCAN_VARW || op == AQG_SCAN_STDDEVW))
+        return aqg_fail(ctx, AQG_ERR_ARG, "aqg_scan: window 0 is undefined for sumw/avgw/varw");
+    if (n == 0) return AQG_OK;
+    return aqg_dispatch_num(t, [&](auto tt) -> int {
+        using T = typename decltype(tt)::type;
+        const T* x = static_cast<const T*>(xv);
+        const uint32_t ntiles = (n + TS - 1) / TS;
+        unsigned sgrid = aqg_grid(ctx, n, SB, 4, 16);
+        switch (op) {
+        case AQG_SCAN_SUMS: return run_prefix<T, sum_alg<T>, W_SUMS>(ctx, x, n, out);
+        case AQG_SCAN_AVGS: return run_prefix<T, sum_alg<T>, W_AVGS>(ctx, x, n, out);
+        case AQG_SCAN_MINS: return run_prefix<T, min_alg<T>, W_MINS>(ctx, x, n, out);
+        case AQG_SCAN_MAXS: return run_prefix<T, max_alg<T>, W_MAXS>(ctx, x, n, out);
+        case AQG_SCAN_DELTAS: hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_DELTAS>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, w, out); return aqg_check_launch(ctx, "deltas");
+        case AQG_SCAN_PREV: hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_PREV>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, w, out); return aqg_check_launch(ctx, "prev");
+        case AQG_SCAN_NEXT: hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_NEXT>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, w, out); return aqg_check_launch(ctx, "aggnext");
+        case AQG_SCAN_RATIOW: {
+            // aggregations.h:172-175: a window not smaller than the column degrades to w = 1
+            uint32_t len = n, ww = w;
+            if (n <= ww) len = 1;
+            ww = ww > len ? len : ww;
+            hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_RATIOW>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, ww, out);
+            return aqg_check_launch(ctx, "ratiow");
+        }
+        case AQG_SCAN_SUMW: case AQG_SCAN_AVGW: case AQG_SCAN_VARW: case AQG_SCAN_STDDEVW: {
+            using A = typename sum_alg<T>::A;
+            uint32_t ww = w > n ? n : w;                                        // w clamped to len (:241,264)
+            const bool var = op == AQG_SCAN_VARW || op == AQG_SCAN_STDDEVW;
+            size_t lds = var ? (size_t)(TS + ww - 1) * sizeof(double) * 2 : (size_t)(TS + ww - 1) * sizeof(A);
+            if constexpr (std::is_floating_point_v<T>) {
+                if (!var && ww <= 64) {
+                    aqg_kernel_timer_begin(ctx);
+                    if (op == AQG_SCAN_SUMW) hipLaunchKernelGGL((window_direct_kernel<T, 0>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, ww, static_cast<double*>(out));
+                    else hipLaunchKernelGGL((window_direct_kernel<T, 1>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, ww, static_cast<double*>(out));
+                    aqg_kernel_timer_end(ctx);
+                    return aqg_check_launch(ctx, "window_direct_kernel");
+                }
+            }
+            if (lds <= HALO_MAX_BYTES) {
+                auto go = [&](auto kern) -> int {
+                    AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    aqg_kernel_timer_begin(ctx);
+                    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(SB), lds, ctx->stream, x, n, ww, out);
+                    aqg_kernel_timer_end(ctx);
+                    return aqg_check_launch(ctx, "window_sum_kernel");
+                };
+                switch (op) {
+                case AQG_SCAN_SUMW: return go(&window_sum_kernel<T, 0>);
+                case AQG_SCAN_AVGW: return go(&window_sum_kernel<T, 1>);
+                case AQG_SCAN_VARW: return go(&window_sum_kernel<T, 2>);
+                default: return go(&window_sum_kernel<T, 3>);
+                }
+            }
+            if (var) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_scan: varw/stddevw window too large for the LDS halo");
+            // wide window: global inclusive prefix, then the difference
+            AQG_TRY(aqg_ws_reset(ctx));
+            AQG_TRY(aqg_ws_ensure(ctx, (size_t)ntiles * sizeof(A) + (size_t)n * sizeof(A) + 8192));
+            A *agg, *S;
+            AQG_TRY(aqg_ws_get(ctx, ntiles, &agg));
+            AQG_TRY(aqg_ws_get(ctx, n, &S));
+            hipLaunchKernelGGL((tile_reduce_kernel<T, sum_alg<T>>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, agg);
+            hipLaunchKernelGGL((agg_scan_kernel<sum_alg<T>>), dim3(1), dim3(SB), 0, ctx->stream, agg, ntiles);
+            hipLaunchKernelGGL((tile_scan_raw_kernel<T>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, agg, S);
+            if (op == AQG_SCAN_SUMW) hipLaunchKernelGGL((prefix_diff_kernel<T, 0>), dim3(sgrid), dim3(SB), 0, ctx->stream, S, n, ww, out);
+            else hipLaunchKernelGGL((prefix_diff_kernel<T, 1>), dim3(sgrid), dim3(SB), 0, ctx->stream, S, n, ww, out);
+            return aqg_check_launch(ctx, "wide window sum");
+        }
+        case AQG_SCAN_MINW: case AQG_SCAN_MAXW: {
+            const bool is_max = op == AQG_SCAN_MAXW;
+            // the deque never expires anything when w == 0 or w >= n: plain running min / max (no seed)
+            uint32_t ww = (w == 0 || w > n) ? n : w;
+            if (ww == n) return is_max ? run_prefix<T, max_alg<T>, W_MAXP>(ctx, x, n, out) : run_prefix<T, min_alg<T>, W_MINS>(ctx, x, n, out);
+            size_t lds = (size_t)(TS + ww - 1) * sizeof(T) * 2;
+            if (lds <= HALO_MAX_BYTES) {
+                auto go = [&](auto kern) -> int {
+                    AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    aqg_kernel_timer_begin(ctx);
+                    hipLaunchKernelGGL(kern, dim3(ntiles), dim3(SB), lds, ctx->stream, x, n, ww, static_cast<T*>(out));
+                    aqg_kernel_timer_end(ctx);
+                    return aqg_check_launch(ctx, "window_minmax_kernel");
+                };
+                return is_max ? go(&window_minmax_kernel<T, true>) : go(&window_minmax_kernel<T, false>);
+            }
+            // wide window: doubling passes through HBM
+            AQG_TRY(aqg_ws_reset(ctx));
+            AQG_TRY(aqg_ws_ensure(ctx, (size_t)n * sizeof(T) * 2 + 8192));
+            T *b0, *b1;
+            AQG_TRY(aqg_ws_get(ctx, n, &b0));
+            AQG_TRY(aqg_ws_get(ctx, n, &b1));
+            uint32_t K = 0;
+            while ((2u << K) <= ww && K < 31) ++K;
+            const T* src = x;
+            T* dst = b0;
+            for (uint32_t k = 0; k < K; ++k) {
+                if (is_max) hipLaunchKernelGGL((doubling_pass_kernel<T, true>), dim3(sgrid), dim3(SB), 0, ctx->stream, src, dst, n, 1u << k);
+                else hipLaunchKernelGGL((doubling_pass_kernel<T, false>), dim3(sgrid), dim3(SB), 0, ctx->stream, src, dst, n, 1u << k);
+                src = dst;
+                dst = dst == b0 ? b1 : b0;
+            }
+            if (is_max) hipLaunchKernelGGL((doubling_final_kernel<T, true>), dim3(sgrid), dim3(SB), 0, ctx->stream, src, static_cast<T*>(out), n, ww, 1u << K);
+            else hipLaunchKernelGGL((doubling_final_kernel<T, false>), dim3(sgrid), dim3(SB), 0, ctx->stream, src, static_cast<T*>(out), n, ww, 1u << K);
+            return aqg_check_launch(ctx, "wide window min/max");
+        }
+        case AQG_SCAN_VARS: case AQG_SCAN_STDDEVS: {
+            AQG_TRY(aqg_ws_reset(ctx));
+            AQG_TRY(aqg_ws_ensure(ctx, (size_t)ntiles * 16 + 8192));
+            double *a1, *a2;
+            AQG_TRY(aqg_ws_get(ctx, ntiles, &a1));
+            AQG_TRY(aqg_ws_get(ctx, ntiles, &a2));
+            hipLaunchKernelGGL((tile_reduce_kernel<T, dsum_alg<T>>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, a1);
+            hipLaunchKernelGGL((tile_reduce_kernel<T, sq_alg<T>>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, a2);
+            hipLaunchKernelGGL((agg_scan_kernel<dsum_alg<T>>), dim3(1), dim3(SB), 0, ctx->stream, a1, ntiles);
+            hipLaunchKernelGGL((agg_scan_kernel<dsum_alg<T>>), dim3(1), dim3(SB), 0, ctx->stream, a2, ntiles);
+            if (op == AQG_SCAN_VARS) hipLaunchKernelGGL((vars_kernel<T, false>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, a1, a2, static_cast<double*>(out));
+            else hipLaunchKernelGGL((vars_kernel<T, true>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, a1, a2, static_cast<double*>(out));
+            return aqg_check_launch(ctx, "vars");
+        }
+        }
+        return AQG_ERR_ARG;
+    });
+}
+
+} // extern "C"
