@@ -148,7 +148,10 @@ def main():
             "config": {"workload": f"h2o_groupby_q1_sum_v1_by_id1_{n:.0e}_rows_per_gpu", "rows_per_gpu": n, "K": 100,
                        "seed": 42, "groups": int(final.ngroups), "parallelism": f"row-range shards x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # PMC-measured HBM bytes per launch at 1e9 rows (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
+                         # profiles/r1_bench_q1_1e9_pmc.md): 8.0007 GB read + 0.0121 GB written; scaled to this run's rows
+                         "traffic": 8.0128e9 * n / 1e9,
                          "kernel": "agg_kernel<LDS,K32,1>", "kernel_ms": k_ms, "algorithmic_bytes": Q1_BYTES_PER_ROW * n},
         }
         if world == 1 and args.cpu_sample > 0:
