@@ -33,7 +33,8 @@ constexpr uint32_t FAIL = 0xFFFFFFFFu;
 enum : int { ACC_ADD_I = 0, ACC_ADD_F = 1, ACC_MIN = 2, ACC_MAX = 3 };
 enum : int { VC_I = 0, VC_U = 1, VC_F = 2 };   // value class of a column: signed / unsigned / floating
 
-struct KeySpec { int nkeys; int dt[MAXKEYS]; const void* col[MAXKEYS]; int shift[MAXKEYS]; int total_bytes; };
+// wide != 0: the tuple does not fit 64 bits; the table then stores a REPRESENTATIVE ROW per slot and compares key columns
+struct KeySpec { int nkeys; int dt[MAXKEYS]; const void* col[MAXKEYS]; int shift[MAXKEYS]; int total_bytes; int wide; };
 // square: accumulate x*x (in the promoted type).  part: 0 whole value; 1 / 2 = low / high 32 bits of an 8-byte
 // integer, so that sums of 8-byte integers stay exact (the two 64-bit accumulators cannot overflow for n < 2^32)
 struct AccSpec { int nacc; int kind[MAXACC]; int dt[MAXACC]; const void* col[MAXACC]; int square[MAXACC]; int part[MAXACC]; };
@@ -190,6 +191,41 @@ __device__ inline uint32_t gt_find(const GTable& gt, uint64_t key) {
     }
     return FAIL;
 }
+// ---- wide tuples: slot word = representative row, equality = column-wise compare against that row ----------
+__device__ inline uint32_t hash_wide(const KeySpec& ks, size_t row) {
+    uint64_t h = 0x7c5f3e9a1b2d4c6bull;
+    for (int j = 0; j < ks.nkeys; ++j) h = (h ^ load_bits(ks.dt[j], ks.col[j], row)) * 0x9E3779B97F4A7C15ull;
+    return (uint32_t)(h >> 32) ^ (uint32_t)h;
+}
+__device__ inline bool rows_equal(const KeySpec& ks, size_t a, size_t b) {
+    for (int j = 0; j < ks.nkeys; ++j) if (load_bits(ks.dt[j], ks.col[j], a) != load_bits(ks.dt[j], ks.col[j], b)) return false;
+    return true;
+}
+__device__ inline uint32_t gt_find_or_insert_wide(const GTable& gt, const KeySpec& ks, uint32_t row) {
+    uint32_t mask = gt.cap - 1, s = hash_wide(ks, row) & mask;
+    for (uint32_t p = 0; p < gt.cap; ++p) {
+        uint64_t cur = gt.keys[s];
+        if (cur == EMPTY64) {
+            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&gt.keys[s]), EMPTY64, (unsigned long long)row);
+            if (old == EMPTY64) return s;
+            cur = old;
+        }
+        if (rows_equal(ks, (uint32_t)cur, row)) return s;
+        s = (s + 1) & mask;
+    }
+    gt.flags[0] = 1;
+    return FAIL;
+}
+__device__ inline uint32_t gt_find_wide(const GTable& gt, const KeySpec& ks, uint32_t row) {
+    uint32_t mask = gt.cap - 1, s = hash_wide(ks, row) & mask;
+    for (uint32_t p = 0; p < gt.cap; ++p) {
+        uint64_t cur = gt.keys[s];
+        if (cur == EMPTY64) return FAIL;
+        if (rows_equal(ks, (uint32_t)cur, row)) return s;
+        s = (s + 1) & mask;
+    }
+    return FAIL;
+}
 __device__ inline void gt_touch_first(const GTable& gt, uint32_t s, uint32_t row) {
     // gt.first[s] only decreases: a stale (larger) value just costs one redundant atomic
     if (row < gt.first[s]) atomicMin(&gt.first[s], row);
@@ -270,7 +306,7 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
 
     // one row whose slot is known
     auto to_global = [&](uint64_t key, uint32_t row, const uint64_t* vals) {
-        uint32_t g = gt_find_or_insert(gt, key);
+        uint32_t g = ks.wide ? gt_find_or_insert_wide(gt, ks, row) : gt_find_or_insert(gt, key);
         if (g == FAIL) return;
         gt_touch_first(gt, g, row);
         if (need_count) atomicAdd(&gt.count[g], 1u);
@@ -286,9 +322,12 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
             pack<uint32_t, 4> kv = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(ks.col[0]) + base);
 #pragma unroll
             for (int j = 0; j < 4; ++j) key[j] = kv.v[j];
-        } else {
+        } else if (!ks.wide) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) key[j] = pack_key(ks, base + j);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) key[j] = base + j;
         }
         uint64_t vals[NACC ? NACC : 1][4];
         _Pragma("unroll") for (int a = 0; a < NACC; ++a) val_operand4(as.dt[a], as.col[a], base, as.kind[a], as.square[a], as.part[a], vals[a]);
@@ -360,7 +399,7 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
     if (blockIdx.x == 0) {
         uint32_t row = (nchunk << 2) + threadIdx.x;
         if (row < n) {
-            uint64_t k = pack_key(ks, row);
+            uint64_t k = ks.wide ? (uint64_t)row : pack_key(ks, row);
             uint64_t v1[NACC ? NACC : 1];
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) v1[a] = val_operand(as.dt[a], as.col[a], row, as.kind[a], as.square[a], as.part[a]);
             to_global(k, row, v1);
@@ -488,7 +527,7 @@ __device__ inline aqg_i128 mul_u64(uint64_t a, uint64_t b) {
 
 // what each requested aggregate reads from the accumulators
 struct AggOut { int op; int dt; int acc0; int acc1; int acc2; int acc3; void* out; };   // wide (8-byte integer) sums: acc0/acc2 = low, acc1/acc3 = high halves
-struct EmitSpec { int nagg; AggOut agg[MAXAGG]; int nkeys; int key_dt[MAXKEYS]; int key_shift[MAXKEYS]; void* key_out[MAXKEYS];
+struct EmitSpec { int nagg; AggOut agg[MAXAGG]; int nkeys; int key_dt[MAXKEYS]; int key_shift[MAXKEYS]; void* key_out[MAXKEYS]; int wide; const void* key_col[MAXKEYS];
                   uint32_t* first_out; uint32_t* count_out; };
 
 template <class T> __device__ inline void store_minmax(void* out, uint32_t g, uint64_t mapped, bool is_max) {
@@ -508,7 +547,7 @@ __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __
         uint32_t s = occ[i], g = gid_of_occ[i];
         uint64_t key = s == gt.cap ? EMPTY64 : gt.keys[s];
         for (int k = 0; k < es.nkeys; ++k) {
-            uint64_t bits = key >> es.key_shift[k];
+            uint64_t bits = es.wide ? load_bits(es.key_dt[k], es.key_col[k], (size_t)(uint32_t)key) : key >> es.key_shift[k];
             switch (aqg_dtype_size_dev(es.key_dt[k])) {
             case 1: static_cast<uint8_t*>(es.key_out[k])[g] = (uint8_t)bits; break;
             case 2: static_cast<uint16_t*>(es.key_out[k])[g] = (uint16_t)bits; break;
@@ -589,7 +628,7 @@ __global__ void __launch_bounds__(256) assign_kernel(KeySpec ks, GTable gt, cons
     const uint32_t nchunk = n >> 2;
     const bool vec_ok = ks.nkeys == 1 && ks.total_bytes == 4;
     auto one = [&](uint64_t key) -> uint32_t {
-        uint32_t s = gt_find(gt, key);
+        uint32_t s = ks.wide ? gt_find_wide(gt, ks, (uint32_t)key) : gt_find(gt, key);
         uint32_t g = s == FAIL ? 0u : slot_gid[s];
         if constexpr (LDS_COUNTS) atomicAdd(&lc[g], 1u); else atomicAdd(&counts[g], 1u);
         return g;
@@ -603,7 +642,7 @@ __global__ void __launch_bounds__(256) assign_kernel(KeySpec ks, GTable gt, cons
             for (int j = 0; j < 4; ++j) key[j] = kv.v[j];
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) key[j] = pack_key(ks, base + j);
+            for (int j = 0; j < 4; ++j) key[j] = ks.wide ? (uint64_t)(base + j) : pack_key(ks, base + j);
         }
         pack<uint32_t, 4> o;
 #pragma unroll
@@ -612,7 +651,7 @@ __global__ void __launch_bounds__(256) assign_kernel(KeySpec ks, GTable gt, cons
     }
     if (blockIdx.x == 0) {
         uint32_t row = (nchunk << 2) + threadIdx.x;
-        if (row < n) reversemap[row] = one(pack_key(ks, row));
+        if (row < n) reversemap[row] = one(ks.wide ? (uint64_t)row : pack_key(ks, row));
     }
     if constexpr (LDS_COUNTS) {
         __syncthreads();
@@ -650,7 +689,8 @@ int make_keyspec(aqg_ctx* ctx, int nkeys, const int* dts, const void* const* key
         ks->dt[j] = dts[j]; ks->col[j] = keys[j]; ks->shift[j] = bits;
         bits += 8 * (int)aqg_dtype_size(dts[j]);
     }
-    if (bits > 64) return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: key tuples wider than 8 bytes are not supported yet");
+    ks->wide = bits > 64;
+    if (ks->wide) for (int j = 0; j < nkeys; ++j) ks->shift[j] = 0;
     ks->total_bytes = bits / 8;
     return AQG_OK;
 }
@@ -712,7 +752,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     const bool k32 = ks.nkeys == 1 && ks.total_bytes == 4;
     uint32_t gcap = next_pow2((uint64_t)(hint < 512 ? 512 : hint) * 2);
     // LDS mode while one workgroup's table (75 % load) fits 64 KB; otherwise rows go straight to HBM
-    bool use_lds = hint <= 3072;
+    bool use_lds = hint <= 3072 && !ks.wide;   // wide tuples compare against HBM-resident rows: HBM mode
     uint32_t lcap = use_lds ? next_pow2((uint64_t)(hint < 64 ? 64 : hint) * 4 / 3 + 1) : 0;
     if (use_lds && lcap < 256) lcap = 256;
     const size_t lds_slot_bytes = 8 + 8 * (size_t)as.nacc + (k32 ? 0 : 4) + (plan.need_count ? 4 : 0);
@@ -814,13 +854,14 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     EmitSpec es;
     memset(&es, 0, sizeof es);
     es.nkeys = ks.nkeys;
+    es.wide = ks.wide;
     {
         size_t kc[MAXKEYS];
         for (int k = 0; k < ks.nkeys; ++k) {
             h->key_dt[k] = ks.dt[k];
             kc[k] = h->cap_groups * aqg_dtype_size(ks.dt[k]);
             if (h->cap_groups < gcapn || !h->keys_out[k]) { size_t c = h->keys_out[k] ? kc[k] : 0; AQG_TRY(dev_realloc(ctx, &h->keys_out[k], &c, gcapn * 8)); }
-            es.key_dt[k] = ks.dt[k]; es.key_shift[k] = ks.shift[k]; es.key_out[k] = h->keys_out[k];
+            es.key_dt[k] = ks.dt[k]; es.key_shift[k] = ks.shift[k]; es.key_out[k] = h->keys_out[k]; es.key_col[k] = ks.col[k];
         }
         if (h->cap_groups < gcapn || !h->first_rows) {
             size_t c = h->first_rows ? h->cap_groups * 4 : 0; AQG_TRY(dev_realloc(ctx, (void**)&h->first_rows, &c, gcapn * 4));

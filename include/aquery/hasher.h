@@ -1,0 +1,190 @@
+// hasher.h -- hash group-by front door of the AQuery library API (reference server/hasher.h).
+//   hasher<Ts...>            tuple hash functor (spelled `transTypes<record_t, hasher>` by generated code)
+//   AQHashTable<Key, Hash>   per-row `hashtable_push(Key&&, i)` + `ht_postproc(n)` (:146-199)
+//   HashTableFactory<K,H>::get(cols...) -> HashTableComponents{size, keys, values, offsets} (:201-207,:327-357;
+//                            does not compile in the reference -- defects D2/D3 -- implemented here for real)
+// The table itself lives on the MI355X (aqg_groupby_build + aqg_groupby_postproc through the C-ABI).
+// Contract = the reference's executable path: dense group ids in FIRST-OCCURRENCE order, row-id lists in
+// DESCENDING row order inside a group, offsets[g] = start of group g in the flat row-id buffer.
+// The hash function is not observable in results; the device uses its own.
+#pragma once
+#include <functional>
+#include <tuple>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "types.h"
+#include "vector_type.hpp"
+
+template <class... Types> struct hasher {
+    size_t operator()(const std::tuple<Types...>& rec) const {
+        size_t h = 0x7c5f3e9a1b2d4c6bULL;
+        std::apply([&](const auto&... f) { ((h = (h ^ std::hash<std::decay_t<decltype(f)>>()(f)) * 0x9E3779B97F4A7C15ULL), ...); }, rec);
+        return h;
+    }
+};
+template <typename Key, typename Val> using aq_map = std::unordered_map<Key, Val>;
+template <typename Key> using aq_set = std::unordered_set<Key>;
+
+template <class> class ColRef;
+
+namespace aq {
+
+struct GroupTable {          // host-side view of one device group-by
+    uint32_t n = 0, G = 0;
+    uint32_t* offsets = nullptr;     // [G+1] malloc'd, host valid
+    uint32_t* counts = nullptr;      // [G]   malloc'd, host valid
+    uint32_t* row_ids = nullptr;     // [n]   malloc'd, device copy registered, host filled lazily
+    aqg_groupby* handle = nullptr;   // keeps reversemap / first_rows on the device
+};
+
+inline GroupTable build_groups(int nkeys, const int* dts, const void* const* dev_cols, uint32_t n, bool want_reversemap, uint32_t* reversemap_host) {
+    auto& rt = dev::Runtime::get();
+    GroupTable t;
+    t.n = n;
+    dev::check(aqg_groupby_build(rt.ctx(), nkeys, dts, dev_cols, n, 0, &t.handle), "aqg_groupby_build");
+    t.G = aqg_groupby_ngroups(t.handle);
+    t.offsets = static_cast<uint32_t*>(std::malloc(((size_t)t.G + 1) * 4));
+    t.counts = static_cast<uint32_t*>(std::malloc(((size_t)t.G + 1) * 4));
+    t.row_ids = static_cast<uint32_t*>(std::malloc(((size_t)n + 1) * 4));
+    void *doff = nullptr, *drows = nullptr;
+    dev::check(aqg_malloc(rt.ctx(), ((size_t)t.G + 1) * 4, &doff), "aqg_malloc");
+    dev::check(aqg_malloc(rt.ctx(), ((size_t)n + 1) * 4, &drows), "aqg_malloc");
+    dev::check(aqg_groupby_postproc(t.handle, static_cast<uint32_t*>(doff), static_cast<uint32_t*>(drows)), "aqg_groupby_postproc");
+    dev::check(aqg_d2h(rt.ctx(), t.offsets, doff, ((size_t)t.G + 1) * 4), "aqg_d2h");
+    if (t.G) dev::check(aqg_d2h(rt.ctx(), t.counts, aqg_groupby_counts(t.handle), (size_t)t.G * 4), "aqg_d2h");
+    if (want_reversemap && n) dev::check(aqg_d2h(rt.ctx(), reversemap_host, aqg_groupby_reversemap(t.handle), (size_t)n * 4), "aqg_d2h");
+    aqg_free(rt.ctx(), doff);
+    rt.adopt(t.row_ids, (size_t)n * 4, drows, /*host_valid=*/false);    // vecs[g] views resolve to the device copy
+    return t;
+}
+
+template <class T> inline void fetch_key_column(const GroupTable& t, int k, std::vector<T>& out) {
+    auto& rt = dev::Runtime::get();
+    out.resize(t.G);
+    if (!t.G) return;
+    void* d = nullptr;
+    dev::check(aqg_malloc(rt.ctx(), (size_t)t.G * sizeof(T), &d), "aqg_malloc");
+    dev::check(aqg_groupby_keys(t.handle, k, d), "aqg_groupby_keys");
+    dev::check(aqg_d2h(rt.ctx(), out.data(), d, (size_t)t.G * sizeof(T)), "aqg_d2h");
+    aqg_free(rt.ctx(), d);
+}
+
+template <class Tuple, size_t... Is> inline void fetch_keys(const GroupTable& t, std::vector<Tuple>& keys, std::index_sequence<Is...>) {
+    std::tuple<std::vector<std::tuple_element_t<Is, Tuple>>...> cols;
+    (fetch_key_column(t, (int)Is, std::get<Is>(cols)), ...);
+    keys.resize(t.G);
+    for (uint32_t g = 0; g < t.G; ++g) keys[g] = Tuple(std::get<Is>(cols)[g]...);
+}
+
+inline vector_type<uint32_t>* make_vecs(const GroupTable& t) {
+    auto vecs = static_cast<vector_type<uint32_t>*>(std::malloc(sizeof(vector_type<uint32_t>) * (t.G ? t.G : 1)));
+    for (uint32_t g = 0; g < t.G; ++g) vecs[g].init_from(t.counts[g], t.row_ids + t.offsets[g]);
+    return vecs;
+}
+
+} // namespace aq
+
+template <class... Ty> struct HashTableComponents {
+    uint32_t size;
+    std::vector<std::tuple<Ty...>>* keys;
+    vector_type<uint32_t>* values;
+    uint32_t* offsets;
+};
+
+template <class Key, class Hash>
+class AQHashTable {
+public:
+    uint32_t *reversemap = nullptr, *mapbase = nullptr, *ht_base = nullptr;
+    AQHashTable() = default;
+    explicit AQHashTable(uint32_t sz) { init(sz); }
+    void init(uint32_t sz) {
+        staged_.clear();
+        staged_.reserve(sz);
+        cap_ = sz;
+        reversemap = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * ((size_t)sz * 2 + 2)));
+        mapbase = reversemap + sz;
+        ht_base = static_cast<uint32_t*>(std::calloc((size_t)sz + 1, sizeof(uint32_t)));
+    }
+    // the reference assigns the dense id here; the device assigns all ids at once in finish()
+    inline void hashtable_push(Key&& k, uint32_t i) {
+        if (staged_.size() <= i) staged_.resize((size_t)i + 1);
+        staged_[i] = std::move(k);
+        done_ = false;
+    }
+    template <typename... Keys_t> inline void hashtable_push_all(Keys_t&... keys, uint32_t len) {
+        build_from_columns(len, keys...);
+    }
+    // counting sort of row ids by group: vecs[g] = rows of group g, DESCENDING; ht_base[g] = start offset
+    vector_type<uint32_t>* ht_postproc(uint32_t sz) {
+        finish(sz);
+        std::memcpy(ht_base, table_.offsets, (size_t)table_.G * 4);
+        auto vecs = aq::make_vecs(table_);
+        // expose the row lists through the reference's `mapbase` too (host copy)
+        aq::dev::Runtime::get().touch(table_.row_ids);
+        std::memcpy(mapbase, table_.row_ids, (size_t)sz * 4);
+        return vecs;
+    }
+    std::vector<Key>& values() { finish((uint32_t)staged_.size()); return keys_; }
+    size_t size() { finish((uint32_t)staged_.size()); return table_.G; }
+    ~AQHashTable() { if (table_.handle) aqg_groupby_destroy(table_.handle); std::free(table_.offsets); std::free(table_.counts); if (table_.row_ids) { aq::dev::Runtime::get().forget(table_.row_ids); std::free(table_.row_ids); } }
+
+private:
+    template <size_t... Is> void finish_staged(uint32_t n, std::index_sequence<Is...>) {
+        // unzip the staged tuples into columns, upload, group on the device
+        std::tuple<std::vector<std::tuple_element_t<Is, Key>>...> cols;
+        ((std::get<Is>(cols).resize(n)), ...);
+        for (uint32_t i = 0; i < n; ++i) ((std::get<Is>(cols)[i] = std::get<Is>(staged_[i])), ...);
+        const int dts[] = {aq::dev::tag_of<std::tuple_element_t<Is, Key>>::value...};
+        aq::dev::In ins[] = {aq::dev::In(std::get<Is>(cols).data(), (size_t)n * sizeof(std::tuple_element_t<Is, Key>), false)...};
+        const void* ptrs[sizeof...(Is)];
+        for (size_t k = 0; k < sizeof...(Is); ++k) ptrs[k] = ins[k].d;
+        table_ = aq::build_groups((int)sizeof...(Is), dts, ptrs, n, true, reversemap);
+        aq::fetch_keys(table_, keys_, std::index_sequence<Is...>{});
+    }
+    template <class... Cols> void build_from_columns(uint32_t n, Cols&... cols) {
+        const int dts[] = {aq::dev::tag_of<std::remove_cv_t<std::remove_pointer_t<decltype(cols.container)>>>::value...};
+        aq::dev::In ins[] = {aq::dev::In(cols.container, (size_t)n * sizeof(*cols.container), cols.capacity == 0)...};
+        const void* ptrs[sizeof...(Cols)];
+        for (size_t k = 0; k < sizeof...(Cols); ++k) ptrs[k] = ins[k].d;
+        table_ = aq::build_groups((int)sizeof...(Cols), dts, ptrs, n, true, reversemap);
+        aq::fetch_keys(table_, keys_, std::make_index_sequence<std::tuple_size_v<Key>>{});
+        for (uint32_t g = 0; g < table_.G; ++g) ht_base[g] = table_.counts[g];
+        done_ = true;
+    }
+    void finish(uint32_t n) {
+        if (done_) return;
+        finish_staged(n, std::make_index_sequence<std::tuple_size_v<Key>>{});
+        for (uint32_t g = 0; g < table_.G; ++g) ht_base[g] = table_.counts[g];
+        done_ = true;
+    }
+    std::vector<Key> staged_, keys_;
+    aq::GroupTable table_;
+    uint32_t cap_ = 0;
+    bool done_ = false;
+};
+
+// `HashTableFactory<record_t, transTypes<record_t, hasher>>::get<decays<decltype(c)>...>(c...)` (engine/ast.py:668-670):
+// the explicit template arguments are the COLUMN types, so `get` takes them as they are.
+template <class Key, class Hash, int PerfectHashingThreshold = 18>
+class HashTableFactory {
+public:
+    template <class... Cols>
+    static HashTableComponents<value_type_r<std::decay_t<Cols>>...> get(Cols&... cols) {
+        using Tuple = std::tuple<value_type_r<std::decay_t<Cols>>...>;
+        uint32_t n = 0;
+        ((n = cols.size), ...);
+        const int dts[] = {aq::dev::tag_of<value_type_r<std::decay_t<Cols>>>::value...};
+        aq::dev::In ins[] = {aq::dev::In(cols.container, (size_t)n * sizeof(value_type_r<std::decay_t<Cols>>), cols.capacity == 0)...};
+        const void* ptrs[sizeof...(Cols)];
+        for (size_t k = 0; k < sizeof...(Cols); ++k) ptrs[k] = ins[k].d;
+        aq::GroupTable t = aq::build_groups((int)sizeof...(Cols), dts, ptrs, n, false, nullptr);
+        auto* keys = new std::vector<Tuple>();           // lives as long as the module, like the reference's
+        aq::fetch_keys(t, *keys, std::index_sequence_for<Cols...>{});
+        HashTableComponents<value_type_r<std::decay_t<Cols>>...> c{t.G, keys, aq::make_vecs(t), t.offsets};
+        std::free(t.counts);
+        // t.handle and t.row_ids stay alive for the lifetime of the components (released with the process / session)
+        return c;
+    }
+};

@@ -1,0 +1,390 @@
+// table.h -- ColRef<T>, TableInfo<Ts...> and the free element-wise operators of the AQuery library API
+// (reference server/table.h:60-258 ColRef, :380-617 TableInfo, :820-937 operators, :939-973 aqop_*).
+// Clean-room; operators dispatch to the HIP kernels through the C-ABI (aqg_ewise), result element types
+// follow the reference: `+ -` Coercion, `*` GetLongType, `/` GetFPType, comparisons bool.
+#pragma once
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <iostream>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "types.h"
+#include "vector_type.hpp"
+
+struct ColRef_cstorage {
+    void* container;
+    unsigned int size, capacity;
+    const char* name;
+    int ty;
+};
+
+#ifdef __AQ__HAS__INT128__
+inline std::ostream& operator<<(std::ostream& os, __int128 v) {
+    if (v == 0) return os << '0';
+    bool neg = v < 0;
+    unsigned __int128 u = neg ? (unsigned __int128)(-(v + 1)) + 1 : (unsigned __int128)v;
+    char buf[48]; int i = 47; buf[i] = 0;
+    while (u) { buf[--i] = char('0' + (int)(u % 10)); u /= 10; }
+    if (neg) buf[--i] = '-';
+    return os << (buf + i);
+}
+inline std::ostream& operator<<(std::ostream& os, unsigned __int128 u) {
+    if (u == 0) return os << '0';
+    char buf[48]; int i = 47; buf[i] = 0;
+    while (u) { buf[--i] = char('0' + (int)(u % 10)); u /= 10; }
+    return os << (buf + i);
+}
+#endif
+
+template <class T> struct TableStats {
+    T minima{};
+    unsigned char bits = 255;
+};
+
+template <typename _Ty>
+class ColRef : public vector_type<_Ty> {
+public:
+    typedef ColRef<_Ty> Decayed_t;
+    const char* name = "";
+    types::Type_t ty = types::Type_t::ERROR;
+    TableStats<_Ty> stats;
+
+    ColRef() : vector_type<_Ty>(), name("") {}
+    ColRef(const uint32_t& n, const char* nm = "") : vector_type<_Ty>(n), name(nm) {}
+    ColRef(const char* nm) : name(nm) {}
+    ColRef(const uint32_t n, void* data, const char* nm = "") : vector_type<_Ty>(n, data), name(nm) {}
+    ColRef(const char* nm, types::Type_t t) : name(nm), ty(t) {}
+    ColRef(const ColRef<_Ty>& o) : vector_type<_Ty>(static_cast<const vector_type<_Ty>&>(o)), name(o.name), ty(o.ty) {}
+    ColRef(ColRef<_Ty>&& o) : vector_type<_Ty>(std::move(static_cast<vector_type<_Ty>&>(o))), name(o.name), ty(o.ty) {}
+
+    void init(const char* nm = "") { ty = types::Types<_Ty>::getType(); this->size = this->capacity = 0; this->container = nullptr; name = nm; }
+    // bind a borrowed buffer (zero-copy view of the data source)
+    void initfrom(uint32_t sz, void* data, const char* nm = "") { ty = types::Types<_Ty>::getType(); this->size = sz; this->capacity = 0; this->container = (_Ty*)data; name = nm; }
+    // take over the buffer of a temporary (the usual `out->get_col<k>().initfrom(<expr>, "name")`)
+    template <template <typename> class VT, typename T> void initfrom(VT<T>&& v, const char* nm = "") {
+        ty = types::Types<_Ty>::getType();
+        this->size = v.size; this->capacity = v.capacity; this->container = (_Ty*)v.container; name = nm;
+        v.capacity = 0;
+    }
+    template <template <typename> class VT, typename T> void initfrom(VT<T>& v, const char* nm = "") {
+        ty = types::Types<_Ty>::getType();
+        this->size = v.size; this->capacity = 0; this->container = (_Ty*)v.container; name = nm;
+    }
+    template <template <typename> class VT, typename T> void initfrom(const VT<T>& v, const char* nm = "") {
+        ty = types::Types<_Ty>::getType();
+        this->size = v.size; this->capacity = 0; this->container = (_Ty*)v.container; name = nm;
+    }
+    void initfrom(vectortype_cstorage v, const char* nm = "") { ty = types::Types<_Ty>::getType(); this->size = v.size; this->capacity = v.capacity; this->container = (_Ty*)v.container; name = nm; }
+    // a scalar result becomes a one-row column
+    template <typename T, std::enable_if_t<!aq::is_column<T>::value>* = nullptr> void initfrom(const T& v, const char* nm = "") {
+        ty = types::Types<_Ty>::getType();
+        this->size = 0; this->capacity = 0; this->container = nullptr;
+        this->emplace_back((_Ty)v);
+        name = nm;
+    }
+    template <class T> ColRef<_Ty>& operator=(ColRef<T>&& o) { this->container = (_Ty*)o.container; this->size = o.size; this->capacity = o.capacity; o.capacity = 0; return *this; }
+    ColRef<_Ty>& operator=(const _Ty& v) { vector_type<_Ty>::operator=(v); return *this; }
+    ColRef<_Ty>& operator=(const ColRef<_Ty>& o) { vector_type<_Ty>::operator=(static_cast<const vector_type<_Ty>&>(o)); return *this; }
+    ColRef<_Ty>& operator=(ColRef<_Ty>&& o) noexcept { vector_type<_Ty>::operator=(std::move(static_cast<vector_type<_Ty>&>(o))); return *this; }
+
+    using vector_type<_Ty>::operator[];
+    using vector_type<_Ty>::subvec;
+    using vector_type<_Ty>::subvec_memcpy;
+    using vector_type<_Ty>::subvec_deep;
+
+    // gather by row ids: ret[i] = col[idx[i]] (reference :184-189) -- one HIP gather
+    vector_type<_Ty> operator[](const vector_type<uint32_t>& idxs) const {
+        vector_type<_Ty> ret(idxs.size);
+        if (idxs.size == 0) return ret;
+        if constexpr (aq::dev::on_device<_Ty>) {
+            auto& rt = aq::dev::Runtime::get();
+            void* dout = rt.result(ret.container, (size_t)idxs.size * sizeof(_Ty));
+            // the column's extent is unknown for `ColRef<T>(0, ptr)`-style views: the device copy must already exist or be borrowed
+            aq::dev::In col(this->container, (size_t)this->size * sizeof(_Ty), this->capacity == 0);
+            aq::dev::In ids(idxs.container, (size_t)idxs.size * 4, idxs.capacity == 0);
+            aq::dev::check(aqg_gather(rt.ctx(), aq::dev::tag_of<_Ty>::value, col.d, static_cast<const uint32_t*>(ids.d), idxs.size, dout), "aqg_gather");
+        } else {
+            for (uint32_t i = 0; i < idxs.size; ++i) ret.container[i] = this->container[idxs[i]];
+        }
+        return ret;
+    }
+    // boolean mask filter as a true stream compaction (the reference prepends `size` junk slots: defect D11)
+    vector_type<_Ty> operator[](const std::vector<bool>& mask) const {
+        std::vector<uint8_t> m(mask.size());
+        for (size_t i = 0; i < mask.size(); ++i) m[i] = mask[i];
+        return filter(m.data(), (uint32_t)m.size());
+    }
+    vector_type<_Ty> operator[](const vector_type<bool>& mask) const {
+        vector_type<_Ty> ret(this->size);
+        uint32_t m = 0;
+        if (this->size) {
+            auto& rt = aq::dev::Runtime::get();
+            void* dout = rt.result(ret.container, (size_t)this->size * sizeof(_Ty));
+            aq::dev::In col(this->container, (size_t)this->size * sizeof(_Ty), this->capacity == 0);
+            aq::dev::In mk(mask.container, (size_t)mask.size, mask.capacity == 0);
+            aq::dev::check(aqg_compact(rt.ctx(), aq::dev::tag_of<_Ty>::value, col.d, static_cast<const uint8_t*>(mk.d), this->size, dout, &m), "aqg_compact");
+        }
+        ret.size = m;
+        return ret;
+    }
+    vector_type<_Ty> filter(const uint8_t* mask, uint32_t n) const {
+        vector_type<bool> mk((bool*)mask, n);
+        return (*this)[mk];
+    }
+
+    // min / width statistics used by the perfect-hash plan of the reference (:76-91); computed on the device
+    bool populate_stats() {
+        if constexpr (std::is_integral_v<_Ty>) {
+            if (stats.bits <= 128) return true;
+            if (this->size == 0) { stats.minima = 0; stats.bits = 0; return true; }
+            auto& rt = aq::dev::Runtime::get();
+            aq::dev::In col(this->container, (size_t)this->size * sizeof(_Ty), this->capacity == 0);
+            unsigned char lo[16], hi[16];
+            aq::dev::check(aqg_reduce(rt.ctx(), AQG_RED_MIN, aq::dev::tag_of<_Ty>::value, col.d, this->size, lo), "aqg_reduce");
+            aq::dev::check(aqg_reduce(rt.ctx(), AQG_RED_MAX, aq::dev::tag_of<_Ty>::value, col.d, this->size, hi), "aqg_reduce");
+            _Ty mn, mx;
+            std::memcpy(&mn, lo, sizeof(_Ty)); std::memcpy(&mx, hi, sizeof(_Ty));
+            stats.minima = mn;
+            unsigned long long range = (unsigned long long)(mx - mn);
+            unsigned char b = 0;
+            while (b < 64 && (1ull << b) < range + 1) ++b;
+            stats.bits = b;
+            return true;
+        }
+        return false;
+    }
+
+    void out(uint32_t n = 1000, const char* sep = " ") const { vector_type<_Ty>::out(n, sep); }
+    ColRef<_Ty>* rename(const char* nm) { name = nm; return this; }
+    template <typename T> ColRef<T> scast() { this->ty = types::Types<T>::getType(); return *(ColRef<T>*)this; }
+    ColRef_cstorage s() { ColRef_cstorage c{this->container, this->size, this->capacity, name, (int)ty}; return c; }
+};
+template <> class ColRef<void> : public ColRef<int> {};
+using uColRef = ColRef<void>;
+
+template <class V> struct is_vector_impl<ColRef<V>> : std::true_type {};
+template <class V> struct is_vector_impl<vector_type<V>> : std::true_type {};
+template <class T> constexpr static bool is_vector(const ColRef<T>&) { return true; }
+template <class T> constexpr static bool is_vector(const vector_type<T>&) { return true; }
+
+template <template <class...> class VT, class T, std::enable_if_t<std::is_base_of_v<vector_base<T>, VT<T>>>* = nullptr>
+std::ostream& operator<<(std::ostream& os, const VT<T>& v) { v.out(); return os; }
+
+// ---- output table ---------------------------------------------------------------------------------------------
+// Columns are stored as a tuple of correctly typed ColRefs (the reference reinterprets a ColRef<void>[] with a
+// 40-byte stride, which overlaps 8-byte columns: defect D10).
+template <class... Types> struct TableInfo;
+
+template <long long _Index, class... _Types> constexpr auto& get(const TableInfo<_Types...>& table) noexcept {
+    return const_cast<TableInfo<_Types...>&>(table).template get_col<(size_t)_Index>();
+}
+
+namespace aq {
+inline void append_value(std::string& s, const char* v) { s += v ? v : ""; }
+inline void append_value(std::string& s, astring_view v) { s += v.rstr ? v.rstr : ""; }
+inline void append_value(std::string& s, bool v) { s += v ? "true" : "false"; }
+inline void append_value(std::string& s, float v) { char b[64]; std::snprintf(b, sizeof b, "%f", v); s += b; }
+inline void append_value(std::string& s, double v) { char b[64]; std::snprintf(b, sizeof b, "%lf", v); s += b; }
+inline void append_value(std::string& s, long double v) { char b[96]; std::snprintf(b, sizeof b, "%Lf", v); s += b; }
+#ifdef __AQ__HAS__INT128__
+inline void append_value(std::string& s, __int128 v) {
+    if (v == 0) { s += '0'; return; }
+    bool neg = v < 0;
+    unsigned __int128 u = neg ? (unsigned __int128)(-(v + 1)) + 1 : (unsigned __int128)v;
+    char buf[48]; int i = 47; buf[i] = 0;
+    while (u) { buf[--i] = char('0' + (int)(u % 10)); u /= 10; }
+    if (neg) buf[--i] = '-';
+    s += buf + i;
+}
+inline void append_value(std::string& s, unsigned __int128 u) {
+    if (u == 0) { s += '0'; return; }
+    char buf[48]; int i = 47; buf[i] = 0;
+    while (u) { buf[--i] = char('0' + (int)(u % 10)); u /= 10; }
+    s += buf + i;
+}
+#endif
+template <class T, std::enable_if_t<std::is_integral_v<T> && !std::is_same_v<T, bool>>* = nullptr>
+inline void append_value(std::string& s, T v) { s += std::to_string(v); }
+} // namespace aq
+
+template <class... Types>
+struct TableInfo {
+    const char* name;
+    uint32_t n_cols;
+    typedef std::tuple<Types...> tuple_type;
+    std::tuple<ColRef<Types>...> cols;
+
+    TableInfo(const char* nm, uint32_t) : name(nm), n_cols(sizeof...(Types)) { init_names(nullptr, std::index_sequence_for<Types...>{}); }
+    TableInfo(const char* nm = "", const char** col_names = nullptr) : name(nm), n_cols(sizeof...(Types)) { init_names(col_names, std::index_sequence_for<Types...>{}); }
+
+    template <size_t i = 0> auto& get_col() { return std::get<i>(cols); }
+    TableInfo<Types...>* rename(const char* nm) { name = nm; return this; }
+    uint32_t rows() const { return std::get<0>(cols).size; }
+
+    std::string get_header_string(const char* __restrict sep, const char* __restrict end) const {
+        std::string h;
+        header_names(h, sep, std::index_sequence_for<Types...>{});
+        std::string line(h.size(), '=');
+        return h + end + line + end;
+    }
+    // `print(*tbl)`: header, rule, one row per line through operator<<
+    void print(const char* __restrict sep, const char* __restrict end) const {
+        std::cout << get_header_string(sep, end);
+        const uint32_t n = n_cols ? rows() : 0;
+        for (uint32_t i = 0; i < n; ++i) { print_row(i, sep, std::index_sequence_for<Types...>{}); std::cout << end; }
+    }
+    // `printall(sep, end, view, fp, limit)`: printf-style values; vector-valued columns are flattened (one output row per
+    // element, the other columns repeated), as the reference's print2 does
+    void printall(const char* __restrict sep = ",", const char* __restrict end = "\n", const vector_type<uint32_t>* __restrict view = nullptr,
+                  FILE* __restrict fp = nullptr, uint32_t limit = std::numeric_limits<uint32_t>::max()) const {
+        FILE* o = fp ? fp : stdout;
+        std::string h;
+        if (fp) { csv_names(h, sep, std::index_sequence_for<Types...>{}); }
+        else { h = get_header_string(sep, end); h.resize(h.size() - std::strlen(end)); }
+        std::fprintf(o, "%s%s", h.c_str(), end);
+        const uint32_t total = view ? view->size : rows();
+        const uint32_t n = limit > total ? total : limit;
+        for (uint32_t r = 0; r < n; ++r) {
+            std::vector<std::string> fields;
+            flatten<0>(view ? (*view)[r] : r, fields, o, sep, end);
+        }
+    }
+
+private:
+    template <size_t... Is> void init_names(const char** names, std::index_sequence<Is...>) { (std::get<Is>(cols).init(names ? names[Is] : ""), ...); }
+    template <size_t... Is> void header_names(std::string& h, const char* sep, std::index_sequence<Is...>) const {
+        size_t k = 0;
+        ((h += std::string(std::get<Is>(cols).name) + (++k < sizeof...(Is) ? std::string(sep) + '|' + sep : std::string())), ...);
+    }
+    template <size_t... Is> void csv_names(std::string& h, const char* sep, std::index_sequence<Is...>) const {
+        size_t k = 0;
+        ((h += std::string(std::get<Is>(cols).name) + (++k < sizeof...(Is) ? std::string(sep) : std::string())), ...);
+    }
+    template <size_t... Is> void print_row(uint32_t i, const char* sep, std::index_sequence<Is...>) const {
+        size_t k = 0;
+        ((std::cout << std::get<Is>(cols)[i], (++k < sizeof...(Is) ? (void)(std::cout << sep) : (void)0)), ...);
+    }
+    template <size_t j> void flatten(uint32_t row, std::vector<std::string>& fields, FILE* o, const char* sep, const char* end) const {
+        if constexpr (j == sizeof...(Types)) {
+            std::string line;
+            for (size_t k = 0; k < fields.size(); ++k) { line += fields[k]; if (k + 1 < fields.size()) line += sep; }
+            std::fprintf(o, "%s%s", line.c_str(), end);
+        } else {
+            using CT = std::tuple_element_t<j, tuple_type>;
+            const auto& v = std::get<j>(cols)[row];
+            if constexpr (is_vector_type<CT>) {
+                for (uint32_t e = 0; e < v.size; ++e) {
+                    std::string s; aq::append_value(s, v[e]);
+                    fields.push_back(s);
+                    flatten<j + 1>(row, fields, o, sep, end);
+                    fields.pop_back();
+                }
+            } else {
+                std::string s; aq::append_value(s, v);
+                fields.push_back(s);
+                flatten<j + 1>(row, fields, o, sep, end);
+                fields.pop_back();
+            }
+        }
+    }
+};
+
+template <class... Types> void print(const TableInfo<Types...>& v, const char* delimiter = " ", const char* endline = "\n") { v.print(delimiter, endline); }
+template <class T, std::enable_if_t<!aq::is_column<T>::value>* = nullptr> void print(const T& v, const char* delimiter = " ") { std::cout << v << delimiter; }
+// a column: every element through print(elem) followed by the delimiter, then the end of line
+template <class T, template <typename> class VT, std::enable_if_t<aq::is_column<VT<T>>::value>* = nullptr>
+void print(const VT<T>& v, const char* delimiter = " ", const char* endline = "\n") {
+    for (uint32_t i = 0; i < v.size; ++i) { print(v[i]); std::cout << delimiter; }
+    std::cout << endline;
+}
+
+// ---- free element-wise operators (reference :820-937) ------------------------------------------------------------------
+namespace aq {
+template <class T1, template <typename> class VT> constexpr bool vt_ok = std::is_base_of_v<vector_base<T1>, VT<T1>>;
+template <class T1, class T2> using co_t = typename types::Coercion<T1, T2>::type;
+}
+
+#define AQ_FREE_OP(sym, code, RESULT)                                                                                           \
+    template <class T1, class T2, template <typename> class VT, template <typename> class VT2,                                  \
+              std::enable_if_t<aq::vt_ok<T1, VT> && aq::vt_ok<T2, VT2>>* = nullptr>                                              \
+    decayed_t<VT, RESULT> operator sym(const VT<T1>& lhs, const VT2<T2>& rhs) {                                                 \
+        decayed_t<VT, RESULT> ret(lhs.size);                                                                                    \
+        aq::device_binary(code, lhs, rhs, static_cast<vector_type<RESULT>&>(ret));                                              \
+        return ret;                                                                                                             \
+    }                                                                                                                           \
+    template <class T1, class T2, template <typename> class VT, std::enable_if_t<aq::vt_ok<T1, VT> && std::is_arithmetic_v<T2>>* = nullptr> \
+    decayed_t<VT, RESULT> operator sym(const VT<T1>& lhs, const T2& rhs) {                                                      \
+        decayed_t<VT, RESULT> ret(lhs.size);                                                                                    \
+        aq::device_binary(code, lhs, rhs, static_cast<vector_type<RESULT>&>(ret));                                              \
+        return ret;                                                                                                             \
+    }                                                                                                                           \
+    template <class T1, class T2, template <typename> class VT, std::enable_if_t<aq::vt_ok<T1, VT> && std::is_arithmetic_v<T2>>* = nullptr> \
+    decayed_t<VT, RESULT> operator sym(const T2& lhs, const VT<T1>& rhs) {                                                      \
+        decayed_t<VT, RESULT> ret(rhs.size);                                                                                    \
+        aq::device_binary(code, lhs, rhs, static_cast<vector_type<RESULT>&>(ret));                                              \
+        return ret;                                                                                                             \
+    }
+#define AQ_COMMA ,
+AQ_FREE_OP(-, AQG_OP_SUB, aq::co_t<T1 AQ_COMMA T2>)
+AQ_FREE_OP(+, AQG_OP_ADD, aq::co_t<T1 AQ_COMMA T2>)
+AQ_FREE_OP(*, AQG_OP_MUL, types::GetLongType<aq::co_t<T1 AQ_COMMA T2>>)
+AQ_FREE_OP(/, AQG_OP_DIV, types::GetFPType<aq::co_t<T1 AQ_COMMA T2>>)
+#undef AQ_FREE_OP
+
+// free comparisons -> VT<bool>; the reference only has `>` (:917-937), the other five are additions
+#define AQ_FREE_CMP(sym, code)                                                                                                  \
+    template <class T1, class T2, template <typename> class VT, template <typename> class VT2,                                  \
+              std::enable_if_t<aq::vt_ok<T1, VT> && aq::vt_ok<T2, VT2>>* = nullptr>                                              \
+    VT<bool> operator sym(const VT<T1>& lhs, const VT2<T2>& rhs) {                                                              \
+        VT<bool> ret(lhs.size);                                                                                                 \
+        aq::device_binary(code, lhs, rhs, static_cast<vector_type<bool>&>(ret));                                                \
+        return ret;                                                                                                             \
+    }
+AQ_FREE_CMP(>, AQG_OP_GT)
+AQ_FREE_CMP(<, AQG_OP_LT)
+AQ_FREE_CMP(>=, AQG_OP_GE)
+AQ_FREE_CMP(<=, AQG_OP_LE)
+#undef AQ_FREE_CMP
+#define AQ_FREE_CMP_S(sym, code, rcode)                                                                                          \
+    template <class T1, class T2, template <typename> class VT, std::enable_if_t<aq::vt_ok<T1, VT> && !std::is_same_v<VT<T1>, vector_type<T1>> && std::is_arithmetic_v<T2>>* = nullptr> \
+    VT<bool> operator sym(const VT<T1>& lhs, const T2& rhs) {                                                                   \
+        VT<bool> ret(lhs.size);                                                                                                 \
+        aq::device_binary(code, lhs, rhs, static_cast<vector_type<bool>&>(ret));                                                \
+        return ret;                                                                                                             \
+    }                                                                                                                           \
+    template <class T1, class T2, template <typename> class VT, std::enable_if_t<aq::vt_ok<T1, VT> && std::is_arithmetic_v<T2>>* = nullptr> \
+    VT<bool> operator sym(const T2& lhs, const VT<T1>& rhs) {                                                                   \
+        VT<bool> ret(rhs.size);                                                                                                 \
+        aq::device_binary(code, lhs, rhs, static_cast<vector_type<bool>&>(ret));                                                \
+        return ret;                                                                                                             \
+    }
+AQ_FREE_CMP_S(>, AQG_OP_GT, AQG_OP_LT)
+AQ_FREE_CMP_S(<, AQG_OP_LT, AQG_OP_GT)
+AQ_FREE_CMP_S(>=, AQG_OP_GE, AQG_OP_LE)
+AQ_FREE_CMP_S(<=, AQG_OP_LE, AQG_OP_GE)
+#undef AQ_FREE_CMP_S
+
+// out-parameter forms `aqop_<op>(l, r, ret)` (reference :939-973): ret[i] = l[i] OP r[i], ret keeps its own element type
+#define AQ_AQOP(x, code)                                                                          \
+    template <class T1, class T2, template <typename> class VT, class Ret>                        \
+    void aqop_##x(const VT<T1>& lhs, const VT<T2>& rhs, Ret& ret) {                               \
+        using RT = std::remove_cv_t<std::remove_pointer_t<decltype(ret.container)>>;              \
+        aq::device_binary(code, lhs, rhs, static_cast<vector_type<RT>&>(ret));                    \
+    }
+AQ_AQOP(add, AQG_OP_ADD)
+AQ_AQOP(minus, AQG_OP_SUB)
+AQ_AQOP(mul, AQG_OP_MUL)
+AQ_AQOP(div, AQG_OP_DIV)
+AQ_AQOP(and, AQG_OP_AND)
+AQ_AQOP(or, AQG_OP_OR)
+AQ_AQOP(xor, AQG_OP_XOR)
+AQ_AQOP(gt, AQG_OP_GT)
+AQ_AQOP(lt, AQG_OP_LT)
+AQ_AQOP(gte, AQG_OP_GE)
+AQ_AQOP(lte, AQG_OP_LE)
+AQ_AQOP(eq, AQG_OP_EQ)
+AQ_AQOP(neq, AQG_OP_NE)
+#undef AQ_AQOP

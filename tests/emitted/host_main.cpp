@@ -1,0 +1,59 @@
+// Minimal host for generated modules, in the shape of the reference's server/server.cpp 'P' message handling
+// (:271 dlopen, :152-161 __AQ_Init_GC__, :301-305 dlsym + call): loads a module, installs an in-memory DataSource
+// holding the reference's own tiny fixtures, runs the named entry points.
+//   host_main <module.so> <dataset> <function>...
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "aquery/libaquery.h"
+
+static std::vector<std::vector<int>> dataset(const std::string& name) {
+    if (name == "moving_avg_asc")   // data/moving_avg.csv ordered by Month (what ASSUMING ASC Mont delivers)
+        return {{1, 2, 3, 4, 5}, {100, 120, 140, 140, 130}};
+    if (name == "moving_avg_desc")
+        return {{5, 4, 3, 2, 1}, {130, 140, 140, 120, 100}};
+    if (name == "stock")            // tests/stock.a:3-18
+        return {{1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16}, {15, 19, 16, 17, 15, 13, 5, 8, 7, 13, 11, 14, 10, 5, 2, 5}};
+    if (name == "stock_desc")
+        return {{16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2, 1}, {5, 2, 5, 10, 14, 11, 13, 7, 8, 5, 13, 15, 17, 16, 19, 15}};
+    if (name == "test_csv")         // data/test.csv columns a, b, c, d
+        return {{1, 2, 2, 1, 1, 4, 2, 2, 1, 3, 1, 3, 2, 3, 2, 2, 2, 3, 2, 1},
+                {1, 1, 4, 2, 2, 2, 1, 1, 2, 2, 2, 2, 1, 3, 2, 3, 4, 4, 3, 2},
+                {2, 2, 3, 2, 3, 1, 3, 1, 3, 4, 3, 1, 4, 4, 3, 4, 1, 1, 2, 3},
+                {2, 2, 4, 2, 4, 4, 3, 2, 4, 2, 3, 2, 2, 4, 1, 4, 2, 2, 2, 1}};
+    return {};
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) { std::fprintf(stderr, "usage: %s module.so dataset function...\n", argv[0]); return 2; }
+    Context* cxt = new Context();
+    Config cfg{};
+    cfg.backend_type = BACKEND_AQuery;
+    cxt->cfg = &cfg;
+    auto cols = dataset(argv[2]);
+    if (cols.empty()) { std::fprintf(stderr, "unknown dataset %s\n", argv[2]); return 2; }
+    ColumnDataSource ds;
+    std::vector<void*> ptrs;
+    for (auto& c : cols) ptrs.push_back(c.data());
+    ds.set((long long)cols[0].size(), ptrs);
+    ds.connect(cxt);
+    cxt->curr_server = &ds;
+    cxt->alt_server[BACKEND_AQuery] = &ds;
+
+    void* handle = dlopen(argv[1], RTLD_NOW);
+    if (!handle) { std::fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
+    if (auto init = reinterpret_cast<void (*)(Context*)>(dlsym(handle, "__AQ_Init_GC__"))) init(cxt);
+    int rc = 0;
+    for (int i = 3; i < argc; ++i) {
+        auto fn = reinterpret_cast<code_snippet>(dlsym(handle, argv[i]));
+        if (!fn) { std::fprintf(stderr, "dlsym %s: %s\n", argv[i], dlerror()); return 1; }
+        rc |= fn(cxt);
+        std::fflush(stdout);
+    }
+    cxt->end_session();
+    return rc;
+}

@@ -135,7 +135,7 @@ def check_agg(gpu, oracle, keys, vals, hint):
         gb.destroy()
 
 
-GB_CASES = [(1, 1000, 10, 0), (1, 50000, 100, 128), (1, 30000, 3000, 0), (2, 40000, 20, 0), (2, 40000, 300, 0),
+GB_CASES = [(3, 40000, 8, 0), (6, 30000, 3, 0), (3, 5000, 40, 0), (1, 1000, 10, 0), (1, 50000, 100, 128), (1, 30000, 3000, 0), (2, 40000, 20, 0), (2, 40000, 300, 0),
             (1, 1, 1, 0), (2, 17, 2, 0), (1, 200000, 100000, 0), (1, 100003, 100, 100)]
 
 
@@ -178,8 +178,6 @@ def test_groupby_build(gpu, oracle):
 def test_groupby_golden(gpu):
     for c in [c for c in gu.load() if c["fn"] == "groupby"]:
         keys = [gu.dec(k) for k in c["keys"]]
-        if sum(k.dtype.itemsize for k in keys) > 8:
-            continue  # wide tuples: not on device yet
         g = gpu.groupby_build(keys)
         assert g.ngroups == c["ngroups"]
         assert np.array_equal(g.reversemap(), gu.dec(c["reversemap"]))

@@ -1,0 +1,97 @@
+"""Drop-in check of the header-level API: modules written in the exact shape the reference's code generator emits
+(tests/emitted/*.cpp) are compiled UNCHANGED against include/aquery (CPU, at build time) and run on the GPU through a
+minimal dlopen host; their printed results are compared with the values the real reference library produces
+(SURVEY.md 8c KATs / tests/golden)."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EM = os.path.join(HERE, "emitted")
+
+
+def build():
+    subprocess.check_call(["make", "-C", EM, "-j", "4"], stdout=subprocess.DEVNULL)
+
+
+def run(module, dataset, *funcs, cwd=None):
+    exe = os.path.join(EM, "build", "host_main")
+    out = subprocess.run([exe, os.path.join(EM, "build", module), dataset, *funcs], capture_output=True, text=True, timeout=300, cwd=cwd or EM)
+    assert out.returncode == 0, out.stderr + out.stdout
+    return out.stdout
+
+
+def test_emitted_modules_compile():
+    """CPU: the generated-shape translation units compile and link against the new library"""
+    build()
+    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "host_main"):
+        assert os.path.exists(os.path.join(EM, "build", m))
+
+
+@pytest.mark.gpu
+def test_moving_avg(tmp_path):
+    build()
+    out = run("moving_avg.so", "moving_avg_asc", "dll_2Cxoox", cwd=str(tmp_path))
+    lines = out.strip().splitlines()
+    assert lines[0] == "Mont | avgw3ysales"
+    rows = [l.split() for l in lines[2:7]]
+    assert [int(r[0]) for r in rows] == [1, 2, 3, 4, 5]
+    assert [float(r[1]) for r in rows] == pytest.approx([100, 110, 120, 133.333, 136.667], abs=1e-3)
+    assert lines[-1] == "done."
+    csv = open(tmp_path / "moving_avg_output.csv").read().strip().splitlines()
+    assert csv[0] == "Mont;avgw3ysales"
+    assert csv[1:] == ["1;100.000000", "2;110.000000", "3;120.000000", "4;133.333333", "5;136.666667"]
+
+
+@pytest.mark.gpu
+def test_moving_avg_groupby_flatten(tmp_path):
+    build()
+    run("moving_avg.so", "moving_avg_desc", "dll_6Ywxmn", cwd=str(tmp_path))
+    csv = open(tmp_path / "flatten.csv").read().strip().splitlines()
+    # one group per month (descending month order = first occurrence), one sales value each -> mins(2, .) of one element
+    assert csv[0] == "Mont,minw2ysales"
+    assert csv[1:] == ["5,130", "4,140", "3,140", "2,120", "1,100"]
+
+
+@pytest.mark.gpu
+def test_stock_queries():
+    build()
+    out = run("stock.so", "stock", "dll_q1", "dll_q2", "dll_q3mask")
+    body = [l for l in out.splitlines() if l and not l.startswith("=") and "done" not in l]
+    assert body[1].strip() == "18", out          # q1: max(price - min(timestamp))
+    assert body[3].strip() == "9", out           # q2: max(price - mins(price))
+    assert body[4] == "1111110001010000", out    # q3 mask: price - timestamp > 1
+    assert body[5].split() == ["15", "19", "16", "17", "15", "13", "13", "14"], out
+    out4 = run("stock.so", "stock_desc", "dll_q2")   # q4: ASSUMING DESC timestamp
+    assert [l for l in out4.splitlines() if l.strip().isdigit()][0].strip() == "17"
+
+
+@pytest.mark.gpu
+def test_groupby_q1_sql():
+    build()
+    out = run("groupby_q1.so", "test_csv", "dll_3kR9pQ")
+    lines = out.strip().splitlines()
+    assert lines[0] == "sumc | b | d | cnt | avgc"
+    rows = [l.split() for l in lines[2:-1]]
+    assert len(rows) == 16, out
+    # reference: 16 groups in first-occurrence order of (a,b,d); sum(c) per group
+    assert [int(r[0]) for r in rows] == [2, 7, 3, 2, 6, 1, 3, 5, 3, 4, 3, 4, 1, 1, 2, 3]
+    assert [(int(r[1]), int(r[2])) for r in rows][:4] == [(1, 2), (1, 2), (4, 4), (2, 2)]
+    assert [int(r[3]) for r in rows] == [1, 3, 1, 1, 2, 1, 1, 2, 1, 1, 1, 1, 1, 1, 1, 1]
+    assert float(rows[1][4]) == pytest.approx(7 / 3, abs=1e-5)
+
+
+@pytest.mark.gpu
+def test_aqhashtable_shape():
+    build()
+    out = run("aqhashtable_shape.so", "test_csv", "dll_7Hs2mk")
+    lines = out.strip().splitlines()
+    assert lines[0].startswith("a,|,b,|,avgw2yc") or lines[0].startswith("a")
+    rows = [l.split(",") for l in lines[2:-1]]
+    # group (a=1,b=1) is row 0 only: c=2 -> avgw = 2.0
+    assert rows[0] == ["1", "1", "2.000000"], out
+    # group (a=2,b=1): rows 12,7,6,1 (descending) -> c = 4,1,3,2 -> avgw(2) = 4, 2.5, 2, 2.5
+    assert rows[1:5] == [["2", "1", "4.000000"], ["2", "1", "2.500000"], ["2", "1", "2.000000"], ["2", "1", "2.500000"]], out
+    # group (a=2,b=4): rows 16,2 -> c = 1,3 -> 1, 2
+    assert rows[5:7] == [["2", "4", "1.000000"], ["2", "4", "2.000000"]], out
