@@ -19,217 +19,13 @@
 //   grouped_kernel    aqg_grouped_reduce: accumulators indexed by dense id.
 //   radix passes      aqg_groupby_postproc: stable partition of row ids by group id.
 // HBM roofline: agg = sum of key and value bytes per row (h2o Q1: 8 B/row); build = 12 B/row.
-#include "aqg_internal.hpp"
-#include "dev_common.hpp"
-#include "groupby_handle.hpp"
+#include "groupby_dev.hpp"
+
+// partition.hip
+size_t aqg_partition_ws_bytes(uint32_t n, int ksz, const AccSpec& as, uint32_t pbits);
+int aqg_partition_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t pbits, uint32_t lcap, int need_count, GTable out, uint32_t out_cap);
 
 namespace {
-
-constexpr uint64_t EMPTY64 = ~0ull;
-constexpr uint32_t EMPTY32 = 0x80000000u;   // nullval<int> (server/types.h:458) doubles as the LDS empty mark
-constexpr uint32_t NOROW = 0xFFFFFFFFu;
-constexpr uint32_t FAIL = 0xFFFFFFFFu;
-
-enum : int { ACC_ADD_I = 0, ACC_ADD_F = 1, ACC_MIN = 2, ACC_MAX = 3 };
-enum : int { VC_I = 0, VC_U = 1, VC_F = 2 };   // value class of a column: signed / unsigned / floating
-
-// wide != 0: the tuple does not fit 64 bits; the table then stores a REPRESENTATIVE ROW per slot and compares key columns
-struct KeySpec { int nkeys; int dt[MAXKEYS]; const void* col[MAXKEYS]; int shift[MAXKEYS]; int total_bytes; int wide; };
-// square: accumulate x*x (in the promoted type).  part: 0 whole value; 1 / 2 = low / high 32 bits of an 8-byte
-// integer, so that sums of 8-byte integers stay exact (the two 64-bit accumulators cannot overflow for n < 2^32)
-struct AccSpec { int nacc; int kind[MAXACC]; int dt[MAXACC]; const void* col[MAXACC]; int square[MAXACC]; int part[MAXACC]; };
-struct GTable {
-    uint64_t* keys;      // [cap+1]  EMPTY64; slot `cap` holds the group whose packed key equals EMPTY64
-    uint32_t* first;     // [cap+1]  NOROW
-    uint32_t* count;     // [cap+1]  0 (may be null)
-    uint64_t* acc[MAXACC];
-    uint32_t cap;        // power of two
-    uint32_t* flags;     // [0] overflow, [1] number of occupied slots (after collect)
-};
-
-__host__ __device__ inline int aqg_dtype_size_dev(int dt) {
-    switch (dt) {
-    case AQG_INT8: case AQG_UINT8: case AQG_BOOL: return 1;
-    case AQG_INT16: case AQG_UINT16: return 2;
-    case AQG_INT32: case AQG_UINT32: case AQG_FLOAT: return 4;
-    default: return 8;
-    }
-}
-__device__ inline uint32_t hash32(uint32_t k) { return (k * 0x9E3779B1u) ^ (k >> 15); }
-__device__ inline uint32_t hash64(uint64_t k) { k *= 0x9E3779B97F4A7C15ull; return (uint32_t)(k >> 32) ^ (uint32_t)k; }
-
-// order-preserving maps into uint64 so that MIN/MAX of every class are unsigned integer atomics
-__device__ inline uint64_t map_i(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; }
-__device__ inline int64_t unmap_i(uint64_t u) { return (int64_t)(u ^ 0x8000000000000000ull); }
-__device__ inline uint64_t map_f(double d) { uint64_t b = __builtin_bit_cast(uint64_t, d); return (b >> 63) ? ~b : (b | 0x8000000000000000ull); }
-__device__ inline double unmap_f(uint64_t u) { uint64_t b = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u; return __builtin_bit_cast(double, b); }
-
-__host__ __device__ inline int vclass(int dt) {
-    switch (dt) {
-    case AQG_FLOAT: case AQG_DOUBLE: return VC_F;
-    case AQG_UINT8: case AQG_UINT16: case AQG_UINT32: case AQG_UINT64: case AQG_BOOL: return VC_U;
-    default: return VC_I;
-    }
-}
-
-// raw bits of element i, zero-extended (key packing)
-__device__ inline uint64_t load_bits(int dt, const void* col, size_t i) {
-    switch (dt) {
-    case AQG_INT8: case AQG_UINT8: case AQG_BOOL: return static_cast<const uint8_t*>(col)[i];
-    case AQG_INT16: case AQG_UINT16: return static_cast<const uint16_t*>(col)[i];
-    case AQG_INT32: case AQG_UINT32: case AQG_FLOAT: return static_cast<const uint32_t*>(col)[i];
-    default: return static_cast<const uint64_t*>(col)[i];
-    }
-}
-__device__ inline uint64_t pack_key(const KeySpec& ks, size_t i) {
-    uint64_t k = load_bits(ks.dt[0], ks.col[0], i);
-    for (int j = 1; j < ks.nkeys; ++j) k |= load_bits(ks.dt[j], ks.col[j], i) << ks.shift[j];
-    return k;
-}
-
-// value of element i as the 64-bit operand of its accumulator
-//   ADD_I: two's complement int64 (unsigned inputs zero-extended), `x*x` in the promoted type if square
-//   ADD_F: double bits; MIN/MAX: order-preserving map
-template <class T> __device__ inline uint64_t val_operand_t(T v, int kind, int square, int part = 0) {
-    if constexpr (sizeof(T) == 8 && std::is_integral_v<T>) {
-        if (kind == ACC_ADD_I && part) {
-            uint64_t b = square ? (uint64_t)v * (uint64_t)v : (uint64_t)v;
-            if (part == 1) return b & 0xFFFFFFFFull;
-            if constexpr (std::is_unsigned_v<T>) return b >> 32; else return (uint64_t)((int64_t)b >> 32);
-        }
-    }
-    if constexpr (std::is_floating_point_v<T>) {
-        double d = square ? (double)(v * v) : (double)v;
-        return kind == ACC_ADD_F ? __builtin_bit_cast(uint64_t, d) : map_f(d);
-    } else {
-        if (kind == ACC_ADD_I) {
-            if (square) {
-                using P = decltype(v * v);
-                using UP = std::make_unsigned_t<P>;
-                P p = (P)((UP)(P)v * (UP)(P)v);
-                if constexpr (std::is_unsigned_v<P>) return (uint64_t)p; else return (uint64_t)(int64_t)p;
-            }
-            if constexpr (std::is_unsigned_v<T>) return (uint64_t)v; else return (uint64_t)(int64_t)v;
-        }
-        if constexpr (std::is_unsigned_v<T>) return (uint64_t)v; else return map_i((int64_t)v);
-    }
-}
-// dt == AQG_NONE: the operand is the row index itself (arg-max of the row id for FIRST; see aqg_grouped_reduce)
-__device__ inline uint64_t val_operand(int dt, const void* col, size_t i, int kind, int square, int part) {
-    if (dt == AQG_NONE) return (uint64_t)i;
-    switch (dt) {
-    case AQG_INT8: return val_operand_t(static_cast<const int8_t*>(col)[i], kind, square);
-    case AQG_INT16: return val_operand_t(static_cast<const int16_t*>(col)[i], kind, square);
-    case AQG_INT32: return val_operand_t(static_cast<const int32_t*>(col)[i], kind, square);
-    case AQG_INT64: return val_operand_t(static_cast<const int64_t*>(col)[i], kind, square, part);
-    case AQG_UINT8: case AQG_BOOL: return val_operand_t(static_cast<const uint8_t*>(col)[i], kind, square);
-    case AQG_UINT16: return val_operand_t(static_cast<const uint16_t*>(col)[i], kind, square);
-    case AQG_UINT32: return val_operand_t(static_cast<const uint32_t*>(col)[i], kind, square);
-    case AQG_UINT64: return val_operand_t(static_cast<const uint64_t*>(col)[i], kind, square, part);
-    case AQG_FLOAT: return val_operand_t(static_cast<const float*>(col)[i], kind, square);
-    default: return val_operand_t(static_cast<const double*>(col)[i], kind, square);
-    }
-}
-// four consecutive rows of a 4-byte column with one 16-byte load
-template <class T> __device__ inline void val_operand4_t(const void* col, size_t base, int kind, int square, int part, uint64_t (&o)[4]) {
-    pack<T, 4> v = *reinterpret_cast<const pack<T, 4>*>(static_cast<const T*>(col) + base);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = val_operand_t(v.v[j], kind, square, part);
-}
-__device__ inline void val_operand4(int dt, const void* col, size_t base, int kind, int square, int part, uint64_t (&o)[4]) {
-    if (dt == AQG_NONE) { o[0] = base; o[1] = base + 1; o[2] = base + 2; o[3] = base + 3; return; }
-    switch (dt) {
-    case AQG_INT8: val_operand4_t<int8_t>(col, base, kind, square, part, o); break;
-    case AQG_INT16: val_operand4_t<int16_t>(col, base, kind, square, part, o); break;
-    case AQG_INT32: val_operand4_t<int32_t>(col, base, kind, square, part, o); break;
-    case AQG_INT64: val_operand4_t<int64_t>(col, base, kind, square, part, o); break;
-    case AQG_UINT8: case AQG_BOOL: val_operand4_t<uint8_t>(col, base, kind, square, part, o); break;
-    case AQG_UINT16: val_operand4_t<uint16_t>(col, base, kind, square, part, o); break;
-    case AQG_UINT32: val_operand4_t<uint32_t>(col, base, kind, square, part, o); break;
-    case AQG_UINT64: val_operand4_t<uint64_t>(col, base, kind, square, part, o); break;
-    case AQG_FLOAT: val_operand4_t<float>(col, base, kind, square, part, o); break;
-    default: val_operand4_t<double>(col, base, kind, square, part, o); break;
-    }
-}
-
-__device__ inline void acc_apply(uint64_t* p, int kind, uint64_t v) {
-    switch (kind) {
-    case ACC_ADD_I: atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); break;
-    case ACC_ADD_F: atomicAdd(reinterpret_cast<double*>(p), __builtin_bit_cast(double, v)); break;
-    case ACC_MIN: atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); break;
-    default: atomicMax(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v); break;
-    }
-}
-__host__ __device__ inline uint64_t acc_init(int kind) { return kind == ACC_MIN ? ~0ull : 0ull; }
-
-// ---- global table ---------------------------------------------------------------------------
-// Slots only ever change EMPTY -> key, so a plain (possibly stale) load is safe: a stale EMPTY is
-// corrected by the device-scope compare-and-swap that follows.
-__device__ inline uint32_t gt_find_or_insert(const GTable& gt, uint64_t key) {
-    if (key == EMPTY64) return gt.cap;
-    uint32_t mask = gt.cap - 1, s = hash64(key) & mask;
-    for (uint32_t p = 0; p < gt.cap; ++p) {
-        uint64_t cur = gt.keys[s];
-        if (cur == key) return s;
-        if (cur == EMPTY64) {
-            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&gt.keys[s]), EMPTY64, key);
-            if (old == EMPTY64 || old == key) return s;
-        }
-        s = (s + 1) & mask;
-    }
-    gt.flags[0] = 1;   // table full
-    return FAIL;
-}
-__device__ inline uint32_t gt_find(const GTable& gt, uint64_t key) {
-    if (key == EMPTY64) return gt.cap;
-    uint32_t mask = gt.cap - 1, s = hash64(key) & mask;
-    for (uint32_t p = 0; p < gt.cap; ++p) {
-        uint64_t cur = gt.keys[s];
-        if (cur == key) return s;
-        if (cur == EMPTY64) return FAIL;
-        s = (s + 1) & mask;
-    }
-    return FAIL;
-}
-// ---- wide tuples: slot word = representative row, equality = column-wise compare against that row ----------
-__device__ inline uint32_t hash_wide(const KeySpec& ks, size_t row) {
-    uint64_t h = 0x7c5f3e9a1b2d4c6bull;
-    for (int j = 0; j < ks.nkeys; ++j) h = (h ^ load_bits(ks.dt[j], ks.col[j], row)) * 0x9E3779B97F4A7C15ull;
-    return (uint32_t)(h >> 32) ^ (uint32_t)h;
-}
-__device__ inline bool rows_equal(const KeySpec& ks, size_t a, size_t b) {
-    for (int j = 0; j < ks.nkeys; ++j) if (load_bits(ks.dt[j], ks.col[j], a) != load_bits(ks.dt[j], ks.col[j], b)) return false;
-    return true;
-}
-__device__ inline uint32_t gt_find_or_insert_wide(const GTable& gt, const KeySpec& ks, uint32_t row) {
-    uint32_t mask = gt.cap - 1, s = hash_wide(ks, row) & mask;
-    for (uint32_t p = 0; p < gt.cap; ++p) {
-        uint64_t cur = gt.keys[s];
-        if (cur == EMPTY64) {
-            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&gt.keys[s]), EMPTY64, (unsigned long long)row);
-            if (old == EMPTY64) return s;
-            cur = old;
-        }
-        if (rows_equal(ks, (uint32_t)cur, row)) return s;
-        s = (s + 1) & mask;
-    }
-    gt.flags[0] = 1;
-    return FAIL;
-}
-__device__ inline uint32_t gt_find_wide(const GTable& gt, const KeySpec& ks, uint32_t row) {
-    uint32_t mask = gt.cap - 1, s = hash_wide(ks, row) & mask;
-    for (uint32_t p = 0; p < gt.cap; ++p) {
-        uint64_t cur = gt.keys[s];
-        if (cur == EMPTY64) return FAIL;
-        if (rows_equal(ks, (uint32_t)cur, row)) return s;
-        s = (s + 1) & mask;
-    }
-    return FAIL;
-}
-__device__ inline void gt_touch_first(const GTable& gt, uint32_t s, uint32_t row) {
-    // gt.first[s] only decreases: a stale (larger) value just costs one redundant atomic
-    if (row < gt.first[s]) atomicMin(&gt.first[s], row);
-}
 
 // ---- the single-pass aggregation kernel -------------------------------------------------------
 // K32: one 4-byte key column (h2o Q1/Q3/Q4/Q5).  LDS slot = {key32, first_row32} in one 8-byte
@@ -309,8 +105,8 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
         uint32_t g = ks.wide ? gt_find_or_insert_wide(gt, ks, row) : gt_find_or_insert(gt, key);
         if (g == FAIL) return;
         gt_touch_first(gt, g, row);
-        if (need_count) atomicAdd(&gt.count[g], 1u);
-        _Pragma("unroll") for (int a = 0; a < NACC; ++a) acc_apply(&gt.acc[a][g], as.kind[a], vals[a]);
+        if (need_count) atomicAdd(gt.count_p(g), 1u);
+        _Pragma("unroll") for (int a = 0; a < NACC; ++a) acc_apply(gt.acc_p(a, g), as.kind[a], vals[a]);
     };
 
     const uint32_t nchunk = n >> 2;   // 4 consecutive rows per lane per step
@@ -419,17 +215,29 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
             if (first == NOROW) continue;          // never touched (covers the sentinel slot too)
             uint32_t g = gt_find_or_insert(gt, key);
             if (g == FAIL) continue;
-            atomicMin(&gt.first[g], first);
-            if (need_count) atomicAdd(&gt.count[g], lcount[s]);
-            _Pragma("unroll") for (int a = 0; a < NACC; ++a) acc_apply(&gt.acc[a][g], as.kind[a], lacc[(size_t)a * LT + s]);
+            atomicMin(gt.first_p(g), first);
+            if (need_count) atomicAdd(gt.count_p(g), lcount[s]);
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) acc_apply(gt.acc_p(a, g), as.kind[a], lacc[(size_t)a * LT + s]);
         }
+    }
+}
+
+__global__ void __launch_bounds__(256) occ_iota_kernel(uint32_t* __restrict__ occ, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) occ[i] = i;
+}
+__global__ void __launch_bounds__(256) gt_init_kernel(GTable gt, AccSpec as) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s <= gt.cap; s += gridDim.x * blockDim.x) {
+        *gt.key_p(s) = EMPTY64;
+        *gt.first_p(s) = NOROW;
+        *gt.count_p(s) = 0;
+        for (int a = 0; a < as.nacc; ++a) *gt.acc_p(a, s) = acc_init(as.kind[a]);
     }
 }
 
 // ---- dense ids in first-occurrence order --------------------------------------------------------
 __global__ void __launch_bounds__(256) collect_kernel(GTable gt, uint32_t* __restrict__ occ) {
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s <= gt.cap; s += gridDim.x * blockDim.x)
-        if (gt.first[s] != NOROW) occ[atomicAdd(&gt.flags[1], 1u)] = s;
+        if ((*gt.first_p(s)) != NOROW) occ[atomicAdd(&gt.flags[1], 1u)] = s;
 }
 // G <= 4096: rank by counting inside one workgroup
 __global__ void __launch_bounds__(1024) rank_small_kernel(GTable gt, const uint32_t* __restrict__ occ, uint32_t* __restrict__ gid_of_occ,
@@ -437,7 +245,7 @@ __global__ void __launch_bounds__(1024) rank_small_kernel(GTable gt, const uint3
     __shared__ uint32_t f[4096];
     uint32_t G = gt.flags[1];
     if (G > 4096) return;
-    for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) f[i] = gt.first[occ[i]];
+    for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) f[i] = (*gt.first_p(occ[i]));
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) {
         uint32_t mine = f[i], r = 0;
@@ -450,7 +258,7 @@ __global__ void __launch_bounds__(1024) rank_small_kernel(GTable gt, const uint3
 __global__ void __launch_bounds__(256) bitmap_set_kernel(GTable gt, const uint32_t* __restrict__ occ, uint32_t* __restrict__ bitmap) {
     uint32_t G = gt.flags[1];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) {
-        uint32_t r = gt.first[occ[i]];
+        uint32_t r = (*gt.first_p(occ[i]));
         atomicOr(&bitmap[r >> 5], 1u << (r & 31));
     }
 }
@@ -498,7 +306,7 @@ __global__ void __launch_bounds__(256) rank_bitmap_kernel(GTable gt, const uint3
                                                           uint32_t* __restrict__ gid_of_occ, uint32_t* __restrict__ slot_gid) {
     uint32_t G = gt.flags[1];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) {
-        uint32_t r = gt.first[occ[i]], w = r >> 5;
+        uint32_t r = (*gt.first_p(occ[i])), w = r >> 5;
         uint32_t rank = tile_prefix[w >> 10] + word_prefix[w] + __popc(bitmap[w] & ((1u << (r & 31)) - 1u));
         gid_of_occ[i] = rank;
         slot_gid[occ[i]] = rank;
@@ -545,7 +353,7 @@ __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __
     uint32_t G = gt.flags[1];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) {
         uint32_t s = occ[i], g = gid_of_occ[i];
-        uint64_t key = s == gt.cap ? EMPTY64 : gt.keys[s];
+        uint64_t key = s == gt.cap ? EMPTY64 : (*gt.key_p(s));
         for (int k = 0; k < es.nkeys; ++k) {
             uint64_t bits = es.wide ? load_bits(es.key_dt[k], es.key_col[k], (size_t)(uint32_t)key) : key >> es.key_shift[k];
             switch (aqg_dtype_size_dev(es.key_dt[k])) {
@@ -555,19 +363,19 @@ __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __
             default: static_cast<uint64_t*>(es.key_out[k])[g] = bits; break;
             }
         }
-        es.first_out[g] = gt.first[s];
-        uint32_t cnt = gt.count ? gt.count[s] : 0;
+        es.first_out[g] = (*gt.first_p(s));
+        uint32_t cnt = gt.has_count ? (*gt.count_p(s)) : 0;
         if (es.count_out) es.count_out[g] = cnt;
         for (int j = 0; j < es.nagg; ++j) {
             const AggOut& a = es.agg[j];
             int vc = vclass(a.dt);
-            uint64_t v0 = a.acc0 >= 0 ? gt.acc[a.acc0][s] : 0;
+            uint64_t v0 = a.acc0 >= 0 ? (*gt.acc_p(a.acc0, s)) : 0;
             const bool wide = a.dt == AQG_INT64 || a.dt == AQG_UINT64;
             // exact 128-bit sum (and sum of squares) of an integer column
             auto sum128 = [&](int lo_acc, int hi_acc) -> aqg_i128 {
-                uint64_t lo = gt.acc[lo_acc][s];
+                uint64_t lo = (*gt.acc_p(lo_acc, s));
                 if (!wide) return vc == VC_U ? i128_from_u64(lo) : i128_from_i64((int64_t)lo);
-                uint64_t hi = gt.acc[hi_acc][s];                       // sum of the high halves, to be shifted by 32
+                uint64_t hi = (*gt.acc_p(hi_acc, s));                       // sum of the high halves, to be shifted by 32
                 aqg_i128 h = vc == VC_U ? i128_from_u64(hi) : i128_from_i64((int64_t)hi);
                 aqg_i128 sh = {h.lo << 32, (h.hi << 32) | (h.lo >> 32)};
                 return i128_add(sh, i128_from_u64(lo));
@@ -586,7 +394,7 @@ __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __
             case AQG_RED_VAR: case AQG_RED_STDDEV: {                        // (ssq - s*s/(double)(n+1)) / (double)(n+1)
                 double np1 = (double)(uint32_t)(cnt + 1), d;
                 if (vc == VC_F) {
-                    double sd = __builtin_bit_cast(double, v0), q = __builtin_bit_cast(double, gt.acc[a.acc2][s]);
+                    double sd = __builtin_bit_cast(double, v0), q = __builtin_bit_cast(double, (*gt.acc_p(a.acc2, s)));
                     d = (q - sd * sd / np1) / np1;
                 } else {
                     aqg_i128 sm = sum128(a.acc0, a.acc1), q = sum128(a.acc2, a.acc3);
@@ -759,21 +567,48 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (use_lds && (size_t)(lcap + 1) * lds_slot_bytes > 64 * 1024) { use_lds = false; lcap = 0; }
     const bool small_rank = hint <= 4096;
     const uint32_t nwords = (n + 31) / 32, ntiles = (nwords + 1023) / 1024;
+    // groups beyond one LDS table: partition the rows instead of hammering an HBM table with scattered atomics
+    // (partition.hip); the build path keeps the HBM table because its second pass looks keys up in it
+    // Measured on MI355X, 1e9 rows (round 1): the partition pipeline is not yet faster than the HBM table (h2o Q5 157 ms vs
+    // 142 ms; its scatter passes run at ~1 TB/s), so it stays off until the scatter reaches streaming rates.
+    const bool use_part = false && !use_lds && !ks.wide && !for_build && n >= (1u << 16) && hint <= (1u << 25);
+    uint32_t part_lcap = 0, pbits = 0;
+    if (use_part) {
+        const size_t sb = 16 + 8 * (size_t)as.nacc;
+        part_lcap = 4096;
+        while ((size_t)(part_lcap + 1) * sb > 64 * 1024) part_lcap >>= 1;
+        uint64_t want_parts = ((uint64_t)hint + part_lcap / 2 - 1) / (part_lcap / 2);
+        pbits = 10;                                  // at least 1024 partitions: every CU gets several
+        while (pbits < 16 && (1ull << pbits) < want_parts) ++pbits;
+        gcap = (uint32_t)((uint64_t)hint + hint / 4 + 4096 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : (uint64_t)hint + hint / 4 + 4096);   // compact record table
+    }
 
     // ---- workspace ----------------------------------------------------------------------------
     size_t slots = (size_t)gcap + 1;
-    size_t need = slots * (8 + 4 + 4 + 8 * (size_t)as.nacc + 4 + 4 + 4) + 4096 + 256 * 16;
+    uint32_t stride = 16;
+    while (stride < 16 + 8 * (uint32_t)as.nacc) stride <<= 1;
+    size_t need = slots * ((size_t)stride + 4 + 4 + 4) + 4096 + 256 * 16;
     if (!small_rank) need += (size_t)nwords * 8 + (size_t)ntiles * 4 + 4096;
+    if (use_part) need += aqg_partition_ws_bytes(n, ks.total_bytes <= 4 ? 4 : 8, as, pbits) + 65536;
     AQG_TRY(aqg_ws_reset(ctx));
     AQG_TRY(aqg_ws_ensure(ctx, need));
     GTable gt;
     memset(&gt, 0, sizeof gt);
     gt.cap = gcap;
+    gt.has_count = plan.need_count;
     uint32_t *occ, *gid_of_occ, *slot_gid, *bitmap = nullptr, *word_prefix = nullptr, *tile_total = nullptr;
-    AQG_TRY(aqg_ws_get(ctx, slots, &gt.keys));
-    AQG_TRY(aqg_ws_get(ctx, slots, &gt.first));
-    if (plan.need_count) AQG_TRY(aqg_ws_get(ctx, slots, &gt.count));
-    for (int a = 0; a < as.nacc; ++a) AQG_TRY(aqg_ws_get(ctx, slots, &gt.acc[a]));
+    {
+        unsigned char* base = nullptr;
+        AQG_TRY(aqg_ws_get(ctx, slots * stride, &base));
+        const bool records = use_part || hint > (1u << 17);
+        if (records) {
+            gt.kb = base; gt.fb = base + 8; gt.cb = base + 12; gt.ab = base + 16;
+            gt.kst = gt.fst = gt.cst = gt.ast = stride; gt.astep = 8;
+        } else {
+            gt.kb = base; gt.fb = base + slots * 8; gt.cb = gt.fb + slots * 4; gt.ab = gt.cb + slots * 4;
+            gt.kst = 8; gt.fst = 4; gt.cst = 4; gt.ast = 8; gt.astep = (uint64_t)slots * 8;
+        }
+    }
     AQG_TRY(aqg_ws_get(ctx, 64, &gt.flags));
     AQG_TRY(aqg_ws_get(ctx, slots, &occ));
     AQG_TRY(aqg_ws_get(ctx, slots, &gid_of_occ));
@@ -783,15 +618,15 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(aqg_ws_get(ctx, nwords, &word_prefix));
         AQG_TRY(aqg_ws_get(ctx, ntiles + 1, &tile_total));
     }
-    AQG_HIP(ctx, hipMemsetAsync(gt.keys, 0xFF, slots * 8, ctx->stream));
-    AQG_HIP(ctx, hipMemsetAsync(gt.first, 0xFF, slots * 4, ctx->stream));
-    if (gt.count) AQG_HIP(ctx, hipMemsetAsync(gt.count, 0, slots * 4, ctx->stream));
-    for (int a = 0; a < as.nacc; ++a) AQG_HIP(ctx, hipMemsetAsync(gt.acc[a], as.kind[a] == ACC_MIN ? 0xFF : 0, slots * 8, ctx->stream));
+    if (!use_part) hipLaunchKernelGGL(gt_init_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, gt, as);
     AQG_HIP(ctx, hipMemsetAsync(gt.flags, 0, 64 * 4, ctx->stream));
     if (bitmap) AQG_HIP(ctx, hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, ctx->stream));
 
     // ---- pass over the rows ---------------------------------------------------------------------
-    if (n) {
+    if (n && use_part) {
+        AQG_TRY(aqg_partition_aggregate(ctx, ks, as, n, pbits, part_lcap, plan.need_count, gt, gcap));
+        hipLaunchKernelGGL(occ_iota_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, occ, (uint32_t)slots);
+    } else if (n) {
         uint32_t lrep = 1;
         if (use_lds) {   // replicate small tables: conflicts fall, LDS stays under ~32 KB per workgroup
             size_t per = (size_t)(lcap + 1) * (8 + 8 * (size_t)as.nacc + (k32 ? 0 : 4) + (plan.need_count ? 4 : 0));
@@ -828,7 +663,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     }
     // ---- dense ids ---------------------------------------------------------------------------------
     unsigned cgrid = aqg_grid(ctx, slots, 256, 1, 8);
-    hipLaunchKernelGGL(collect_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, gt, occ);
+    if (!(n && use_part)) hipLaunchKernelGGL(collect_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, gt, occ);
     uint32_t fl[2] = {0, 0};
     AQG_HIP(ctx, hipMemcpyAsync(fl, gt.flags, 8, hipMemcpyDeviceToHost, ctx->stream));
     AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));

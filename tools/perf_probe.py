@@ -1,0 +1,90 @@
+"""scratch: kernel timings for every config shape on the GPU box (HIP events around the whole call + dominant kernel)"""
+import sys
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import aquery2_amd as A
+import checker as ck
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
+which = sys.argv[2] if len(sys.argv) > 2 else "all"
+d = A.Device(0)
+K = 100
+cols = {}
+def col(c):
+    if c not in cols:
+        cols[c] = d.gen_column(c, 42, 0, n, n, K)
+    return cols[c]
+
+def timeit(name, bytes_per_row, fn, reps=4, kernel=True):
+    best, kbest = 1e9, 1e9
+    for _ in range(reps):
+        d.sync(); d.timer_start(); r = fn(); ms = d.timer_stop_ms()
+        best = min(best, ms)
+        if kernel:
+            try: kbest = min(kbest, d.last_kernel_ms())
+            except Exception: kbest = float('nan')
+    gbs = bytes_per_row * n / best / 1e6
+    kg = bytes_per_row * n / kbest / 1e6 if kernel and kbest == kbest else float('nan')
+    print(f"{name:34s} {best:9.3f} ms  {n/best/1e6:8.1f} Grows/s  call {gbs:7.1f} GB/s ({gbs/80:.1f}%)  kernel {kbest:8.3f} ms {kg:7.1f} GB/s ({kg/80:.1f}%)", flush=True)
+    return r
+
+if which in ("all", "gb"):
+    id1, id2, id3, id6, v1, v2, v3 = (col(c) for c in (ck.GEN_ID1, ck.GEN_ID2, ck.GEN_ID3, ck.GEN_ID6, ck.GEN_V1, ck.GEN_V2, ck.GEN_V3))
+    h = {}
+    def agg(key, keys, ops, vals, hint):
+        def f():
+            h[key] = d.groupby_agg(keys, ops, vals, hint=hint, handle=h.get(key))
+            return h[key]
+        return f
+    timeit("Q1 sum(v1) by id1", 8, agg("q1", [id1], [ck.RED_SUM], [v1], 128))
+    timeit("Q2 sum(v1) by id1,id2", 12, agg("q2", [id1, id2], [ck.RED_SUM], [v1], 16384))
+    timeit("Q4 avg(v1,v2,v3) by id1", 16, agg("q4", [id1], [ck.RED_AVG] * 3, [v1, v2, v3], 128))
+    g = timeit("Q3 sum(v1),avg(v3) by id3", 12, agg("q3", [id3], [ck.RED_SUM, ck.RED_AVG], [v1, v3], n // K + 1024), reps=2)
+    print("   Q3 groups", g.ngroups)
+    g = timeit("Q5 sum(v1,v2,v3) by id6", 16, agg("q5", [id6], [ck.RED_SUM] * 3, [v1, v2, v3], n // K + 1024), reps=2)
+    print("   Q5 groups", g.ngroups)
+    timeit("Q7 max(v1),min(v2) by id3", 12, agg("q7", [id3], [ck.RED_MAX, ck.RED_MIN], [v1, v2], n // K + 1024), reps=2)
+    for k in list(h): h[k].destroy()
+if which in ("all", "build"):
+    id1 = col(ck.GEN_ID1)
+    hb = {}
+    def build():
+        if "b" in hb: hb["b"].destroy()
+        hb["b"] = d.groupby_build([id1], hint=128); return hb["b"]
+    g = timeit("build reversemap by id1", 12, build, reps=3)
+    off = d.empty(g.ngroups + 1, np.uint32); rows = d.empty(n, np.uint32)
+    import ctypes as C
+    def pp():
+        d._chk(d.lib.aqg_groupby_postproc(g.h, C.c_void_p(off.ptr), C.c_void_p(rows.ptr)), "pp")
+    timeit("ht_postproc (1 radix pass)", 12, pp, reps=3)
+    v1 = col(ck.GEN_V1)
+    timeit("grouped_reduce sum(v1[vecs])", 8, lambda: d.grouped_reduce(g, ck.RED_SUM, v1), reps=3)
+    g.destroy()
+if which in ("all", "scan"):
+    price, v1 = col(ck.GEN_PRICE), col(ck.GEN_V1)
+    outs = {}
+    def sc(op, x, w, key):
+        def f():
+            if key in outs: outs[key].free()
+            outs[key] = d.scan(op, x, w, keep=True)
+        return f
+    for name, bpr, w in (("mins", 8, 0), ("maxs", 8, 0), ("sums", 20, 0), ("avgs", 12, 0), ("deltas", 8, 0), ("prev", 8, 0),
+                         ("ratiow", 8, 1), ("avgw", 12, 5), ("avgw", 12, 100), ("sumw", 20, 5), ("minw", 8, 3), ("minw", 8, 10), ("minw", 8, 100), ("maxw", 8, 1000)):
+        timeit(f"{name}({w}) price", bpr, sc(ck.SCAN_NAMES[name], price, w, "o"), reps=3)
+    for k in list(outs): outs[k].free()
+if which in ("all", "ew"):
+    price, v1, v3 = col(ck.GEN_PRICE), col(ck.GEN_V1), col(ck.GEN_V3)
+    outs = {}
+    def ew(op, l, r, key="o", ot=None):
+        def f():
+            if key in outs: outs[key].free()
+            outs[key] = d.ewise(op, l, r, ot=ot, keep=True)
+        return f
+    timeit("price + v1 (int32)", 12, ew(ck.OP_ADD, price, v1), kernel=False)
+    timeit("price * v1 (->int128)", 24, ew(ck.OP_MUL, price, v1), kernel=False)
+    timeit("price > 275 (->bool)", 5, ew(ck.OP_GT, price, np.int32(275)), kernel=False)
+    timeit("v3 * 2.0f (->double)", 12, ew(ck.OP_MUL, v3, np.float32(2.0)), kernel=False)
+    timeit("sum(price)", 4, lambda: d.reduce(ck.RED_SUM, price), kernel=False)
+    timeit("max(price)", 4, lambda: d.reduce(ck.RED_MAX, price), kernel=False)
+    timeit("sum(v3) float", 4, lambda: d.reduce(ck.RED_SUM, v3), kernel=False)
+    for k in list(outs): outs[k].free()
