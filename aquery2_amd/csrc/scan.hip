@@ -111,6 +111,19 @@ template <class T> __device__ inline void load_tile_items(const T* __restrict__ 
     }
 }
 
+// Blocked results (IT consecutive elements per lane) are written through LDS so that consecutive lanes store consecutive
+// elements: a lane-blocked store of 16-byte results touches 64 different 128-B lines per instruction (sums: 2.4 TB/s),
+// the transposed one writes whole lines.
+template <class O> __device__ inline void store_tile_striped(O* __restrict__ out, uint32_t tile_base, const O (&v)[IT], uint32_t n, O* lds /* TS elements */) {
+    const uint32_t t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < IT; ++j) lds[t * IT + j] = v[j];
+    __syncthreads();
+    const uint32_t live = tile_base + TS <= n ? TS : n - tile_base;
+#pragma unroll
+    for (int j = 0; j < IT; ++j) { uint32_t e = j * SB + t; if (e < live) out[tile_base + e] = lds[e]; }
+}
+
 // K1: aggregate of each tile
 template <class T, class ALG> __global__ void __launch_bounds__(SB) tile_reduce_kernel(const T* __restrict__ x, uint32_t n, typename ALG::A* __restrict__ tile_agg) {
     using A = typename ALG::A;
@@ -165,36 +178,35 @@ __global__ void __launch_bounds__(SB) tile_scan_kernel(const T* __restrict__ x, 
     for (int j = 0; j < IT; ++j) if ((uint32_t)j < cnt) a = ALG::op(a, ALG::lift(v[j]));
     A total;
     A run = ALG::op(tile_prefix[blockIdx.x], block_scan_excl<ALG>(a, lds_w, total));
+    extern __shared__ __align__(16) unsigned char stage_raw[];
+    const uint32_t tile_base = blockIdx.x * TS;
     if constexpr (WR == W_SUMS) {
         using O = std::conditional_t<std::is_floating_point_v<T>, double, aqg_i128>;
-        pack<O, IT> o;
+        O o[IT];
 #pragma unroll
         for (int j = 0; j < IT; ++j) {
             if ((uint32_t)j < cnt) run = ALG::op(run, ALG::lift(v[j]));
-            if constexpr (std::is_floating_point_v<T>) o.v[j] = run; else o.v[j] = sum_alg<T>::to_i128(run);
+            if constexpr (std::is_floating_point_v<T>) o[j] = run; else o[j] = sum_alg<T>::to_i128(run);
         }
-        if (cnt == IT) *reinterpret_cast<pack<O, IT>*>(static_cast<O*>(out) + base) = o;
-        else for (uint32_t j = 0; j < cnt; ++j) static_cast<O*>(out)[base + j] = o.v[j];
+        store_tile_striped(static_cast<O*>(out), tile_base, o, n, reinterpret_cast<O*>(stage_raw));
     } else if constexpr (WR == W_AVGS) {
-        pack<double, IT> o;
+        double o[IT];
 #pragma unroll
         for (int j = 0; j < IT; ++j) {
             if ((uint32_t)j < cnt) run = ALG::op(run, ALG::lift(v[j]));
-            o.v[j] = sum_alg<T>::to_double(run) / (double)(base + j + 1);            // (s += arr[i]) / (double)(i + 1)
+            o[j] = sum_alg<T>::to_double(run) / (double)(base + j + 1);            // (s += arr[i]) / (double)(i + 1)
         }
-        if (cnt == IT) *reinterpret_cast<pack<double, IT>*>(static_cast<double*>(out) + base) = o;
-        else for (uint32_t j = 0; j < cnt; ++j) static_cast<double*>(out)[base + j] = o.v[j];
+        store_tile_striped(static_cast<double*>(out), tile_base, o, n, reinterpret_cast<double*>(stage_raw));
     } else {
-        pack<T, IT> o;
+        T o[IT];
 #pragma unroll
         for (int j = 0; j < IT; ++j) {
             if ((uint32_t)j < cnt) run = ALG::op(run, ALG::lift(v[j]));
             T r = run;
             if constexpr (WR == W_MAXS) { T seed = dlimits<T>::min(); r = seed > r ? seed : r; }  // maxs seeds with numeric_limits<T>::min()
-            o.v[j] = r;
+            o[j] = r;
         }
-        if (cnt == IT) *reinterpret_cast<pack<T, IT>*>(static_cast<T*>(out) + base) = o;
-        else for (uint32_t j = 0; j < cnt; ++j) static_cast<T*>(out)[base + j] = o.v[j];
+        store_tile_striped(static_cast<T*>(out), tile_base, o, n, reinterpret_cast<T*>(stage_raw));
     }
 }
 
@@ -202,11 +214,38 @@ __global__ void __launch_bounds__(SB) tile_scan_kernel(const T* __restrict__ x, 
 template <class T, int OP>
 __global__ void __launch_bounds__(SB) shift_kernel(const T* __restrict__ x, uint32_t n, uint32_t w, void* __restrict__ out) {
     using FP = std::conditional_t<sizeof(T) == 4, float, double>;           // GetFPType
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        if constexpr (OP == AQG_SCAN_DELTAS) static_cast<T*>(out)[i] = i ? (T)(x[i] - x[i - 1]) : (T)0;
-        else if constexpr (OP == AQG_SCAN_PREV) static_cast<T*>(out)[i] = i ? x[i - 1] : x[0];
-        else if constexpr (OP == AQG_SCAN_NEXT) static_cast<T*>(out)[i] = i + 1 < n ? x[i + 1] : x[n - 1];
-        else static_cast<FP*>(out)[i] = (FP)(x[i] / (FP)(i < w ? x[0] : x[i - w]));   // ratiow: arr[i] / (FPType)arr[i-w]
+    using O = std::conditional_t<OP == AQG_SCAN_RATIOW, FP, T>;
+    constexpr int V = 16 / sizeof(T) < 16 / sizeof(O) ? 16 / sizeof(T) : 16 / sizeof(O);   // elements per lane per step
+    auto one = [&](uint32_t i, T cur, T prv, T nxt) -> O {
+        if constexpr (OP == AQG_SCAN_DELTAS) return i ? (T)(cur - prv) : (T)0;
+        else if constexpr (OP == AQG_SCAN_PREV) return i ? prv : cur;
+        else if constexpr (OP == AQG_SCAN_NEXT) return i + 1 < n ? nxt : cur;
+        else return (FP)(cur / (FP)prv);                                    // ratiow: arr[i] / (FPType)arr[i-w] (prv = arr[0] for i < w)
+    };
+    const uint32_t nv = n / V;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nv && aligned; c += gridDim.x * blockDim.x) {
+        const uint32_t base = c * V;
+        pack<T, V> cur = *reinterpret_cast<const pack<T, V>*>(x + base);
+        pack<O, V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const uint32_t i = base + j;
+            T prv, nxt = cur.v[j];
+            if constexpr (OP == AQG_SCAN_RATIOW) prv = i < w ? x[0] : x[i - w];
+            else prv = j ? cur.v[j - 1] : (i ? x[i - 1] : cur.v[0]);
+            if constexpr (OP == AQG_SCAN_NEXT) nxt = j + 1 < V ? cur.v[j + 1] : (i + 1 < n ? x[i + 1] : cur.v[j]);
+            o.v[j] = one(i, cur.v[j], prv, nxt);
+        }
+        *reinterpret_cast<pack<O, V>*>(static_cast<O*>(out) + base) = o;
+    }
+    // tail (and the whole column when the buffers are not 16-byte aligned)
+    const uint32_t start = aligned ? nv * V : 0;
+    for (uint32_t i = start + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        T cur = x[i];
+        T prv = OP == AQG_SCAN_RATIOW ? (i < w ? x[0] : x[i - w]) : (i ? x[i - 1] : cur);
+        T nxt = i + 1 < n ? x[i + 1] : cur;
+        static_cast<O*>(out)[i] = one(i, cur, prv, nxt);
     }
 }
 
@@ -235,11 +274,17 @@ __global__ void __launch_bounds__(SB) window_sum_kernel(const T* __restrict__ x,
     A* Q = S + (MODE >= 2 ? ext_len : 0);                        // inclusive prefix of x*x (variance modes)
     const uint32_t per = (ext_len + SB - 1) / SB;                // consecutive elements per lane
     const uint32_t b = threadIdx.x * per, e = b + per < ext_len ? b + per : ext_len;
+    // coalesced load of the extended tile into LDS, then every lane scans its own run of `per` elements in place
+    for (uint32_t k = threadIdx.x; k < ext_len; k += SB) {
+        T v = x[ext_start + k];
+        S[k] = ALG::lift(v);
+        if constexpr (MODE >= 2) Q[k] = (double)v * (double)v;
+    }
+    __syncthreads();
     A a = ALG::identity(), q = ALG::identity();
     for (uint32_t k = b; k < e; ++k) {
-        T v = x[ext_start + k];
-        a = ALG::op(a, ALG::lift(v)); S[k] = a;
-        if constexpr (MODE >= 2) { q = q + (double)v * (double)v; Q[k] = q; }
+        a = ALG::op(a, S[k]); S[k] = a;
+        if constexpr (MODE >= 2) { q = q + Q[k]; Q[k] = q; }
     }
     A tot, tot2;
     A excl = block_scan_excl<ALG>(a, lds_w, tot);
@@ -397,8 +442,9 @@ int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out) {
     AQG_TRY(aqg_ws_get(ctx, ntiles, &agg));
     hipLaunchKernelGGL((tile_reduce_kernel<T, ALG>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, agg);
     hipLaunchKernelGGL((agg_scan_kernel<ALG>), dim3(1), dim3(SB), 0, ctx->stream, agg, ntiles);
+    constexpr size_t osz = WR == W_SUMS ? (std::is_floating_point_v<T> ? 8 : 16) : WR == W_AVGS ? 8 : sizeof(T);
     aqg_kernel_timer_begin(ctx);
-    hipLaunchKernelGGL((tile_scan_kernel<T, ALG, WR>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, agg, out);
+    hipLaunchKernelGGL((tile_scan_kernel<T, ALG, WR>), dim3(ntiles), dim3(SB), (size_t)TS * osz, ctx->stream, x, n, agg, out);
     aqg_kernel_timer_end(ctx);
     return aqg_check_launch(ctx, "prefix scan");
 }
