@@ -222,6 +222,169 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
     }
 }
 
+// ---- fast path: one 4-byte key column, 4-byte value columns, SUM/AVG/COUNT (h2o Q1, Q4) -------------------------------------
+// Same LDS open-addressing idea as agg_kernel, pared down to what this shape needs: the slot is the 4-byte key alone, eight
+// rows per lane per step with all probes issued before the first compare, and NO first-row bookkeeping in the loop -- first
+// rows are recovered afterwards by first_rows_kernel, which stops as soon as every group has one (a few tiles on h2o data).
+// vkind: 0 int32, 1 uint32, 2 float (accumulated in double).
+struct FastVals { const void* col[3]; int vkind[3]; };
+constexpr uint32_t OCCUPIED = 0xFFFFFFFEu;   // first_row mark: "group exists, first row not yet known"
+
+template <int NV, bool COUNT>
+__global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__ keys, FastVals fv, GTable gt, uint32_t n, uint32_t lcap) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const uint32_t LT = lcap + 1;
+    uint64_t* lacc = reinterpret_cast<uint64_t*>(smem_raw);                  // [NV][LT]
+    uint32_t* lkey = reinterpret_cast<uint32_t*>(lacc + (size_t)NV * LT);    // [LT], slot lcap = the key equal to EMPTY32
+    uint32_t* lcount = lkey + LT;                                            // [LT] if COUNT
+    uint32_t* ltouch = lcount + (COUNT ? LT : 0);                            // [1]  sentinel slot used?
+    __shared__ uint32_t lused;
+    const uint32_t lmask = lcap - 1, llimit = lcap - (lcap >> 2);
+    for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) {
+        lkey[s] = EMPTY32;
+        _Pragma("unroll") for (int a = 0; a < NV; ++a) lacc[(size_t)a * LT + s] = 0;
+        if constexpr (COUNT) lcount[s] = 0;
+    }
+    if (threadIdx.x == 0) { lused = 0; *ltouch = 0; }
+    __syncthreads();
+
+    auto slow_slot = [&](uint32_t k) -> uint32_t {      // insert path (first sight of a key in this workgroup)
+        if (k == EMPTY32) { *ltouch = 1; return lcap; }
+        uint32_t s = hash32(k) & lmask;
+        for (uint32_t p = 0; p <= lmask; ++p) {
+            uint32_t cur = lkey[s];
+            if (cur == k) return s;
+            if (cur == EMPTY32) {
+                if (lused >= llimit) return FAIL;
+                uint32_t old = atomicCAS(&lkey[s], EMPTY32, k);
+                if (old == EMPTY32) { atomicAdd(&lused, 1u); return s; }
+                if (old == k) return s;
+            }
+            s = (s + 1) & lmask;
+        }
+        return FAIL;
+    };
+    auto operand = [&](int a, uint32_t bits) -> uint64_t {
+        switch (fv.vkind[a]) {
+        case 0: return (uint64_t)(int64_t)(int32_t)bits;
+        case 1: return (uint64_t)bits;
+        default: return __builtin_bit_cast(uint64_t, (double)__uint_as_float(bits));
+        }
+    };
+    auto to_table = [&](uint32_t k, const uint32_t* vbits) {   // rare: LDS table at its load limit, or tail rows
+        uint32_t g = gt_find_or_insert(gt, (uint64_t)k);
+        if (g == FAIL) return;
+        atomicMin(gt.first_p(g), OCCUPIED);
+        if constexpr (COUNT) atomicAdd(gt.count_p(g), 1u);
+        _Pragma("unroll") for (int a = 0; a < NV; ++a) acc_apply(gt.acc_p(a, g), fv.vkind[a] == 2 ? ACC_ADD_F : ACC_ADD_I, operand(a, vbits[a]));
+    };
+
+    const uint32_t nchunk = n >> 3;            // 8 consecutive rows per lane per step
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+        const size_t base = (size_t)c * 8;
+        pack<uint32_t, 4> k0 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base);
+        pack<uint32_t, 4> k1 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base + 4);
+        pack<uint32_t, 4> v0[NV ? NV : 1], v1[NV ? NV : 1];
+        _Pragma("unroll") for (int a = 0; a < NV; ++a) {
+            v0[a] = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(fv.col[a]) + base);
+            v1[a] = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(fv.col[a]) + base + 4);
+        }
+        uint32_t k[8], slot[8], cur[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { k[j] = k0.v[j]; k[4 + j] = k1.v[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { slot[j] = hash32(k[j]) & lmask; cur[j] = lkey[slot[j]]; }     // eight probes in flight
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (cur[j] != k[j] || k[j] == EMPTY32) slot[j] = slow_slot(k[j]);
+        if constexpr (COUNT) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(&lcount[slot[j]], 1u);
+        }
+        _Pragma("unroll") for (int a = 0; a < NV; ++a) {
+            uint64_t* la = lacc + (size_t)a * LT;
+            if (fv.vkind[a] == 2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<double*>(&la[slot[j]]), (double)__uint_as_float(j < 4 ? v0[a].v[j] : v1[a].v[j - 4]));
+            } else if (fv.vkind[a] == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)(int64_t)(int32_t)(j < 4 ? v0[a].v[j] : v1[a].v[j - 4]));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)(j < 4 ? v0[a].v[j] : v1[a].v[j - 4]));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (slot[j] == FAIL) {
+                uint32_t vb[NV ? NV : 1];
+                _Pragma("unroll") for (int a = 0; a < NV; ++a) vb[a] = j < 4 ? v0[a].v[j] : v1[a].v[j - 4];
+                to_table(k[j], vb);
+            }
+        }
+    }
+    if (blockIdx.x == 0) {                     // tail rows (< 8)
+        uint32_t row = (nchunk << 3) + threadIdx.x;
+        if (row < n) {
+            uint32_t vb[NV ? NV : 1];
+            _Pragma("unroll") for (int a = 0; a < NV; ++a) vb[a] = static_cast<const uint32_t*>(fv.col[a])[row];
+            to_table(keys[row], vb);
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) {
+        const uint32_t key = lkey[s];
+        if (s < lcap ? key == EMPTY32 : *ltouch == 0) continue;
+        uint32_t g = gt_find_or_insert(gt, (uint64_t)(s < lcap ? key : EMPTY32));
+        if (g == FAIL) continue;
+        atomicMin(gt.first_p(g), OCCUPIED);
+        if constexpr (COUNT) atomicAdd(gt.count_p(g), lcount[s]);
+        _Pragma("unroll") for (int a = 0; a < NV; ++a) acc_apply(gt.acc_p(a, g), fv.vkind[a] == 2 ? ACC_ADD_F : ACC_ADD_I, lacc[(size_t)a * LT + s]);
+    }
+}
+
+// first row of every group, after the fact: tiles are scanned in order by a small grid; once every group has a candidate,
+// a workgroup stops as soon as its next tile starts beyond the largest candidate (no later row can lower any of them).
+__global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restrict__ keys, uint32_t n, GTable gt, const uint32_t* __restrict__ occ) {
+    __shared__ uint32_t red[4];
+    __shared__ uint32_t stop;
+    const uint32_t G = gt.flags[1];
+    constexpr uint32_t TILE = 256 * 16;
+    for (uint32_t t = blockIdx.x; (uint64_t)t * TILE < n; t += gridDim.x) {
+        const uint32_t tbase = t * TILE;
+        if (threadIdx.x == 0) stop = 0;
+        __syncthreads();
+        if (__hip_atomic_load(&gt.flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G) {
+            uint32_t m = 0;
+            for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) {
+                uint32_t f = __hip_atomic_load(gt.first_p(occ[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                m = f > m ? f : m;
+            }
+            m = wave_reduce(m, OpMax{});
+            if (lane_id() == 0) red[wave_id()] = m;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t bound = red[0] > red[1] ? red[0] : red[1];
+                bound = bound > red[2] ? bound : red[2];
+                bound = bound > red[3] ? bound : red[3];
+                stop = tbase > bound;
+            }
+            __syncthreads();
+        }
+        if (stop) break;
+        for (int r = 0; r < 16; ++r) {
+            uint32_t row = tbase + r * 256 + threadIdx.x;
+            if (row < n) {
+                uint32_t s = gt_find(gt, (uint64_t)keys[row]);
+                if (s != FAIL && row < *gt.first_p(s)) {
+                    uint32_t old = atomicMin(gt.first_p(s), row);
+                    if (old >= OCCUPIED) atomicAdd(&gt.flags[2], 1u);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void __launch_bounds__(256) occ_iota_kernel(uint32_t* __restrict__ occ, uint32_t n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) occ[i] = i;
 }
@@ -622,8 +785,40 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     AQG_HIP(ctx, hipMemsetAsync(gt.flags, 0, 64 * 4, ctx->stream));
     if (bitmap) AQG_HIP(ctx, hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, ctx->stream));
 
+    // fast path eligibility: LDS mode, one 4-byte integer key, 1..3 four-byte value columns, plain additive accumulators
+    bool fast = use_lds && k32 && n >= 8 && as.nacc >= (plan.need_count ? 0 : 1) && as.nacc <= 3 && !for_build &&
+                (ks.dt[0] == AQG_INT32 || ks.dt[0] == AQG_UINT32) && ((uintptr_t)ks.col[0] & 15) == 0;
+    FastVals fv;
+    memset(&fv, 0, sizeof fv);
+    for (int a = 0; a < as.nacc && fast; ++a) {
+        const bool addk = as.kind[a] == ACC_ADD_I || as.kind[a] == ACC_ADD_F;
+        const int dt = as.dt[a];
+        if (!addk || as.square[a] || as.part[a] || !(dt == AQG_INT32 || dt == AQG_UINT32 || dt == AQG_FLOAT) || ((uintptr_t)as.col[a] & 15)) fast = false;
+        fv.col[a] = as.col[a];
+        fv.vkind[a] = dt == AQG_INT32 ? 0 : dt == AQG_UINT32 ? 1 : 2;
+    }
     // ---- pass over the rows ---------------------------------------------------------------------
-    if (n && use_part) {
+    if (n && fast) {
+        const size_t lds = (size_t)(lcap + 1) * (4 + 8 * (size_t)as.nacc + (plan.need_count ? 4 : 0)) + 64;
+        unsigned bpc = lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : 2;
+        unsigned grid = aqg_grid(ctx, n / 8 + 1, 256, 2, bpc);
+        auto launch = [&](auto kern) -> int {
+            AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            aqg_kernel_timer_begin(ctx);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, static_cast<const uint32_t*>(ks.col[0]), fv, gt, n, lcap);
+            aqg_kernel_timer_end(ctx);
+            return aqg_check_launch(ctx, "agg32_kernel");
+        };
+        int rc;
+        if (plan.need_count) {
+            switch (as.nacc) { case 0: rc = launch(&agg32_kernel<0, true>); break; case 1: rc = launch(&agg32_kernel<1, true>); break;
+                               case 2: rc = launch(&agg32_kernel<2, true>); break; default: rc = launch(&agg32_kernel<3, true>); break; }
+        } else {
+            switch (as.nacc) { case 1: rc = launch(&agg32_kernel<1, false>); break; case 2: rc = launch(&agg32_kernel<2, false>); break;
+                               default: rc = launch(&agg32_kernel<3, false>); break; }
+        }
+        AQG_TRY(rc);
+    } else if (n && use_part) {
         AQG_TRY(aqg_partition_aggregate(ctx, ks, as, n, pbits, part_lcap, plan.need_count, gt, gcap));
         hipLaunchKernelGGL(occ_iota_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, occ, (uint32_t)slots);
     } else if (n) {
@@ -671,6 +866,11 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     uint32_t G = fl[1];
     if (small_rank && G > 4096) return AQG_ERR_OVERFLOW;
     if (use_lds && G > 3072 && G > hint) return AQG_ERR_OVERFLOW;   // correct but slow: re-plan in HBM mode
+    if (G && n && fast) {
+        unsigned fgrid = aqg_grid(ctx, n / 16 + 1, 256, 1, 1);
+        hipLaunchKernelGGL(first_rows_kernel, dim3(fgrid), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(ks.col[0]), n, gt, (const uint32_t*)occ);
+        AQG_TRY(aqg_check_launch(ctx, "first_rows_kernel"));
+    }
     if (G) {
         if (small_rank) {
             hipLaunchKernelGGL(rank_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, gt, occ, gid_of_occ, slot_gid);

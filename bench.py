@@ -150,9 +150,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # PMC-measured HBM bytes per launch at 1e9 rows (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
-                         # profiles/r1_bench_q1_1e9_pmc.md): 8.0007 GB read + 0.0121 GB written; scaled to this run's rows
-                         "traffic": 8.0128e9 * n / 1e9,
-                         "kernel": "agg_kernel<LDS,K32,1>", "kernel_ms": k_ms, "algorithmic_bytes": Q1_BYTES_PER_ROW * n},
+                         # profiles/r1_bench_q1_1e9_pmc.md): 8.0255 GB read + 0.0121 GB written; scaled to this run's rows
+                         "traffic": 8.0376e9 * n / 1e9,
+                         "kernel": "agg32_kernel<1,false>", "kernel_ms": k_ms, "algorithmic_bytes": Q1_BYTES_PER_ROW * n},
         }
         if world == 1 and args.cpu_sample > 0:
             line["cpu_baseline"] = cpu_baseline(int(args.cpu_sample))
