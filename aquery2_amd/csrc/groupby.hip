@@ -734,7 +734,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     // (partition.hip); the build path keeps the HBM table because its second pass looks keys up in it
     // Measured on MI355X, 1e9 rows (round 1): the partition pipeline is not yet faster than the HBM table (h2o Q5 157 ms vs
     // 142 ms; its scatter passes run at ~1 TB/s), so it stays off until the scatter reaches streaming rates.
-    const bool use_part = false && !use_lds && !ks.wide && !for_build && n >= (1u << 16) && hint <= (1u << 25);
+    static const bool part_on = getenv("AQG_EXPERIMENTAL_PARTITION") != nullptr;   // development switch, see above
+    const bool use_part = part_on && !use_lds && !ks.wide && !for_build && n >= (1u << 16) && hint <= (1u << 25);
     uint32_t part_lcap = 0, pbits = 0;
     if (use_part) {
         const size_t sb = 16 + 8 * (size_t)as.nacc;
