@@ -5,4 +5,5 @@ HIP kernels under aquery2_amd/csrc/, plus the host C++ headers under include/aqu
 the reference's header-level API.  This Python package is a thin ctypes harness over the C-ABI
 used by tests/ and bench.py; it contains no compute of its own and no CPU fallback.
 """
+from . import capi  # noqa: F401
 from .capi import Device, DevBuf, AqgError, lib_path, load_library  # noqa: F401

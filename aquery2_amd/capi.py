@@ -209,7 +209,7 @@ class Device:
         return out
 
     # -- element-wise
-    def ewise(self, op, l, r, ot=None, keep=False):
+    def ewise(self, op, l, r, ot=None, keep=False, out=None):
         l_vec = isinstance(l, DevBuf) or np.ndim(l) > 0
         r_vec = isinstance(r, DevBuf) or np.ndim(r) > 0
         kind = VEC_VEC if (l_vec and r_vec) else (VEC_SCALAR if l_vec else SCALAR_VEC)
@@ -224,7 +224,7 @@ class Device:
             ot = self.lib.aqg_ewise_out_dtype(op, lt, rt)
         if ot == ERROR:
             raise AqgError("aqg_ewise_out_dtype", ERROR)
-        out = self.empty(n, TAG2NP[ot])
+        out = out if out is not None else self.empty(n, TAG2NP[ot])
         lp = C.c_void_p(ld.ptr) if l_vec else ls.ctypes.data_as(C.c_void_p)
         rp = C.c_void_p(rd.ptr) if r_vec else rs.ctypes.data_as(C.c_void_p)
         self._chk(self.lib.aqg_ewise(self.ctx, op, kind, lt, lp, rt, rp, ot, C.c_void_p(out.ptr), C.c_uint32(n)), "aqg_ewise")
@@ -258,10 +258,10 @@ class Device:
         return out.value
 
     # -- scans
-    def scan(self, op, x, w=0, keep=False):
+    def scan(self, op, x, w=0, keep=False, out=None):
         xd = self._dev(x)
         ot = self.lib.aqg_scan_out_dtype(op, xd.tag)
-        out = self.empty(xd.n, TAG2NP[ot])
+        out = out if out is not None else self.empty(xd.n, TAG2NP[ot])
         self._chk(self.lib.aqg_scan(self.ctx, op, xd.tag, C.c_void_p(xd.ptr), C.c_uint32(xd.n), C.c_uint32(w),
                                     C.c_void_p(out.ptr)), "aqg_scan")
         return out if keep else out.to_host()

@@ -12,25 +12,27 @@
 
 namespace {
 
-constexpr int E = 8; // elements per lane per step
+// elements per lane per vector: chosen so that a lane STORES exactly 16 bytes (int128 results: 1 element, bool: 16);
+// each lane handles UNR such vectors per step, every one a separate fully coalesced access
+template <class OT> constexpr int elems_for() { return (int)(16 / sizeof(OT)); }
 
-template <class C, class T> __device__ inline void load_chunk_t(const void* p, size_t base, C (&o)[E]) {
+template <class C, class T, int E> __device__ inline void load_chunk_t(const void* p, size_t base, C (&o)[E]) {
     pack<T, E> v = *reinterpret_cast<const pack<T, E>*>(static_cast<const T*>(p) + base);
 #pragma unroll
     for (int j = 0; j < E; ++j) o[j] = (C)v.v[j];
 }
-template <class C> __device__ inline void load_chunk(const void* p, int dt, size_t base, C (&o)[E]) {
+template <class C, int E> __device__ inline void load_chunk(const void* p, int dt, size_t base, C (&o)[E]) {
     switch (dt) {
-    case AQG_INT8: load_chunk_t<C, int8_t>(p, base, o); break;
-    case AQG_INT16: load_chunk_t<C, int16_t>(p, base, o); break;
-    case AQG_INT32: load_chunk_t<C, int32_t>(p, base, o); break;
-    case AQG_INT64: load_chunk_t<C, int64_t>(p, base, o); break;
-    case AQG_BOOL: case AQG_UINT8: load_chunk_t<C, uint8_t>(p, base, o); break;
-    case AQG_UINT16: load_chunk_t<C, uint16_t>(p, base, o); break;
-    case AQG_UINT32: load_chunk_t<C, uint32_t>(p, base, o); break;
-    case AQG_UINT64: load_chunk_t<C, uint64_t>(p, base, o); break;
-    case AQG_FLOAT: load_chunk_t<C, float>(p, base, o); break;
-    default: load_chunk_t<C, double>(p, base, o); break;
+    case AQG_INT8: load_chunk_t<C, int8_t, E>(p, base, o); break;
+    case AQG_INT16: load_chunk_t<C, int16_t, E>(p, base, o); break;
+    case AQG_INT32: load_chunk_t<C, int32_t, E>(p, base, o); break;
+    case AQG_INT64: load_chunk_t<C, int64_t, E>(p, base, o); break;
+    case AQG_BOOL: case AQG_UINT8: load_chunk_t<C, uint8_t, E>(p, base, o); break;
+    case AQG_UINT16: load_chunk_t<C, uint16_t, E>(p, base, o); break;
+    case AQG_UINT32: load_chunk_t<C, uint32_t, E>(p, base, o); break;
+    case AQG_UINT64: load_chunk_t<C, uint64_t, E>(p, base, o); break;
+    case AQG_FLOAT: load_chunk_t<C, float, E>(p, base, o); break;
+    default: load_chunk_t<C, double, E>(p, base, o); break;
     }
 }
 template <class C> __device__ inline C load_one(const void* p, int dt, size_t i) {
@@ -98,25 +100,41 @@ template <int OP, class C, class OT> __device__ inline OT apply(C a, C b) {
 
 template <int OP, class C, class OT>
 __device__ inline void ewise_body(int kind, int lt, const void* l, int rt, const void* r, C sc, OT* out, uint32_t n) {
-    uint32_t nchunk = n / E;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
-        C a[E], b[E];
-        size_t base = (size_t)c * E;
-        if (kind == AQG_SCALAR_VEC) {
+    constexpr int E = elems_for<OT>();
+    constexpr int UNR = E >= 16 ? 1 : (16 / E > 8 ? 8 : 16 / E);   // ~16 elements in flight per lane
+    const uint32_t nvec = n / E;
+    const uint32_t stride = blockDim.x;                      // a workgroup covers UNR * 256 consecutive vectors per step (one 4-64 KB span)
+    for (uint64_t c = blockIdx.x; c * UNR * blockDim.x < nvec; c += gridDim.x) {
+        const uint32_t v0 = (uint32_t)(c * UNR * blockDim.x) + threadIdx.x;
+        C a[UNR][E], b[UNR][E];
 #pragma unroll
-            for (int j = 0; j < E; ++j) a[j] = sc;
-        } else load_chunk<C>(l, lt, base, a);
-        if (kind == AQG_VEC_SCALAR) {
+        for (int u = 0; u < UNR; ++u) {
+            const uint32_t vid = v0 + u * stride;
+            if (vid < nvec) {
+                const size_t base = (size_t)vid * E;
+                if (kind == AQG_SCALAR_VEC) {
 #pragma unroll
-            for (int j = 0; j < E; ++j) b[j] = sc;
-        } else load_chunk<C>(r, rt, base, b);
-        pack<OT, E> o;
+                    for (int j = 0; j < E; ++j) a[u][j] = sc;
+                } else load_chunk<C, E>(l, lt, base, a[u]);
+                if (kind == AQG_VEC_SCALAR) {
 #pragma unroll
-        for (int j = 0; j < E; ++j) o.v[j] = apply<OP, C, OT>(a[j], b[j]);
-        *reinterpret_cast<pack<OT, E>*>(out + base) = o;
+                    for (int j = 0; j < E; ++j) b[u][j] = sc;
+                } else load_chunk<C, E>(r, rt, base, b[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const uint32_t vid = v0 + u * stride;
+            if (vid < nvec) {
+                pack<OT, E> o;
+#pragma unroll
+                for (int j = 0; j < E; ++j) o.v[j] = apply<OP, C, OT>(a[u][j], b[u][j]);
+                *reinterpret_cast<pack<OT, E>*>(out + (size_t)vid * E) = o;
+            }
+        }
     }
     if (blockIdx.x == 0) {
-        uint32_t i = nchunk * E + threadIdx.x;
+        uint32_t i = nvec * E + threadIdx.x;
         if (i < n) {
             C a = kind == AQG_SCALAR_VEC ? sc : load_one<C>(l, lt, i);
             C b = kind == AQG_VEC_SCALAR ? sc : load_one<C>(r, rt, i);
@@ -185,7 +203,7 @@ int launch_ewise(aqg_ctx* ctx, int op, int kind, int lt, const void* l, int rt, 
         C sc = 0;
         if (kind == AQG_VEC_SCALAR) sc = host_scalar<C>(rt, r);
         if (kind == AQG_SCALAR_VEC) sc = host_scalar<C>(lt, l);
-        unsigned grid = aqg_grid(ctx, n / E + 1, 256, 1, 16);
+        unsigned grid = aqg_grid(ctx, n / 8 + 1, 256, 1, 16);
         hipLaunchKernelGGL((ewise_kernel<C, OT>), dim3(grid), dim3(256), 0, ctx->stream, op, kind, lt,
                            kind == AQG_SCALAR_VEC ? nullptr : l, rt, kind == AQG_VEC_SCALAR ? nullptr : r, sc,
                            static_cast<OT*>(out), n);
@@ -250,7 +268,7 @@ int aqg_ewise(aqg_ctx* ctx, int op, int kind, int lt, const void* l, int rt, con
     if ((c == AQG_FLOAT || c == AQG_DOUBLE) && (op == AQG_OP_MOD || op == AQG_OP_AND || op == AQG_OP_OR || op == AQG_OP_XOR))
         return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_ewise: bitwise/mod on floating operands");
     // chunk loads need E*sizeof(T)-aligned bases (capped at 16): device allocations always are
-    auto aligned = [](const void* p, int dt) { size_t a = E * aqg_dtype_size(dt); if (a > 16) a = 16; return ((uintptr_t)p & (a - 1)) == 0; };
+    auto aligned = [](const void* p, int) { return ((uintptr_t)p & 15) == 0; };
     if ((kind != AQG_SCALAR_VEC && !aligned(l, lt)) || (kind != AQG_VEC_SCALAR && !aligned(r, rt)) || !aligned(out, ot))
         return aqg_fail(ctx, AQG_ERR_ARG, "aqg_ewise: operands must be 16-byte aligned");
     switch (c) {
