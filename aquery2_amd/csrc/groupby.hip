@@ -587,20 +587,50 @@ __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __
 }
 
 // ---- second pass of aqg_groupby_build: reversemap + counts ---------------------------------------
-template <bool LDS_COUNTS>
-__global__ void __launch_bounds__(256) assign_kernel(KeySpec ks, GTable gt, const uint32_t* __restrict__ slot_gid, uint32_t n,
-                                                     uint32_t G, uint32_t* __restrict__ reversemap, uint32_t* __restrict__ counts) {
+// LDS_COUNTS: group counts in an LDS histogram.  LDS_MAP: additionally a private copy of the {key -> dense id} map in LDS
+// (small group counts: every lookup becomes an LDS probe instead of an L2 round trip).
+template <bool LDS_COUNTS, bool LDS_MAP>
+__global__ void __launch_bounds__(256) assign_kernel(KeySpec ks, GTable gt, const uint32_t* __restrict__ slot_gid, const uint32_t* __restrict__ occ, uint32_t n,
+                                                     uint32_t G, uint32_t mcap, uint32_t* __restrict__ reversemap, uint32_t* __restrict__ counts) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    uint32_t* lc = reinterpret_cast<uint32_t*>(smem_raw);
-    if constexpr (LDS_COUNTS) {
-        for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) lc[g] = 0;
+    uint32_t* lc = reinterpret_cast<uint32_t*>(smem_raw);                       // [G] counts
+    uint64_t* mkey = reinterpret_cast<uint64_t*>(smem_raw + (((size_t)G * 4 + 15) & ~(size_t)15));   // [mcap] keys
+    uint32_t* mgid = reinterpret_cast<uint32_t*>(mkey + mcap);                  // [mcap] dense ids
+    __shared__ uint32_t sentinel_gid;
+    if constexpr (LDS_COUNTS) for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) lc[g] = 0;
+    if constexpr (LDS_MAP) {
+        for (uint32_t s = threadIdx.x; s < mcap; s += blockDim.x) mkey[s] = EMPTY64;
+        if (threadIdx.x == 0) sentinel_gid = 0;
         __syncthreads();
+        for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) {
+            const uint32_t s0 = occ[i];
+            const uint32_t gid = slot_gid[s0];
+            if (s0 == gt.cap) { sentinel_gid = gid; continue; }
+            const uint64_t key = *gt.key_p(s0);
+            uint32_t s = hash64(key) & (mcap - 1);
+            while (true) {                                                       // keys are distinct: plain claim by CAS
+                unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&mkey[s]), EMPTY64, key);
+                if (old == EMPTY64) { mgid[s] = gid; break; }
+                s = (s + 1) & (mcap - 1);
+            }
+        }
     }
+    if constexpr (LDS_COUNTS || LDS_MAP) __syncthreads();
     const uint32_t nchunk = n >> 2;
     const bool vec_ok = ks.nkeys == 1 && ks.total_bytes == 4;
     auto one = [&](uint64_t key) -> uint32_t {
-        uint32_t s = ks.wide ? gt_find_wide(gt, ks, (uint32_t)key) : gt_find(gt, key);
-        uint32_t g = s == FAIL ? 0u : slot_gid[s];
+        uint32_t g = 0;
+        if constexpr (LDS_MAP) {
+            if (key == EMPTY64) g = sentinel_gid;
+            else {
+                uint32_t s = hash64(key) & (mcap - 1);
+                while (mkey[s] != key) s = (s + 1) & (mcap - 1);               // every key of the column is in the map
+                g = mgid[s];
+            }
+        } else {
+            uint32_t s = ks.wide ? gt_find_wide(gt, ks, (uint32_t)key) : gt_find(gt, key);
+            g = s == FAIL ? 0u : slot_gid[s];
+        }
         if constexpr (LDS_COUNTS) atomicAdd(&lc[g], 1u); else atomicAdd(&counts[g], 1u);
         return g;
     };
@@ -718,7 +748,7 @@ int make_plan(aqg_ctx* ctx, int naggs, const int* ops, const int* dts, const voi
 
 // One attempt at a given global capacity.  Returns AQG_ERR_OVERFLOW when the table filled up.
 int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
-            GTable* gt_out, uint32_t** slot_gid_out) {
+            GTable* gt_out, uint32_t** slot_gid_out, uint32_t** occ_out = nullptr) {
     const AccSpec& as = plan.as;
     const bool k32 = ks.nkeys == 1 && ks.total_bytes == 4;
     uint32_t gcap = next_pow2((uint64_t)(hint < 512 ? 512 : hint) * 2);
@@ -923,15 +953,16 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     }
     if (gt_out) *gt_out = gt;
     if (slot_gid_out) *slot_gid_out = slot_gid;
+    if (occ_out) *occ_out = occ;
     return AQG_OK;
 }
 
 int run_with_retry(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
-                   GTable* gt_out, uint32_t** slot_gid_out) {
+                   GTable* gt_out, uint32_t** slot_gid_out, uint32_t** occ_out = nullptr) {
     uint64_t cur = hint ? hint : (h->hint_used ? h->hint_used : 1024);
     for (int attempt = 0; attempt < 12; ++attempt) {
         if (cur > n && n) cur = n;
-        int rc = run_agg(ctx, ks, plan, n, (uint32_t)cur, for_build, h, gt_out, slot_gid_out);
+        int rc = run_agg(ctx, ks, plan, n, (uint32_t)cur, for_build, h, gt_out, slot_gid_out, occ_out);
         if (rc != AQG_ERR_OVERFLOW) { if (rc == AQG_OK) h->hint_used = (uint32_t)cur; return rc; }
         if (n && cur >= n) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "group-by: table overflow at full capacity");
         cur *= 16;
@@ -994,8 +1025,8 @@ int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void
     memset(&plan, 0, sizeof plan);
     aqg_groupby* h = *out ? *out : new aqg_groupby();
     h->ctx = ctx; h->n = n;
-    GTable gt; uint32_t* slot_gid = nullptr;
-    int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, true, h, &gt, &slot_gid);
+    GTable gt; uint32_t* slot_gid = nullptr; uint32_t* occ_dev = nullptr;
+    int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, true, h, &gt, &slot_gid, &occ_dev);
     if (rc == AQG_OK) {
         size_t c = h->reversemap ? h->cap_rows * 4 : 0;
         rc = dev_realloc(ctx, (void**)&h->reversemap, &c, ((size_t)n + 4) * 4);
@@ -1006,11 +1037,15 @@ int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void
     if (n) {
         hipMemsetAsync(h->counts, 0, (size_t)(G ? G : 1) * 4, ctx->stream);
         unsigned grid = aqg_grid(ctx, n / 4 + 1, 256, 2, 8);
-        if (G <= 8192) {
+        if (G <= 2048 && !ks.wide) {
+            const uint32_t mcap = next_pow2((uint64_t)G * 2 + 2);
+            size_t lds = (((size_t)G * 4 + 15) & ~(size_t)15) + (size_t)mcap * 12 + 16;
+            hipLaunchKernelGGL((assign_kernel<true, true>), dim3(grid), dim3(256), lds, ctx->stream, ks, gt, slot_gid, occ_dev, n, G, mcap, h->reversemap, h->counts);
+        } else if (G <= 8192) {
             size_t lds = (size_t)G * 4 + 16;
-            hipLaunchKernelGGL((assign_kernel<true>), dim3(grid), dim3(256), lds, ctx->stream, ks, gt, slot_gid, n, G, h->reversemap, h->counts);
+            hipLaunchKernelGGL((assign_kernel<true, false>), dim3(grid), dim3(256), lds, ctx->stream, ks, gt, slot_gid, occ_dev, n, G, 0u, h->reversemap, h->counts);
         } else {
-            hipLaunchKernelGGL((assign_kernel<false>), dim3(grid), dim3(256), 0, ctx->stream, ks, gt, slot_gid, n, G, h->reversemap, h->counts);
+            hipLaunchKernelGGL((assign_kernel<false, false>), dim3(grid), dim3(256), 0, ctx->stream, ks, gt, slot_gid, occ_dev, n, G, 0u, h->reversemap, h->counts);
         }
         rc = aqg_check_launch(ctx, "assign_kernel");
         if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }

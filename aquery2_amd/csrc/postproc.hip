@@ -99,47 +99,59 @@ __global__ void __launch_bounds__(RB) radix_hist_kernel(const uint32_t* __restri
     hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
 }
 
+constexpr int SUB = 4;   // rounds ranked between two barriers
+
 template <bool FIRST, bool LAST>
 __global__ void __launch_bounds__(RB) radix_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n, uint32_t shift,
                                                            uint32_t ntiles, const uint32_t* __restrict__ hist_scanned,
                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
-    __shared__ uint32_t gbase[256];      // where this tile's rows of each digit start in the output
-    __shared__ uint32_t run[256];        // rows of each digit already placed by earlier rounds
-    __shared__ uint32_t wcnt[4][256];    // rows of each digit in each wave, this round
+    __shared__ uint32_t gbase[256];           // where this tile's rows of each digit start in the output
+    __shared__ uint32_t run[256];             // rows of each digit already placed by earlier rounds
+    __shared__ uint32_t wcnt[SUB][4][256];    // rows of each digit in each wave of each round of the current batch
     gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * ntiles + blockIdx.x];
     run[threadIdx.x] = 0;
     const uint32_t tbase = blockIdx.x * RT;
     const int lane = lane_id(), wid = wave_id();
     const uint64_t lt_mask = (1ull << lane) - 1ull;
-    for (int r = 0; r < ROUNDS; ++r) {
+    for (int r0 = 0; r0 < ROUNDS; r0 += SUB) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) wcnt[w][threadIdx.x] = 0;
+        for (int q = 0; q < SUB * 4; ++q) (&wcnt[0][0][0])[q * 256 + threadIdx.x] = 0;
         __syncthreads();
-        const uint32_t p = tbase + r * RB + threadIdx.x;
-        const bool live = p < n;
-        uint32_t k = 0, v = 0;
-        if (live) load_pair<FIRST>(keys, vals, n, p, k, v);
-        const uint32_t d = (k >> shift) & 255;
-        // lanes of this wave holding the same digit
-        uint64_t peers = __ballot(live);
+        uint32_t k[SUB], v[SUB], d[SUB], rank[SUB];
+        bool live[SUB];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            uint64_t bal = __ballot((d >> b) & 1);
-            peers &= ((d >> b) & 1) ? bal : ~bal;
-        }
-        const uint32_t rank_in_wave = __popcll(peers & lt_mask);
-        if (live && rank_in_wave == 0) wcnt[wid][d] = __popcll(peers);
-        __syncthreads();
-        if (live) {
-            uint32_t off = run[d] + rank_in_wave;
-            for (int w = 0; w < wid; ++w) off += wcnt[w][d];
-            const uint32_t dst = gbase[d] + off;
-            if constexpr (!LAST) keys_out[dst] = k;
-            vals_out[dst] = v;
+        for (int sb = 0; sb < SUB; ++sb) {
+            const uint32_t p = tbase + (r0 + sb) * RB + threadIdx.x;
+            live[sb] = p < n;
+            k[sb] = 0; v[sb] = 0;
+            if (live[sb]) load_pair<FIRST>(keys, vals, n, p, k[sb], v[sb]);
+            d[sb] = (k[sb] >> shift) & 255;
+            uint64_t peers = __ballot(live[sb]);            // lanes of this wave holding the same digit in this round
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                uint64_t bal = __ballot((d[sb] >> bit) & 1);
+                peers &= ((d[sb] >> bit) & 1) ? bal : ~bal;
+            }
+            rank[sb] = __popcll(peers & lt_mask);
+            if (live[sb] && rank[sb] == 0) wcnt[sb][wid][d[sb]] = __popcll(peers);
         }
         __syncthreads();
-        run[threadIdx.x] += wcnt[0][threadIdx.x] + wcnt[1][threadIdx.x] + wcnt[2][threadIdx.x] + wcnt[3][threadIdx.x];
-        // the next round's zeroing of wcnt is ordered behind this read by the barrier after it
+#pragma unroll
+        for (int sb = 0; sb < SUB; ++sb) {
+            if (live[sb]) {
+                uint32_t off = run[d[sb]] + rank[sb];
+                for (int s2 = 0; s2 < sb; ++s2) off += wcnt[s2][0][d[sb]] + wcnt[s2][1][d[sb]] + wcnt[s2][2][d[sb]] + wcnt[s2][3][d[sb]];
+                for (int w2 = 0; w2 < wid; ++w2) off += wcnt[sb][w2][d[sb]];
+                const uint32_t dst = gbase[d[sb]] + off;
+                if constexpr (!LAST) keys_out[dst] = k[sb];
+                vals_out[dst] = v[sb];
+            }
+        }
+        __syncthreads();
+        uint32_t add = 0;
+#pragma unroll
+        for (int q = 0; q < SUB * 4; ++q) add += (&wcnt[0][0][0])[q * 256 + threadIdx.x];
+        run[threadIdx.x] += add;
         __syncthreads();
     }
 }
