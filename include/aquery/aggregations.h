@@ -20,9 +20,11 @@ template <template <typename...> class VT, class T> constexpr bool is_vt = std::
 
 template <class R, class T, template <typename...> class VT> inline R device_reduce(int op, const VT<T>& v) {
     auto& rt = dev::Runtime::get();
-    dev::In in(v.container, (size_t)v.size * sizeof(T), v.capacity == 0);
     alignas(16) unsigned char buf[16];
-    dev::check(aqg_reduce(rt.ctx(), op, dev::tag_of<T>::value, in.d, v.size, buf), "aqg_reduce");
+    if (!rt.deferred_reduce(v.container, op, buf)) {      // not a deferred `col[vecs[g]]`: reduce this very vector
+        dev::In in(v.container, (size_t)v.size * sizeof(T), v.capacity == 0);
+        dev::check(aqg_reduce(rt.ctx(), op, dev::tag_of<T>::value, in.d, v.size, buf), "aqg_reduce");
+    }
     R r;
     std::memcpy(&r, buf, sizeof(R));
     return r;

@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <utility>
+#include <vector>
 
 #include "../aqg.h"
 
@@ -29,11 +31,33 @@ namespace dev {
     std::abort();
 }
 
+// One device group-by (the table behind HashTableFactory::get / AQHashTable).  Its row-id buffer is registered like any
+// other RESULT; `vecs[g]` views into it let the runtime recognise `col[vecs[g]]` as "group g of this grouping".
+struct GroupCtx {
+    aqg_groupby* handle = nullptr;
+    uint32_t n = 0, G = 0;
+    uint32_t* offsets = nullptr;   // [G+1] host
+    uint32_t* counts = nullptr;    // [G]   host
+    uint32_t* row_ids = nullptr;   // [n]   host address (device copy registered)
+    // (source column, op) -> G result slots of 16 bytes, filled for ALL groups by one kernel on first request
+    std::map<std::pair<const void*, int>, std::vector<unsigned char>> cache;
+};
+
 struct Entry {
     void* dptr = nullptr;
     size_t bytes = 0;
     bool host_stale = false;   // RESULT not yet downloaded
     bool pinned = false;       // PINNED borrowed column
+    GroupCtx* gctx = nullptr;  // set on a grouping's row-id buffer
+    // DEFERRED gather `col[vecs[g]]`: nothing has run yet; reductions are answered from the grouping's cache,
+    // anything else materialises the gather first
+    bool deferred = false;
+    GroupCtx* dgroup = nullptr;
+    uint32_t dg = 0;
+    const void* dsrc = nullptr;
+    size_t dsrc_bytes = 0;
+    int dtag = 0;
+    bool dsrc_borrowed = false;
 };
 
 class Runtime {
@@ -70,6 +94,7 @@ public:
         *temp_out = nullptr;
         if (bytes == 0) return nullptr;
         auto it = find(p);
+        if (it != map_.end() && it->second.deferred) materialize(it);
         if (it != map_.end() && (uintptr_t)p + bytes <= it->first + it->second.bytes)
             return static_cast<char*>(it->second.dptr) + ((uintptr_t)p - it->first);
         void* d = nullptr;
@@ -103,9 +128,81 @@ public:
         ++stale;
         return d;
     }
+    // ---- grouped fast path ------------------------------------------------------------------------------------
+    void adopt_group(GroupCtx* g, void* drows) {
+        adopt(g->row_ids, (size_t)g->n * 4, drows, /*host_valid=*/false);
+        auto it = map_.find((uintptr_t)g->row_ids);
+        if (it != map_.end()) it->second.gctx = g;
+    }
+    // is [idx, idx+count) exactly the row list of one group of a registered grouping?
+    bool group_of(const uint32_t* idx, uint32_t count, GroupCtx** gc, uint32_t* g) {
+        auto it = find(idx);
+        if (it == map_.end() || !it->second.gctx) return false;
+        GroupCtx* c = it->second.gctx;
+        uint32_t off = (uint32_t)(idx - c->row_ids);
+        uint32_t lo = 0, hi = c->G;                       // largest g with offsets[g] <= off
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (c->offsets[mid] <= off) lo = mid; else hi = mid; }
+        if (c->G == 0 || c->offsets[lo] != off || c->counts[lo] != count) return false;
+        *gc = c; *g = lo;
+        return true;
+    }
+    void defer_gather(void* host_out, size_t bytes, GroupCtx* gc, uint32_t g, const void* src, size_t src_bytes, bool src_borrowed, int tag) {
+        forget_range(host_out, bytes);
+        Entry e; e.bytes = bytes; e.host_stale = true; e.deferred = true; e.dgroup = gc; e.dg = g;
+        e.dsrc = src; e.dsrc_bytes = src_bytes; e.dsrc_borrowed = src_borrowed; e.dtag = tag;
+        map_[(uintptr_t)host_out] = e;
+        ++stale;
+    }
+    void materialize(std::map<uintptr_t, Entry>::iterator it) {
+        Entry& e = it->second;
+        GroupCtx* c = e.dgroup;
+        void* d = nullptr;
+        int rc = aqg_malloc(ctx(), e.bytes ? e.bytes : 16, &d);
+        if (rc != AQG_OK) die("aqg_malloc", rc, ctx_);
+        e.deferred = false;                                // (before input(): the source may be this very registry)
+        e.dptr = d;
+        void* tmp = nullptr;
+        const void* dsrc = input(e.dsrc, e.dsrc_bytes, e.dsrc_borrowed, &tmp);
+        void* tmp2 = nullptr;
+        const void* drows = input(c->row_ids + c->offsets[e.dg], (size_t)c->counts[e.dg] * 4, false, &tmp2);
+        rc = aqg_gather(ctx_, e.dtag, dsrc, static_cast<const uint32_t*>(drows), c->counts[e.dg], d);
+        if (rc != AQG_OK) die("aqg_gather", rc, ctx_);
+        release(tmp); release(tmp2);
+    }
+    // op(col[vecs[g]]) for a deferred gather at p: answered from the per-grouping cache (one kernel for all groups)
+    bool deferred_reduce(const void* p, int op, void* out16) {
+        auto it = map_.find((uintptr_t)p);
+        if (it == map_.end() || !it->second.deferred) return false;
+        Entry& e = it->second;
+        GroupCtx* c = e.dgroup;
+        auto key = std::make_pair(e.dsrc, op);
+        auto hit = c->cache.find(key);
+        if (hit == c->cache.end()) {
+            const int ot = aqg_reduce_out_dtype(op, e.dtag);
+            const size_t osz = aqg_dtype_size(ot);
+            void* dout = nullptr;
+            int rc = aqg_malloc(ctx(), (size_t)c->G * 16 + 16, &dout);
+            if (rc != AQG_OK) die("aqg_malloc", rc, ctx_);
+            void* tmp = nullptr;
+            const void* dsrc = input(e.dsrc, e.dsrc_bytes, e.dsrc_borrowed, &tmp);
+            rc = aqg_grouped_reduce(ctx_, c->handle, op, e.dtag, dsrc, dout);
+            if (rc != AQG_OK) die("aqg_grouped_reduce", rc, ctx_);
+            std::vector<unsigned char> packed((size_t)c->G * osz), slots((size_t)c->G * 16, 0);
+            rc = aqg_d2h(ctx_, packed.data(), dout, packed.size());
+            if (rc != AQG_OK) die("aqg_d2h", rc, ctx_);
+            for (uint32_t g = 0; g < c->G; ++g) std::memcpy(&slots[(size_t)g * 16], &packed[(size_t)g * osz], osz);
+            release(tmp);
+            aqg_free(ctx_, dout);
+            hit = c->cache.emplace(key, std::move(slots)).first;
+        }
+        std::memcpy(out16, &hit->second[(size_t)e.dg * 16], 16);
+        return true;
+    }
+
     // make the host copy of the buffer containing p valid
     void touch(const void* p) {
         auto it = find(p);
+        if (it != map_.end() && it->second.deferred) materialize(it);
         if (it == map_.end() || !it->second.host_stale) return;
         int rc = aqg_d2h(ctx(), (void*)it->first, it->second.dptr, it->second.bytes);
         if (rc != AQG_OK) die("aqg_d2h", rc, ctx_);
@@ -117,7 +214,7 @@ public:
         auto it = map_.find((uintptr_t)p);
         if (it == map_.end()) return;
         if (it->second.host_stale) --stale;
-        aqg_free(ctx(), it->second.dptr);
+        if (it->second.dptr) aqg_free(ctx(), it->second.dptr);
         map_.erase(it);
     }
     void forget_range(const void* p, size_t bytes) {
@@ -125,7 +222,7 @@ public:
         auto it = map_.lower_bound((uintptr_t)p);
         while (it != map_.end() && it->first < (uintptr_t)p + (bytes ? bytes : 1)) {
             if (it->second.host_stale) --stale;
-            aqg_free(ctx(), it->second.dptr);
+            if (it->second.dptr) aqg_free(ctx(), it->second.dptr);
             it = map_.erase(it);
         }
     }
@@ -140,7 +237,7 @@ private:
     Runtime() = default;
     ~Runtime() {
         if (ctx_) {
-            for (auto& kv : map_) aqg_free(ctx_, kv.second.dptr);
+            for (auto& kv : map_) if (kv.second.dptr) aqg_free(ctx_, kv.second.dptr);
             aqg_ctx_destroy(ctx_);
         }
     }

@@ -31,17 +31,11 @@ template <class> class ColRef;
 
 namespace aq {
 
-struct GroupTable {          // host-side view of one device group-by
-    uint32_t n = 0, G = 0;
-    uint32_t* offsets = nullptr;     // [G+1] malloc'd, host valid
-    uint32_t* counts = nullptr;      // [G]   malloc'd, host valid
-    uint32_t* row_ids = nullptr;     // [n]   malloc'd, device copy registered, host filled lazily
-    aqg_groupby* handle = nullptr;   // keeps reversemap / first_rows on the device
-};
+using GroupTable = dev::GroupCtx;   // host-side view of one device group-by (offsets/counts host valid, row_ids filled lazily)
 
-inline GroupTable build_groups(int nkeys, const int* dts, const void* const* dev_cols, uint32_t n, bool want_reversemap, uint32_t* reversemap_host) {
+inline GroupTable& build_groups(int nkeys, const int* dts, const void* const* dev_cols, uint32_t n, bool want_reversemap, uint32_t* reversemap_host) {
     auto& rt = dev::Runtime::get();
-    GroupTable t;
+    GroupTable& t = *new GroupTable();      // owned by whoever holds the grouping (AQHashTable / the module's lifetime)
     t.n = n;
     dev::check(aqg_groupby_build(rt.ctx(), nkeys, dts, dev_cols, n, 0, &t.handle), "aqg_groupby_build");
     t.G = aqg_groupby_ngroups(t.handle);
@@ -56,7 +50,7 @@ inline GroupTable build_groups(int nkeys, const int* dts, const void* const* dev
     if (t.G) dev::check(aqg_d2h(rt.ctx(), t.counts, aqg_groupby_counts(t.handle), (size_t)t.G * 4), "aqg_d2h");
     if (want_reversemap && n) dev::check(aqg_d2h(rt.ctx(), reversemap_host, aqg_groupby_reversemap(t.handle), (size_t)n * 4), "aqg_d2h");
     aqg_free(rt.ctx(), doff);
-    rt.adopt(t.row_ids, (size_t)n * 4, drows, /*host_valid=*/false);    // vecs[g] views resolve to the device copy
+    rt.adopt_group(&t, drows);    // vecs[g] views resolve to the device copy and identify their group
     return t;
 }
 
@@ -119,16 +113,15 @@ public:
     // counting sort of row ids by group: vecs[g] = rows of group g, DESCENDING; ht_base[g] = start offset
     vector_type<uint32_t>* ht_postproc(uint32_t sz) {
         finish(sz);
-        std::memcpy(ht_base, table_.offsets, (size_t)table_.G * 4);
-        auto vecs = aq::make_vecs(table_);
+        std::memcpy(ht_base, table().offsets, (size_t)table().G * 4);
+        auto vecs = aq::make_vecs(table());
         // expose the row lists through the reference's `mapbase` too (host copy)
-        aq::dev::Runtime::get().touch(table_.row_ids);
-        std::memcpy(mapbase, table_.row_ids, (size_t)sz * 4);
+        if (sz) { aq::dev::Runtime::get().touch(table().row_ids); std::memcpy(mapbase, table().row_ids, (size_t)sz * 4); }
         return vecs;
     }
     std::vector<Key>& values() { finish((uint32_t)staged_.size()); return keys_; }
-    size_t size() { finish((uint32_t)staged_.size()); return table_.G; }
-    ~AQHashTable() { if (table_.handle) aqg_groupby_destroy(table_.handle); std::free(table_.offsets); std::free(table_.counts); if (table_.row_ids) { aq::dev::Runtime::get().forget(table_.row_ids); std::free(table_.row_ids); } }
+    size_t size() { finish((uint32_t)staged_.size()); return table().G; }
+    ~AQHashTable() { drop_table(); }
 
 private:
     template <size_t... Is> void finish_staged(uint32_t n, std::index_sequence<Is...>) {
@@ -140,27 +133,39 @@ private:
         aq::dev::In ins[] = {aq::dev::In(std::get<Is>(cols).data(), (size_t)n * sizeof(std::tuple_element_t<Is, Key>), false)...};
         const void* ptrs[sizeof...(Is)];
         for (size_t k = 0; k < sizeof...(Is); ++k) ptrs[k] = ins[k].d;
-        table_ = aq::build_groups((int)sizeof...(Is), dts, ptrs, n, true, reversemap);
-        aq::fetch_keys(table_, keys_, std::index_sequence<Is...>{});
+        drop_table();
+        tp_ = &aq::build_groups((int)sizeof...(Is), dts, ptrs, n, true, reversemap);
+        aq::fetch_keys(*tp_, keys_, std::index_sequence<Is...>{});
     }
     template <class... Cols> void build_from_columns(uint32_t n, Cols&... cols) {
         const int dts[] = {aq::dev::tag_of<std::remove_cv_t<std::remove_pointer_t<decltype(cols.container)>>>::value...};
         aq::dev::In ins[] = {aq::dev::In(cols.container, (size_t)n * sizeof(*cols.container), cols.capacity == 0)...};
         const void* ptrs[sizeof...(Cols)];
         for (size_t k = 0; k < sizeof...(Cols); ++k) ptrs[k] = ins[k].d;
-        table_ = aq::build_groups((int)sizeof...(Cols), dts, ptrs, n, true, reversemap);
-        aq::fetch_keys(table_, keys_, std::make_index_sequence<std::tuple_size_v<Key>>{});
-        for (uint32_t g = 0; g < table_.G; ++g) ht_base[g] = table_.counts[g];
+        drop_table();
+        tp_ = &aq::build_groups((int)sizeof...(Cols), dts, ptrs, n, true, reversemap);
+        aq::fetch_keys(*tp_, keys_, std::make_index_sequence<std::tuple_size_v<Key>>{});
+        for (uint32_t g = 0; g < tp_->G; ++g) ht_base[g] = tp_->counts[g];
         done_ = true;
     }
     void finish(uint32_t n) {
         if (done_) return;
         finish_staged(n, std::make_index_sequence<std::tuple_size_v<Key>>{});
-        for (uint32_t g = 0; g < table_.G; ++g) ht_base[g] = table_.counts[g];
+        for (uint32_t g = 0; g < table().G; ++g) ht_base[g] = table().counts[g];
         done_ = true;
     }
     std::vector<Key> staged_, keys_;
-    aq::GroupTable table_;
+    aq::GroupTable* tp_ = nullptr;
+    aq::GroupTable empty_;
+    aq::GroupTable& table() { return tp_ ? *tp_ : empty_; }
+    void drop_table() {
+        if (!tp_) return;
+        if (tp_->row_ids) { aq::dev::Runtime::get().forget(tp_->row_ids); std::free(tp_->row_ids); }
+        if (tp_->handle) aqg_groupby_destroy(tp_->handle);
+        std::free(tp_->offsets); std::free(tp_->counts);
+        delete tp_;
+        tp_ = nullptr;
+    }
     uint32_t cap_ = 0;
     bool done_ = false;
 };
@@ -179,12 +184,11 @@ public:
         aq::dev::In ins[] = {aq::dev::In(cols.container, (size_t)n * sizeof(value_type_r<std::decay_t<Cols>>), cols.capacity == 0)...};
         const void* ptrs[sizeof...(Cols)];
         for (size_t k = 0; k < sizeof...(Cols); ++k) ptrs[k] = ins[k].d;
-        aq::GroupTable t = aq::build_groups((int)sizeof...(Cols), dts, ptrs, n, false, nullptr);
+        aq::GroupTable& t = aq::build_groups((int)sizeof...(Cols), dts, ptrs, n, false, nullptr);
         auto* keys = new std::vector<Tuple>();           // lives as long as the module, like the reference's
         aq::fetch_keys(t, *keys, std::index_sequence_for<Cols...>{});
         HashTableComponents<value_type_r<std::decay_t<Cols>>...> c{t.G, keys, aq::make_vecs(t), t.offsets};
-        std::free(t.counts);
-        // t.handle and t.row_ids stay alive for the lifetime of the components (released with the process / session)
+        // the grouping (device handle, row ids, offsets, counts) stays alive for the lifetime of the module, like `keys`
         return c;
     }
 };

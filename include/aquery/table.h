@@ -101,6 +101,15 @@ public:
         if (idxs.size == 0) return ret;
         if constexpr (aq::dev::on_device<_Ty>) {
             auto& rt = aq::dev::Runtime::get();
+            // `col[vecs[g]]` of a device grouping: defer -- a following sum/avg/min/max/... is answered for ALL groups by one
+            // kernel (the generated per-group loop, engine/ast.py:722-789, then costs one launch per aggregate, not per group)
+            aq::dev::GroupCtx* gc = nullptr;
+            uint32_t g = 0;
+            if (rt.group_of(idxs.container, idxs.size, &gc, &g)) {
+                rt.defer_gather(ret.container, (size_t)idxs.size * sizeof(_Ty), gc, g, this->container, (size_t)this->size * sizeof(_Ty),
+                                this->capacity == 0, aq::dev::tag_of<_Ty>::value);
+                return ret;
+            }
             void* dout = rt.result(ret.container, (size_t)idxs.size * sizeof(_Ty));
             // the column's extent is unknown for `ColRef<T>(0, ptr)`-style views: the device copy must already exist or be borrowed
             aq::dev::In col(this->container, (size_t)this->size * sizeof(_Ty), this->capacity == 0);

@@ -25,6 +25,18 @@ static std::vector<std::vector<int>> dataset(const std::string& name) {
                 {1, 1, 4, 2, 2, 2, 1, 1, 2, 2, 2, 2, 1, 3, 2, 3, 4, 4, 3, 2},
                 {2, 2, 3, 2, 3, 1, 3, 1, 3, 4, 3, 1, 4, 4, 3, 4, 1, 1, 2, 3},
                 {2, 2, 4, 2, 4, 4, 3, 2, 4, 2, 3, 2, 2, 4, 1, 4, 2, 2, 2, 1}};
+    if (name == "synthetic") {      // 200,000 rows, 1,000 groups: a = lcg % 1000, b = 7, c = lcg % 97, d = 1 (same LCG in tests/test_gpu_emitted.py)
+        std::vector<std::vector<int>> t(4, std::vector<int>(200000));
+        unsigned long long x = 12345;
+        for (int i = 0; i < 200000; ++i) {
+            x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+            t[0][i] = (int)((x >> 33) % 1000);
+            t[1][i] = 7;
+            t[2][i] = (int)((x >> 20) % 97);
+            t[3][i] = 1;
+        }
+        return t;
+    }
     return {};
 }
 

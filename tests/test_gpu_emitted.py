@@ -95,3 +95,31 @@ def test_aqhashtable_shape():
     assert rows[1:5] == [["2", "1", "4.000000"], ["2", "1", "2.500000"], ["2", "1", "2.000000"], ["2", "1", "2.500000"]], out
     # group (a=2,b=4): rows 16,2 -> c = 1,3 -> 1, 2
     assert rows[5:7] == [["2", "4", "1.000000"], ["2", "4", "2.000000"]], out
+
+
+@pytest.mark.gpu
+def test_group_loop_many_groups_uses_one_kernel_per_aggregate():
+    """1,000 groups through the UNCHANGED generated loop: `sum(c[val])` / `avg(c[val])` per group are answered by the
+    deferred-gather fast path (one grouped kernel per aggregate); results vs a straight recomputation."""
+    import time
+    build()
+    t0 = time.time()
+    out = run("groupby_q1.so", "synthetic", "dll_3kR9pQ")
+    dt = time.time() - t0
+    x = 12345
+    a, c = [], []
+    for _ in range(200000):
+        x = (x * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        a.append((x >> 33) % 1000)
+        c.append((x >> 20) % 97)
+    order, sums, cnts = [], {}, {}
+    for k, v in zip(a, c):
+        if k not in sums:
+            order.append(k); sums[k] = 0; cnts[k] = 0
+        sums[k] += v; cnts[k] += 1
+    rows = [l.split() for l in out.strip().splitlines()[2:-1]]
+    assert len(rows) == len(order) == 1000
+    assert [int(r[0]) for r in rows] == [sums[k] for k in order]
+    assert [int(r[3]) for r in rows] == [cnts[k] for k in order]
+    assert all(abs(float(r[4]) - sums[k] / cnts[k]) < 1e-3 for r, k in zip(rows, order))
+    assert dt < 60
