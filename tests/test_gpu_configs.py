@@ -1,0 +1,141 @@
+"""GPU parity on the BASELINE.json configurations' own shapes (seed-42 h2o / time-series columns generated on both
+sides by the same counter-based generator), at sizes the oracle finishes in seconds, plus size-independent properties
+at 1e8 rows."""
+import numpy as np
+import pytest
+
+import checker as ck
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+K = 100
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import aquery2_amd
+    d = aquery2_amd.Device(0)
+    yield d
+    d.close()
+
+
+def cols(gpu, oracle, n, which):
+    dev = {c: gpu.gen_column(c, 42, 0, n, n, K) for c in which}
+    host = {c: oracle.gen_column(c, 42, 0, n, n, K) for c in which}
+    return dev, host
+
+
+def test_config1_q1_sum_by_single_int_key(gpu, oracle):
+    n = 5_000_003
+    dev, host = cols(gpu, oracle, n, [ck.GEN_ID1, ck.GEN_V1])
+    gb = gpu.groupby_agg([dev[ck.GEN_ID1]], [ck.RED_SUM], [dev[ck.GEN_V1]], hint=128)
+    o = oracle.groupby([host[ck.GEN_ID1]])
+    assert gb.ngroups == o["ngroups"] == 100
+    assert np.array_equal(gb.keys(0, np.int32), host[ck.GEN_ID1][o["first_rows"]])
+    assert np.array_equal(gb.first_rows(), o["first_rows"])
+    assert gu.same_bits(gb.result(0, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, host[ck.GEN_V1], o))
+
+
+def test_config2_q5_high_cardinality_and_q2_multi_key(gpu, oracle):
+    n = 3_000_000
+    dev, host = cols(gpu, oracle, n, [ck.GEN_ID1, ck.GEN_ID2, ck.GEN_ID6, ck.GEN_V1, ck.GEN_V2, ck.GEN_V3])
+    # Q5: sum(v1), sum(v2), sum(v3) by id6   (id6 ~ U{1..n/K}: 30,000 groups)
+    ops = [ck.RED_SUM] * 3
+    gb = gpu.groupby_agg([dev[ck.GEN_ID6]], ops, [dev[ck.GEN_V1], dev[ck.GEN_V2], dev[ck.GEN_V3]], hint=n // K + 1024)
+    o = oracle.groupby([host[ck.GEN_ID6]])
+    assert gb.ngroups == o["ngroups"]
+    assert np.array_equal(gb.first_rows(), o["first_rows"])
+    assert np.array_equal(gb.keys(0, np.int32), host[ck.GEN_ID6][o["first_rows"]])
+    for j, c in enumerate((ck.GEN_V1, ck.GEN_V2)):
+        assert gu.same_bits(gb.result(j, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, host[c], o))
+    got, want = gb.result(2, ck.RED_SUM, ck.FLOAT), oracle.grouped_reduce(ck.RED_SUM, host[ck.GEN_V3], o)
+    assert np.all(np.abs(got - want) <= np.maximum(1.0, np.abs(want)) * 1000 * 2.0 ** -52)   # <= ~100 rows per group
+    # Q2: sum(v1) by id1, id2 (1e4 groups, two int32 keys packed into one 64-bit word)
+    gb2 = gpu.groupby_agg([dev[ck.GEN_ID1], dev[ck.GEN_ID2]], [ck.RED_SUM], [dev[ck.GEN_V1]])
+    o2 = oracle.groupby([host[ck.GEN_ID1], host[ck.GEN_ID2]])
+    assert gb2.ngroups == o2["ngroups"] == 10000
+    assert np.array_equal(gb2.first_rows(), o2["first_rows"])
+    assert gu.same_bits(gb2.result(0, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, host[ck.GEN_V1], o2))
+
+
+def test_config2_q10_six_keys(gpu, oracle):
+    n = 300_000
+    ids = [ck.GEN_ID1, ck.GEN_ID2, ck.GEN_ID3, ck.GEN_ID4, ck.GEN_ID5, ck.GEN_ID6]
+    dev, host = cols(gpu, oracle, n, ids + [ck.GEN_V3])
+    gb = gpu.groupby_agg([dev[c] for c in ids], [ck.RED_SUM, ck.RED_COUNT], [dev[ck.GEN_V3], dev[ck.GEN_V3]])
+    o = oracle.groupby([host[c] for c in ids])
+    assert gb.ngroups == o["ngroups"]
+    assert np.array_equal(gb.first_rows(), o["first_rows"])
+    assert np.array_equal(gb.counts(), o["counts"])
+    for k, c in enumerate(ids):
+        assert np.array_equal(gb.keys(k, np.int32), host[c][o["first_rows"]])
+
+
+def test_config3_moving_windows_over_ordered_series(gpu, oracle):
+    """stock.a-style queries over a time series: max(price - mins(price)), avgs / sums windows w in {3,5,10,100}"""
+    n = 4_000_001
+    dev, host = cols(gpu, oracle, n, [ck.GEN_TIMESTAMP, ck.GEN_PRICE])
+    p_d, p_h = dev[ck.GEN_PRICE], host[ck.GEN_PRICE]
+    assert np.array_equal(host[ck.GEN_TIMESTAMP][:3], [1, 2, 3])
+    # q2 of tests/stock.a
+    d = gpu.ewise(ck.OP_SUB, p_d, gpu.scan(ck.SCAN_MINS, p_d, keep=True), keep=True)
+    want = oracle.reduce(ck.RED_MAX, oracle.ewise(ck.OP_SUB, p_h, oracle.scan(ck.SCAN_MINS, p_h)))
+    assert int(gpu.reduce(ck.RED_MAX, d)) == int(want)
+    for w in (3, 5, 10, 100):
+        assert gu.same_bits(gpu.scan(ck.SCAN_SUMW, p_d, w), oracle.scan(ck.SCAN_SUMW, p_h, w)), w
+        assert gu.same_bits(gpu.scan(ck.SCAN_MINW, p_d, w), oracle.scan(ck.SCAN_MINW, p_h, w)), w
+        assert gu.same_bits(gpu.scan(ck.SCAN_MAXW, p_d, w), oracle.scan(ck.SCAN_MAXW, p_h, w)), w
+        a, b = gpu.scan(ck.SCAN_AVGW, p_d, w), oracle.scan(ck.SCAN_AVGW, p_h, w)
+        # device: exact window mean rounded once; reference: floating recurrence drifting by ~ulp per step
+        assert np.all(np.abs(a - b) <= 4.0 * np.spacing(500.0) * (np.arange(n) + 2)), w
+    assert gu.same_bits(gpu.scan(ck.SCAN_SUMS, p_d), oracle.scan(ck.SCAN_SUMS, p_h))
+    assert gu.same_bits(gpu.scan(ck.SCAN_AVGS, p_d), oracle.scan(ck.SCAN_AVGS, p_h))
+    assert gu.same_bits(gpu.scan(ck.SCAN_DELTAS, p_d), oracle.scan(ck.SCAN_DELTAS, p_h))
+    assert gu.same_bits(gpu.scan(ck.SCAN_RATIOW, p_d, 1), oracle.scan(ck.SCAN_RATIOW, p_h, 1))
+
+
+def test_config4_join_then_groupby(gpu, oracle):
+    """fact JOIN small(id4, w) ON id4, then sum(v1 * w) by id1 -- composed from the C-ABI pieces"""
+    n = 2_000_000
+    dev, host = cols(gpu, oracle, n, [ck.GEN_ID1, ck.GEN_ID4, ck.GEN_V1])
+    rng = np.random.default_rng(4)
+    dim_key = rng.permutation(np.arange(1, K + 1, dtype=np.int32))
+    dim_w = rng.integers(1, 50, K).astype(np.int32)
+    look = gpu.join_lookup(dim_key, dev[ck.GEN_ID4])                      # build row of every fact row
+    pos = np.zeros(K + 1, np.uint32)
+    pos[dim_key] = np.arange(K, dtype=np.uint32)
+    assert np.array_equal(look, pos[host[ck.GEN_ID4]])
+    w_of_row = gpu.gather(dim_w, look)
+    prod = gpu.ewise(ck.OP_MUL, dev[ck.GEN_V1], w_of_row, ot=ck.INT64, keep=True)   # aqop_mul with an int64 Ret
+    gb = gpu.groupby_agg([dev[ck.GEN_ID1]], [ck.RED_SUM], [prod], hint=128)
+    o = oracle.groupby([host[ck.GEN_ID1]])
+    want_prod = host[ck.GEN_V1].astype(np.int64) * dim_w[pos[host[ck.GEN_ID4]]].astype(np.int64)
+    assert np.array_equal(gb.first_rows(), o["first_rows"])
+    assert gu.same_bits(gb.result(0, ck.RED_SUM, ck.INT64), oracle.grouped_reduce(ck.RED_SUM, want_prod, o))
+
+
+def test_full_size_properties_q5_and_windows(gpu):
+    """1e8 rows: Q5 invariants (sums of group sums, counts) and window invariants"""
+    n = 100_000_000
+    id6 = gpu.gen_column(ck.GEN_ID6, 42, 0, n, n, K)
+    v1 = gpu.gen_column(ck.GEN_V1, 42, 0, n, n, K)
+    v2 = gpu.gen_column(ck.GEN_V2, 42, 0, n, n, K)
+    gb = gpu.groupby_agg([id6], [ck.RED_SUM, ck.RED_SUM, ck.RED_COUNT], [v1, v2, v1], hint=n // K + 1024)
+    assert gb.ngroups <= n // K and gb.ngroups > 0.99 * (n // K)
+    s1 = gb.result(0, ck.RED_SUM, ck.INT32)
+    s2 = gb.result(1, ck.RED_SUM, ck.INT32)
+    assert int(s1["lo"].astype(np.int64).sum()) == int(gpu.reduce(ck.RED_SUM, v1)) and not s1["hi"].any()
+    assert int(s2["lo"].astype(np.int64).sum()) == int(gpu.reduce(ck.RED_SUM, v2))
+    assert int(gb.result(2, ck.RED_COUNT, ck.INT32).sum()) == n
+    first = gb.first_rows().astype(np.int64)
+    assert np.all(np.diff(first) > 0)
+    price = gpu.gen_column(ck.GEN_PRICE, 42, 0, n, n, K)
+    for w in (5, 100):
+        mw = gpu.scan(ck.SCAN_MINW, price, w, keep=True)
+        xw = gpu.scan(ck.SCAN_MAXW, price, w, keep=True)
+        assert int(gpu.reduce(ck.RED_MIN, gpu.ewise(ck.OP_SUB, price, mw, keep=True))) >= 0
+        assert int(gpu.reduce(ck.RED_MIN, gpu.ewise(ck.OP_SUB, xw, price, keep=True))) >= 0
+        mw.free(); xw.free()
+    sw = gpu.scan(ck.SCAN_SUMW, price, n, keep=True)      # window = whole column: last element is the column sum
+    last = sw.to_host()[-1]
+    assert (int(last["hi"]) << 64) + int(last["lo"]) == int(gpu.reduce(ck.RED_SUM, price))
