@@ -30,8 +30,13 @@ namespace {
 // ---- the single-pass aggregation kernel -------------------------------------------------------
 // K32: one 4-byte key column (h2o Q1/Q3/Q4/Q5).  LDS slot = {key32, first_row32} in one 8-byte
 // word, so a hit costs one ds_read_b64 + one LDS atomic per accumulator.
-template <bool USE_LDS, bool K32, int NACC>
-__global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable gt, uint32_t n, uint32_t lcap, int need_count, uint32_t lrep) {
+// Tables that do not fit one 64 KB LDS table (up to ~25,000 groups: h2o Q2) use BLOCK = 1024, one workgroup per CU with a table
+// of up to 150 KB (gfx950: 160 KB of LDS per workgroup), and `npass` passes over the rows: pass p aggregates only the keys
+// whose pass hash equals p, so every pass's groups fit the table.  npass x (key + value bytes) of streaming reads beat the
+// ~3e10/s scattered HBM atomics of the global table by an order of magnitude (Q2, 1e9 rows: 54 ms -> see DESIGN.md).
+constexpr uint32_t SKIP = 0xFFFFFFFEu;          // row belongs to another pass
+template <bool USE_LDS, bool K32, int NACC, int BLOCK = 256>
+__global__ void __launch_bounds__(BLOCK) agg_kernel(KeySpec ks, AccSpec as, GTable gt, uint32_t n, uint32_t lcap, int need_count, uint32_t lrep, uint32_t npass) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     // LDS layout (USE_LDS): lkey u64[lcap+1] | lacc[a] u64[lcap+1] ... | lfirst u32[lcap+1] (wide keys) | lcount u32[lcap+1] | lused u32
     // `lrep` replicas of the table (lane l uses replica l % lrep) cut same-address / same-bank conflicts
@@ -43,10 +48,13 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
     uint32_t* lcount = lfirst + (K32 ? 0 : LT);
     uint32_t* lused = lcount + (need_count ? LT : 0);
     const uint32_t rbase = USE_LDS ? (threadIdx.x & (lrep - 1)) * (lcap + 1) : 0;
-    const uint32_t lmask = lcap - 1;
     const uint32_t llimit = lcap - (lcap >> 2);   // stop inserting at 75 % load; further new keys go to HBM
+    // slot of a hash: multiply-shift, so the capacity need not be a power of two (it is sized to the LDS budget)
+    auto home = [&](uint32_t h1) -> uint32_t { return __umulhi(lds_h2(h1), lcap); };
 
+  for (uint32_t pass = 0; pass < npass; ++pass) {
     if constexpr (USE_LDS) {
+        if (pass) __syncthreads();
         for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) {
             if constexpr (K32) lkey[s] = ((uint64_t)NOROW << 32) | EMPTY32; else { lkey[s] = EMPTY64; lfirst[s] = NOROW; }
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) lacc[(size_t)a * LT + s] = acc_init(as.kind[a]);
@@ -57,14 +65,13 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
     }
 
     // returns the LDS slot of `key` (inserting it), or FAIL when the table is at its load limit
-    auto lds_slot = [&](uint64_t key) -> uint32_t {
+    auto lds_slot = [&](uint64_t key, uint32_t s) -> uint32_t {   // s: home slot
         if constexpr (K32) {
             uint32_t k = (uint32_t)key;
             if (k == EMPTY32) return rbase + lcap;
             uint32_t* kw = reinterpret_cast<uint32_t*>(lkey + rbase);
             uint32_t* used = lused + (threadIdx.x & (lrep - 1));
-            uint32_t s = hash32(k) & lmask;
-            for (uint32_t p = 0; p <= lmask; ++p) {
+            for (uint32_t p = 0; p < lcap; ++p) {
                 uint32_t cur = kw[2 * s];
                 if (cur == k) return rbase + s;
                 if (cur == EMPTY32) {
@@ -73,15 +80,14 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
                     if (old == EMPTY32) { atomicAdd(used, 1u); return rbase + s; }
                     if (old == k) return rbase + s;
                 }
-                s = (s + 1) & lmask;
+                s = s + 1 == lcap ? 0 : s + 1;
             }
             return FAIL;
         } else {
             if (key == EMPTY64) return rbase + lcap;
             uint64_t* kw = lkey + rbase;
             uint32_t* used = lused + (threadIdx.x & (lrep - 1));
-            uint32_t s = hash64(key) & lmask;
-            for (uint32_t p = 0; p <= lmask; ++p) {
+            for (uint32_t p = 0; p < lcap; ++p) {
                 uint64_t cur = kw[s];
                 if (cur == key) return rbase + s;
                 if (cur == EMPTY64) {
@@ -90,7 +96,7 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
                     if (old == EMPTY64) { atomicAdd(used, 1u); return rbase + s; }
                     if (old == key) return rbase + s;
                 }
-                s = (s + 1) & lmask;
+                s = s + 1 == lcap ? 0 : s + 1;
             }
             return FAIL;
         }
@@ -119,8 +125,7 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
 #pragma unroll
             for (int j = 0; j < 4; ++j) key[j] = kv.v[j];
         } else if (!ks.wide) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) key[j] = pack_key(ks, base + j);
+            pack_key4(ks, base, key);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) key[j] = base + j;
@@ -131,25 +136,32 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
         if constexpr (USE_LDS) {
             // speculative first probe of all four rows at once: one LDS round trip in the common (hit) case
             uint64_t w[4];
-            if constexpr (K32) {
+            uint32_t hs[4];                     // home slot (without the replica base)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { slot[j] = rbase + (hash32((uint32_t)key[j]) & lmask); w[j] = lkey[slot[j]]; }
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t h1 = lds_h1<K32>(key[j]);
+                if (npass > 1 && __umulhi(h1, npass) != pass) { slot[j] = SKIP; continue; }
+                hs[j] = home(h1);
+                slot[j] = rbase + hs[j];
+                w[j] = lkey[slot[j]];
+            }
+            if constexpr (K32) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     uint32_t row = (uint32_t)base + j;
+                    if (slot[j] == SKIP) continue;
                     if ((uint32_t)w[j] == (uint32_t)key[j] && (uint32_t)key[j] != EMPTY32) {
                         if (row < (uint32_t)(w[j] >> 32)) atomicMin(reinterpret_cast<uint32_t*>(lkey) + 2 * slot[j] + 1, row);
                     } else {
-                        slot[j] = lds_slot(key[j]);
+                        slot[j] = lds_slot(key[j], hs[j]);
                         if (slot[j] != FAIL) lds_touch_first(slot[j], row);
                     }
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { slot[j] = rbase + (hash64(key[j]) & lmask); w[j] = lkey[slot[j]]; }
-#pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (!(w[j] == key[j] && key[j] != EMPTY64)) slot[j] = lds_slot(key[j]);
+                    if (slot[j] == SKIP) continue;
+                    if (!(w[j] == key[j] && key[j] != EMPTY64)) slot[j] = lds_slot(key[j], hs[j]);
                     if (slot[j] != FAIL) lds_touch_first(slot[j], (uint32_t)base + j);
                 }
             }
@@ -159,26 +171,26 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
         }
         if (need_count) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (slot[j] != FAIL) atomicAdd(&lcount[slot[j]], 1u);
+            for (int j = 0; j < 4; ++j) if (slot[j] < SKIP) atomicAdd(&lcount[slot[j]], 1u);
         }
         _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
             uint64_t* la = lacc + (size_t)a * LT;
             switch (as.kind[a]) {   // wave-uniform: one branch per accumulator per four rows
             case ACC_ADD_I:
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)vals[a][j]);
+                for (int j = 0; j < 4; ++j) if (slot[j] < SKIP) atomicAdd(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)vals[a][j]);
                 break;
             case ACC_ADD_F:
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<double*>(&la[slot[j]]), __builtin_bit_cast(double, vals[a][j]));
+                for (int j = 0; j < 4; ++j) if (slot[j] < SKIP) atomicAdd(reinterpret_cast<double*>(&la[slot[j]]), __builtin_bit_cast(double, vals[a][j]));
                 break;
             case ACC_MIN:
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (slot[j] != FAIL) atomicMin(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)vals[a][j]);
+                for (int j = 0; j < 4; ++j) if (slot[j] < SKIP) atomicMin(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)vals[a][j]);
                 break;
             default:
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (slot[j] != FAIL) atomicMax(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)vals[a][j]);
+                for (int j = 0; j < 4; ++j) if (slot[j] < SKIP) atomicMax(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)vals[a][j]);
                 break;
             }
         }
@@ -192,7 +204,7 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
         }
     }
     // tail rows (< 4) by the first lanes of block 0
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && pass == 0) {
         uint32_t row = (nchunk << 2) + threadIdx.x;
         if (row < n) {
             uint64_t k = ks.wide ? (uint64_t)row : pack_key(ks, row);
@@ -220,6 +232,7 @@ __global__ void __launch_bounds__(256) agg_kernel(KeySpec ks, AccSpec as, GTable
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) acc_apply(gt.acc_p(a, g), as.kind[a], lacc[(size_t)a * LT + s]);
         }
     }
+  }   // passes
 }
 
 // ---- fast path: one 4-byte key column, 4-byte value columns, SUM/AVG/COUNT (h2o Q1, Q4) -------------------------------------
@@ -752,28 +765,44 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     const AccSpec& as = plan.as;
     const bool k32 = ks.nkeys == 1 && ks.total_bytes == 4;
     uint32_t gcap = next_pow2((uint64_t)(hint < 512 ? 512 : hint) * 2);
-    // LDS mode while one workgroup's table (75 % load) fits 64 KB; otherwise rows go straight to HBM
+    // LDS mode, small: one workgroup's table (75 % load) fits 64 KB, several workgroups per CU.
+    // LDS mode, big:   one 1024-thread workgroup per CU with a table of up to 150 KB, and up to MAX_PASSES passes over the
+    //                  rows, each aggregating the keys of one hash class (agg_kernel).  Beyond that rows go straight to HBM.
+    constexpr uint32_t MAX_PASSES = 4;
+    constexpr size_t LDS_SMALL = 64 * 1024, LDS_BIG = 150 * 1024;
     bool use_lds = hint <= 3072 && !ks.wide;   // wide tuples compare against HBM-resident rows: HBM mode
     uint32_t lcap = use_lds ? next_pow2((uint64_t)(hint < 64 ? 64 : hint) * 4 / 3 + 1) : 0;
     if (use_lds && lcap < 256) lcap = 256;
     const size_t lds_slot_bytes = 8 + 8 * (size_t)as.nacc + (k32 ? 0 : 4) + (plan.need_count ? 4 : 0);
-    if (use_lds && (size_t)(lcap + 1) * lds_slot_bytes > 64 * 1024) { use_lds = false; lcap = 0; }
+    if (use_lds && (size_t)(lcap + 1) * lds_slot_bytes > LDS_SMALL) { use_lds = false; lcap = 0; }
+    uint32_t npass = 1;
+    bool big_lds = false;
+    if (!use_lds && !ks.wide && n >= (1u << 20)) {
+        const uint32_t max_slots = (uint32_t)(LDS_BIG / lds_slot_bytes) - 1;
+        const uint32_t per_pass = max_slots - (max_slots >> 2);
+        const uint64_t want = ((uint64_t)hint + per_pass - 1) / per_pass;
+        if (want <= MAX_PASSES) { use_lds = big_lds = true; npass = (uint32_t)want; lcap = max_slots; }
+    }
+    const uint64_t lds_group_cap = use_lds ? (uint64_t)npass * (lcap - (lcap >> 2)) : 0;
     const bool small_rank = hint <= 4096;
     const uint32_t nwords = (n + 31) / 32, ntiles = (nwords + 1023) / 1024;
-    // groups beyond one LDS table: partition the rows instead of hammering an HBM table with scattered atomics
-    // (partition.hip); the build path keeps the HBM table because its second pass looks keys up in it
-    // Measured on MI355X, 1e9 rows (round 1): the partition pipeline is not yet faster than the HBM table (h2o Q5 157 ms vs
-    // 142 ms; its scatter passes run at ~1 TB/s), so it stays off until the scatter reaches streaming rates.
-    static const bool part_on = getenv("AQG_EXPERIMENTAL_PARTITION") != nullptr;   // development switch, see above
-    const bool use_part = part_on && !use_lds && !ks.wide && !for_build && n >= (1u << 16) && hint <= (1u << 25);
+    // groups beyond the LDS tables: partition the rows instead of hammering an HBM table with scattered atomics
+    // (partition.hip: h2o Q5, 1e9 rows, 1e7 groups: 42 ms against 141 ms); the build path keeps the HBM table because
+    // its second pass looks keys up in it.  AQG_DISABLE_PARTITION=1 forces the HBM table (A/B measurements only).
+    static const bool part_off = getenv("AQG_DISABLE_PARTITION") != nullptr;
+    const bool use_part = !part_off && !use_lds && !ks.wide && !for_build && n >= (1u << 20) && hint <= (1u << 25);
     uint32_t part_lcap = 0, pbits = 0;
     if (use_part) {
+        // LDS table of one partition: as many slots as fit 72 KB (two 512-thread workgroups per CU); the slot of a hash is
+        // a multiply-shift, so the capacity need not be a power of two.  Partitions are sized for a load factor <= LF/16:
+        // measured (1e9 rows, 1e7 groups) the LDS aggregation runs 2x faster at 0.3 than at 0.6 (probe sequences are
+        // walked by whole wavefronts), while every extra partition bit costs the scatter passes ~10 %.
+        static const int lf16 = getenv("AQG_PART_LF16") ? atoi(getenv("AQG_PART_LF16")) : 6;
+        static const int lds_kb = getenv("AQG_PART_LDSKB") ? atoi(getenv("AQG_PART_LDSKB")) : 72;
         const size_t sb = 16 + 8 * (size_t)as.nacc;
-        part_lcap = 4096;
-        while ((size_t)(part_lcap + 1) * sb > 64 * 1024) part_lcap >>= 1;
-        uint64_t want_parts = ((uint64_t)hint + part_lcap / 2 - 1) / (part_lcap / 2);
+        part_lcap = (uint32_t)((size_t)lds_kb * 1024 / sb) - 1;
         pbits = 10;                                  // at least 1024 partitions: every CU gets several
-        while (pbits < 16 && (1ull << pbits) < want_parts) ++pbits;
+        while (pbits < 16 && ((uint64_t)hint >> pbits) * 16 > (uint64_t)part_lcap * lf16) ++pbits;
         gcap = (uint32_t)((uint64_t)hint + hint / 4 + 4096 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : (uint64_t)hint + hint / 4 + 4096);   // compact record table
     }
 
@@ -817,7 +846,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (bitmap) AQG_HIP(ctx, hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, ctx->stream));
 
     // fast path eligibility: LDS mode, one 4-byte integer key, 1..3 four-byte value columns, plain additive accumulators
-    bool fast = use_lds && k32 && n >= 8 && as.nacc >= (plan.need_count ? 0 : 1) && as.nacc <= 3 && !for_build &&
+    bool fast = use_lds && !big_lds && k32 && n >= 8 && as.nacc >= (plan.need_count ? 0 : 1) && as.nacc <= 3 && !for_build &&
                 (ks.dt[0] == AQG_INT32 || ks.dt[0] == AQG_UINT32) && ((uintptr_t)ks.col[0] & 15) == 0;
     FastVals fv;
     memset(&fv, 0, sizeof fv);
@@ -861,29 +890,32 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         }
         size_t lds = use_lds ? (size_t)lrep * (lcap + 1) * (8 + 8 * (size_t)as.nacc + (k32 ? 0 : 4) + (plan.need_count ? 4 : 0)) + 4 * 64 : 0;
         unsigned bpc = !use_lds ? 8 : lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : lds <= 80 * 1024 ? 2 : 1;
-        unsigned grid = aqg_grid(ctx, n / 4 + 1, 256, 2, bpc);
+        const unsigned block = big_lds ? (as.nacc <= 2 ? 1024 : 512) : 256;
+        unsigned grid = big_lds ? (unsigned)ctx->num_cu : aqg_grid(ctx, n / 4 + 1, 256, 2, bpc);
         auto launch = [&](auto kern) -> int {
             if (lds) AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, ks, as, gt, n, lcap, plan.need_count, lrep);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, ctx->stream, ks, as, gt, n, lcap, plan.need_count, lrep, npass);
             return AQG_OK;
         };
-        auto by_nacc = [&](auto lds_tag, auto k32_tag) -> int {
+        auto by_nacc = [&](auto lds_tag, auto k32_tag, auto block_tag) -> int {
             constexpr bool L = decltype(lds_tag)::value, K = decltype(k32_tag)::value;
+            constexpr int B = decltype(block_tag)::value;
+            // big tables: 1024 threads per workgroup up to 2 accumulators (<= 128 VGPRs without spills), 512 beyond
+#define AQG_AGG_CASE(N) case N: if constexpr ((B == 1024 && N > 2) || (B == 512 && N <= 2)) return AQG_ERR_ARG; else return launch(&agg_kernel<L, K, N, B>);
             switch (as.nacc) {
-            case 0: return launch(&agg_kernel<L, K, 0>);
-            case 1: return launch(&agg_kernel<L, K, 1>);
-            case 2: return launch(&agg_kernel<L, K, 2>);
-            case 3: return launch(&agg_kernel<L, K, 3>);
-            case 4: return launch(&agg_kernel<L, K, 4>);
-            case 5: return launch(&agg_kernel<L, K, 5>);
-            case 6: return launch(&agg_kernel<L, K, 6>);
-            case 7: return launch(&agg_kernel<L, K, 7>);
-            default: return launch(&agg_kernel<L, K, 8>);
+            AQG_AGG_CASE(0) AQG_AGG_CASE(1) AQG_AGG_CASE(2) AQG_AGG_CASE(3) AQG_AGG_CASE(4) AQG_AGG_CASE(5) AQG_AGG_CASE(6) AQG_AGG_CASE(7)
+            default: if constexpr (B == 1024) return AQG_ERR_ARG; else return launch(&agg_kernel<L, K, 8, B>);
             }
+#undef AQG_AGG_CASE
         };
+        using B256 = std::integral_constant<int, 256>;
+        using B512 = std::integral_constant<int, 512>;
+        using B1024 = std::integral_constant<int, 1024>;
         aqg_kernel_timer_begin(ctx);
-        if (use_lds) { if (k32) AQG_TRY(by_nacc(std::true_type{}, std::true_type{})); else AQG_TRY(by_nacc(std::true_type{}, std::false_type{})); }
-        else { if (k32) AQG_TRY(by_nacc(std::false_type{}, std::true_type{})); else AQG_TRY(by_nacc(std::false_type{}, std::false_type{})); }
+        if (big_lds && block == 1024) { if (k32) AQG_TRY(by_nacc(std::true_type{}, std::true_type{}, B1024{})); else AQG_TRY(by_nacc(std::true_type{}, std::false_type{}, B1024{})); }
+        else if (big_lds) { if (k32) AQG_TRY(by_nacc(std::true_type{}, std::true_type{}, B512{})); else AQG_TRY(by_nacc(std::true_type{}, std::false_type{}, B512{})); }
+        else if (use_lds) { if (k32) AQG_TRY(by_nacc(std::true_type{}, std::true_type{}, B256{})); else AQG_TRY(by_nacc(std::true_type{}, std::false_type{}, B256{})); }
+        else { if (k32) AQG_TRY(by_nacc(std::false_type{}, std::true_type{}, B256{})); else AQG_TRY(by_nacc(std::false_type{}, std::false_type{}, B256{})); }
         aqg_kernel_timer_end(ctx);
         AQG_TRY(aqg_check_launch(ctx, "agg_kernel"));
     }
@@ -896,7 +928,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (fl[0]) return AQG_ERR_OVERFLOW;
     uint32_t G = fl[1];
     if (small_rank && G > 4096) return AQG_ERR_OVERFLOW;
-    if (use_lds && G > 3072 && G > hint) return AQG_ERR_OVERFLOW;   // correct but slow: re-plan in HBM mode
+    if (use_lds && G > lds_group_cap && G > hint) return AQG_ERR_OVERFLOW;   // correct but slow (overflow rows took the HBM path): re-plan
     if (G && n && fast) {
         unsigned fgrid = aqg_grid(ctx, n / 16 + 1, 256, 1, 1);
         hipLaunchKernelGGL(first_rows_kernel, dim3(fgrid), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(ks.col[0]), n, gt, (const uint32_t*)occ);

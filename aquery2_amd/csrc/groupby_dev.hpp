@@ -49,6 +49,15 @@ __host__ __device__ inline int aqg_dtype_size_dev(int dt) {
 __device__ inline uint32_t hash32(uint32_t k) { return (k * 0x9E3779B1u) ^ (k >> 15); }
 __device__ inline uint32_t hash64(uint64_t k) { k *= 0x9E3779B97F4A7C15ull; return (uint32_t)(k >> 32) ^ (uint32_t)k; }
 
+// LDS-table hashing in 32-bit multiplies only (the row loop is VALU-bound: a 64-bit multiply costs four quarter-rate ones).
+// h1's top bits pick the pass, a second mix of h1 picks the slot, so the two are independent.
+template <bool K32> __device__ inline uint32_t lds_h1(uint64_t key) {
+    uint32_t k = (uint32_t)key;
+    if constexpr (!K32) k ^= (uint32_t)(key >> 32) * 0x85EBCA6Bu;
+    return k * 0x9E3779B1u;
+}
+__device__ inline uint32_t lds_h2(uint32_t h1) { return (h1 ^ (h1 >> 15)) * 0x2C1B3C6Du; }
+
 // order-preserving maps into uint64 so that MIN/MAX of every class are unsigned integer atomics
 __device__ inline uint64_t map_i(int64_t v) { return (uint64_t)v ^ 0x8000000000000000ull; }
 __device__ inline int64_t unmap_i(uint64_t u) { return (int64_t)(u ^ 0x8000000000000000ull); }
@@ -76,6 +85,30 @@ __device__ inline uint64_t pack_key(const KeySpec& ks, size_t i) {
     uint64_t k = load_bits(ks.dt[0], ks.col[0], i);
     for (int j = 1; j < ks.nkeys; ++j) k |= load_bits(ks.dt[j], ks.col[j], i) << ks.shift[j];
     return k;
+}
+
+// four consecutive rows at once: one vector load per key column instead of four scalar ones
+template <class T> __device__ inline void load_bits4_t(const void* col, size_t base, uint64_t (&o)[4]) {
+    pack<T, 4> v = *reinterpret_cast<const pack<T, 4>*>(static_cast<const T*>(col) + base);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = v.v[j];
+}
+__device__ inline void load_bits4(int dt, const void* col, size_t base, uint64_t (&o)[4]) {
+    switch (dt) {
+    case AQG_INT8: case AQG_UINT8: case AQG_BOOL: load_bits4_t<uint8_t>(col, base, o); break;
+    case AQG_INT16: case AQG_UINT16: load_bits4_t<uint16_t>(col, base, o); break;
+    case AQG_INT32: case AQG_UINT32: case AQG_FLOAT: load_bits4_t<uint32_t>(col, base, o); break;
+    default: load_bits4_t<uint64_t>(col, base, o); break;
+    }
+}
+__device__ inline void pack_key4(const KeySpec& ks, size_t base, uint64_t (&key)[4]) {
+    load_bits4(ks.dt[0], ks.col[0], base, key);
+    for (int j = 1; j < ks.nkeys; ++j) {
+        uint64_t b[4];
+        load_bits4(ks.dt[j], ks.col[j], base, b);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) key[r] |= b[r] << ks.shift[j];
+    }
 }
 
 // value of element i as the 64-bit operand of its accumulator

@@ -1,40 +1,84 @@
 // partition.hip -- high-cardinality group-by without global atomics.
 //
-// Scattered device-scope atomics top out near 3e10 per second on MI355X (measured: h2o Q5, 1e9 rows, 1e7 groups:
-// 140-170 ms through the HBM table), so groups that do not fit one workgroup's LDS table are handled by
-// PARTITIONING the rows instead: records {packed key, row id, value columns} are radix-partitioned on hash bits
-// (7 bits per pass, stable scatter with wavefront match-any ranks, runs of >= 128 B per bin and tile) until a
-// partition holds about a thousand groups; each partition is then aggregated in LDS by one workgroup and its
-// groups are appended to a compact record table.  The compact table feeds the same collect / rank / emit
-// kernels as the hash path (first-occurrence order comes from the carried row ids).
-// Traffic for Q5 (16 B/row algorithmic): key count pass 4 + two passes (read 20 + write 24 / read 24 + write 24)
-// + aggregate 24 = ~120 B/row, all streaming.
+// Scattered device-scope atomics top out near 3e10 per second on MI355X (they execute at the memory side; measured: h2o Q5,
+// 1e9 rows, 1e7 groups: 130-140 ms through the HBM table), so groups that do not fit a workgroup's LDS table are handled by
+// PARTITIONING the rows instead: {packed key, row id, value columns} are radix-partitioned on the top bits of a 32-bit key
+// hash (MSD, two levels of <= 8 bits) until a partition holds about a thousand groups; each partition is then aggregated in
+// LDS by one workgroup and its groups are appended to a compact record table.  The compact table feeds the same
+// collect / rank / emit kernels as the hash path (first-occurrence order comes from the carried row ids).
+//
+// What bounds these kernels is memory-level parallelism, not the access pattern: every thread first issues ALL the loads of
+// its rows of a tile (SR independent loads in flight, index clamped instead of branched), and only then ranks / stages them.
+// (Round-1 measurements, 1e9 rows: the same scatter with one load -> use -> next load per round ran 57-66 ms per level;
+// writing to linear instead of scattered positions did not change that, i.e. the scattered 128-byte runs were never the cost.)
 #include "groupby_dev.hpp"
 
 namespace {
 
-constexpr int PB = 256;
-constexpr int PROUNDS = 32;
-constexpr int PT = PB * PROUNDS;   // rows per tile (8192): ~32 rows = 128 B per bin and tile at 256 bins
-constexpr int MAXPAY = MAXACC + 2;
+constexpr int SB = 1024;          // threads per workgroup of the histogram / scatter kernels
+constexpr int SR = 8;             // rows per thread and tile, all loaded before first use
+constexpr int PT = SB * SR;       // rows per tile (8192): ~32 rows = 128 B per bin and tile at 256 bins
+constexpr int MAXPL = 4 + 2 * MAXACC;
 
 struct KeyIn {            // where a pass reads the packed key of row i from
     int from_cols;        // 1: pack from the user's key columns; 0: record array
     KeySpec ks;
     const void* rec;      // record keys
     int ksz;              // 4 or 8 bytes per record key
+    uint32_t pbits;       // partition id = top pbits bits of the key hash
 };
-__device__ inline uint64_t read_key(const KeyIn& k, size_t i) {
-    if (k.from_cols) return pack_key(k.ks, i);
-    return k.ksz == 4 ? (uint64_t) static_cast<const uint32_t*>(k.rec)[i] : static_cast<const uint64_t*>(k.rec)[i];
+__device__ inline uint32_t part_id(uint64_t key, uint32_t pbits) { return lds_h1<false>(key) >> (32 - pbits); }
+
+// keys of this thread's SR rows of the tile [rb, re): row r*SB + tid, index clamped into the tile so every load is issued
+__device__ inline void load_keys(const KeyIn& k, uint32_t rb, uint32_t re, uint64_t (&key)[SR]) {
+    size_t idx[SR];
+#pragma unroll
+    for (int r = 0; r < SR; ++r) { uint32_t j = rb + r * SB + threadIdx.x; idx[r] = j < re ? j : re - 1; }
+    if (!k.from_cols) {
+        if (k.ksz == 4) {
+#pragma unroll
+            for (int r = 0; r < SR; ++r) key[r] = static_cast<const uint32_t*>(k.rec)[idx[r]];
+        } else {
+#pragma unroll
+            for (int r = 0; r < SR; ++r) key[r] = static_cast<const uint64_t*>(k.rec)[idx[r]];
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < SR; ++r) key[r] = 0;
+    for (int c = 0; c < k.ks.nkeys; ++c) {
+        const int sh = c ? k.ks.shift[c] : 0;
+        const void* col = k.ks.col[c];
+        switch (aqg_dtype_size_dev(k.ks.dt[c])) {
+        case 1:
+#pragma unroll
+            for (int r = 0; r < SR; ++r) key[r] |= (uint64_t) static_cast<const uint8_t*>(col)[idx[r]] << sh;
+            break;
+        case 2:
+#pragma unroll
+            for (int r = 0; r < SR; ++r) key[r] |= (uint64_t) static_cast<const uint16_t*>(col)[idx[r]] << sh;
+            break;
+        case 4:
+#pragma unroll
+            for (int r = 0; r < SR; ++r) key[r] |= (uint64_t) static_cast<const uint32_t*>(col)[idx[r]] << sh;
+            break;
+        default:
+#pragma unroll
+            for (int r = 0; r < SR; ++r) key[r] |= static_cast<const uint64_t*>(col)[idx[r]] << sh;
+            break;
+        }
+    }
 }
-struct Payload {          // columns carried along: [0] = key, [1] = row id, [2..] = value columns
-    int ncols;
-    const void* in[MAXPAY];
-    void* out[MAXPAY];
-    int esz[MAXPAY];
+
+// Everything a scatter pass moves is a DWORD PLANE: one 32-bit word per row, read from a source (or made from the key / row
+// index already in registers) and written to a destination at a dword stride.  8-byte columns are two planes.
+enum : int { PL_LOAD = 0, PL_KEYLO = 1, PL_KEYHI = 2, PL_ROWIDX = 3 };
+struct Plane {
+    const unsigned char* src; int src_esz; int src_stride; int src_off;   // PL_LOAD: esz (1, 2, 4) bytes at src + row * stride + off
+    uint32_t* dst; int dst_stride_dw; int dst_off_dw;
+    int kind;
 };
-__device__ inline uint32_t part_hash(uint64_t key) { return hash64(key * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull); }
+struct Planes { int n; Plane p[MAXPL]; };
 
 // ---- MSD partitioning, up to two levels of <= 8 hash bits ---------------------------------------------------------------
 // A level splits every SEGMENT of the current record set (level 1: the whole input = one segment; level 2: each level-1 bin)
@@ -59,94 +103,107 @@ __device__ inline bool tile_range(const Segs& sg, uint32_t t, uint32_t& seg, uin
     return true;
 }
 
-__global__ void __launch_bounds__(PB) part_hist_kernel(KeyIn kin, Segs sg, uint32_t shift, uint32_t bits, uint32_t* __restrict__ hist) {
+__global__ void __launch_bounds__(SB) part_hist_kernel(KeyIn kin, Segs sg, uint32_t shift, uint32_t bits, uint32_t* __restrict__ hist) {
     __shared__ uint32_t h[256];
     const uint32_t nb = 1u << bits;
     uint32_t seg, tin, ntseg, rb, re;
     if (!tile_range(sg, blockIdx.x, seg, tin, ntseg, rb, re)) return;
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t p = rb + threadIdx.x; p < re; p += PB) atomicAdd(&h[(part_hash(read_key(kin, p)) >> shift) & (nb - 1)], 1u);
+    uint64_t key[SR];
+    load_keys(kin, rb, re, key);
+#pragma unroll
+    for (int r = 0; r < SR; ++r)
+        if (rb + r * SB + threadIdx.x < re) atomicAdd(&h[(part_id(key[r], kin.pbits) >> shift) & (nb - 1)], 1u);
     __syncthreads();
     if (threadIdx.x < nb) hist[(size_t)sg.tile_prefix[seg] * nb + (size_t)threadIdx.x * ntseg + tin] = h[threadIdx.x];
 }
 
-// Scatter with LDS-staged, coalesced writes: a tile's rows are ranked inside their bins (returning LDS atomics), laid out
-// bin-major in LDS one column at a time, and streamed out so that consecutive lanes write consecutive addresses of a bin's run
-// (~32 rows = 128 B per bin and tile).  Scattering straight from registers costs 34-68 ms per level at 1e9 rows (partial-line
-// writes); staged it is a streaming copy.
-template <bool FIRST>
-__global__ void __launch_bounds__(PB) part_scatter_kernel(KeyIn kin, Payload pay, Segs sg, uint32_t shift, uint32_t bits, const uint32_t* __restrict__ hist_scanned) {
+// Scatter with LDS-staged, coalesced writes: a tile's rows are ranked inside their bins (returning LDS atomics), each plane is
+// laid out bin-major in LDS and streamed out so that consecutive lanes write consecutive addresses of a bin's run.
+__global__ void __launch_bounds__(SB) part_scatter_kernel(KeyIn kin, Planes pl, Segs sg, uint32_t shift, uint32_t bits, const uint32_t* __restrict__ hist_scanned) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    uint64_t* stage = reinterpret_cast<uint64_t*>(smem_raw);                 // PT slots of 8 bytes
-    uint8_t* binid = reinterpret_cast<uint8_t*>(smem_raw) + (size_t)PT * 8;   // bin of every staged position
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);      // [PT] one plane of the tile, bin-major
+    uint32_t* delta = stage + PT;                                 // [PT] destination row minus staged position
     __shared__ uint32_t gbase[256], cnt[256], lbase[256], wsum[4];
     const uint32_t nb = 1u << bits;
     uint32_t seg, tin, ntseg, rb, re;
     if (!tile_range(sg, blockIdx.x, seg, tin, ntseg, rb, re)) return;
     const uint32_t nrows = re - rb;
-    gbase[threadIdx.x] = threadIdx.x < nb ? hist_scanned[(size_t)sg.tile_prefix[seg] * nb + (size_t)threadIdx.x * ntseg + tin] : 0;
-    cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t pd[PROUNDS];                                                     // (digit << 16) | rank, later (digit << 16) | position
-#pragma unroll
-    for (int r = 0; r < PROUNDS; ++r) {
-        const uint32_t j = r * PB + threadIdx.x;
-        if (j < nrows) {
-            const uint32_t d = (part_hash(read_key(kin, rb + j)) >> shift) & (nb - 1);
-            pd[r] = (d << 16) | atomicAdd(&cnt[d], 1u);
-        }
+    if (threadIdx.x < 256) {
+        gbase[threadIdx.x] = threadIdx.x < nb ? hist_scanned[(size_t)sg.tile_prefix[seg] * nb + (size_t)threadIdx.x * ntseg + tin] : 0;
+        cnt[threadIdx.x] = 0;
     }
     __syncthreads();
-    {   // exclusive scan of the 256 bin counts
-        const uint32_t c = cnt[threadIdx.x];
-        const uint32_t incl = wave_scan_incl(c, OpAdd{}, lane_id());
+    uint64_t key[SR];
+    load_keys(kin, rb, re, key);
+    uint32_t pos[SR];                                             // (bin << 16) | rank, later the staged position
+#pragma unroll
+    for (int r = 0; r < SR; ++r) {
+        const uint32_t d = (part_id(key[r], kin.pbits) >> shift) & (nb - 1);
+        pos[r] = r * SB + threadIdx.x < nrows ? (d << 16) | atomicAdd(&cnt[d], 1u) : 0;
+    }
+    __syncthreads();
+    uint32_t c = 0, incl = 0;
+    if (threadIdx.x < 256) {   // exclusive scan of the 256 bin counts by the first four wavefronts
+        c = cnt[threadIdx.x];
+        incl = wave_scan_incl(c, OpAdd{}, lane_id());
         if (lane_id() == 63) wsum[wave_id()] = incl;
-        __syncthreads();
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
         uint32_t base = 0;
         for (int w = 0; w < wave_id(); ++w) base += wsum[w];
         lbase[threadIdx.x] = base + incl - c;
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < PROUNDS; ++r) {
-        const uint32_t j = r * PB + threadIdx.x;
-        if (j < nrows) {
-            const uint32_t d = pd[r] >> 16, pos = lbase[d] + (pd[r] & 0xFFFF);
-            pd[r] = (d << 16) | pos;
-            binid[pos] = (uint8_t)d;
+    for (int r = 0; r < SR; ++r) {
+        if (r * SB + threadIdx.x < nrows) {
+            const uint32_t d = pos[r] >> 16, lb = lbase[d], p = lb + (pos[r] & 0xFFFF);
+            pos[r] = p;
+            delta[p] = gbase[d] - lb;
         }
     }
-    for (int c = 0; c < pay.ncols; ++c) {
-        __syncthreads();
+    for (int ci = 0; ci < pl.n; ++ci) {
+        const Plane& P = pl.p[ci];
+        uint32_t v[SR];
+        if (P.kind == PL_KEYLO) {
 #pragma unroll
-        for (int r = 0; r < PROUNDS; ++r) {
-            const uint32_t j = r * PB + threadIdx.x;
-            if (j < nrows) {
-                const uint32_t p = rb + j;
-                uint64_t v;
-                if (c == 0) v = read_key(kin, p);
-                else if (c == 1) v = FIRST ? (uint64_t)p : (uint64_t) static_cast<const uint32_t*>(pay.in[1])[p];
-                else switch (pay.esz[c]) {
-                    case 1: v = static_cast<const uint8_t*>(pay.in[c])[p]; break;
-                    case 2: v = static_cast<const uint16_t*>(pay.in[c])[p]; break;
-                    case 4: v = static_cast<const uint32_t*>(pay.in[c])[p]; break;
-                    default: v = static_cast<const uint64_t*>(pay.in[c])[p]; break;
-                }
-                stage[pd[r] & 0xFFFF] = v;
+            for (int r = 0; r < SR; ++r) v[r] = (uint32_t)key[r];
+        } else if (P.kind == PL_KEYHI) {
+#pragma unroll
+            for (int r = 0; r < SR; ++r) v[r] = (uint32_t)(key[r] >> 32);
+        } else if (P.kind == PL_ROWIDX) {
+#pragma unroll
+            for (int r = 0; r < SR; ++r) v[r] = rb + r * SB + threadIdx.x;
+        } else {
+            const unsigned char* src = P.src + P.src_off;
+            const size_t st = (size_t)P.src_stride;
+            size_t idx[SR];
+#pragma unroll
+            for (int r = 0; r < SR; ++r) { uint32_t j = r * SB + threadIdx.x; idx[r] = (size_t)rb + (j < nrows ? j : nrows - 1); }
+            if (P.src_esz == 4) {
+#pragma unroll
+                for (int r = 0; r < SR; ++r) v[r] = *reinterpret_cast<const uint32_t*>(src + idx[r] * st);
+            } else if (P.src_esz == 2) {
+#pragma unroll
+                for (int r = 0; r < SR; ++r) v[r] = *reinterpret_cast<const uint16_t*>(src + idx[r] * st);
+            } else {
+#pragma unroll
+                for (int r = 0; r < SR; ++r) v[r] = src[idx[r] * st];
             }
         }
+        __syncthreads();                       // the previous plane has left `stage` (and, first time, `delta` is complete)
+#pragma unroll
+        for (int r = 0; r < SR; ++r) if (r * SB + threadIdx.x < nrows) stage[pos[r]] = v[r];
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < nrows; j += PB) {
-            const uint32_t d = binid[j];
-            const size_t dst = (size_t)gbase[d] + (j - lbase[d]);
-            const uint64_t v = stage[j];
-            switch (pay.esz[c]) {
-            case 1: static_cast<uint8_t*>(pay.out[c])[dst] = (uint8_t)v; break;
-            case 2: static_cast<uint16_t*>(pay.out[c])[dst] = (uint16_t)v; break;
-            case 4: static_cast<uint32_t*>(pay.out[c])[dst] = (uint32_t)v; break;
-            default: static_cast<uint64_t*>(pay.out[c])[dst] = v; break;
-            }
+        uint32_t* dst = P.dst + P.dst_off_dw;
+        const size_t dstride = (size_t)P.dst_stride_dw;
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            const uint32_t j = r * SB + threadIdx.x;
+            if (j < nrows) dst[(size_t)(j + delta[j]) * dstride] = stage[j];
         }
     }
 }
@@ -185,9 +242,29 @@ __global__ void __launch_bounds__(1024) tile_prefix_kernel(const uint32_t* __res
     }
 }
 
+// ---- aggregate each partition in LDS -------------------------------------------------------------------------------------
+constexpr int AB = 512;    // threads per workgroup
+constexpr int AR = 4;      // rows per thread and step, loaded together
+struct AggIn { const void* col[MAXACC]; int esz[MAXACC]; };   // partitioned value arrays (4- or 8-byte elements); null: the row id
+
+__device__ inline uint64_t val_operand_bits(int dt, uint64_t bits, int kind, int square, int part) {
+    switch (dt) {
+    case AQG_INT8: return val_operand_t((int8_t)bits, kind, square);
+    case AQG_INT16: return val_operand_t((int16_t)bits, kind, square);
+    case AQG_INT32: return val_operand_t((int32_t)bits, kind, square);
+    case AQG_INT64: return val_operand_t((int64_t)bits, kind, square, part);
+    case AQG_UINT8: case AQG_BOOL: return val_operand_t((uint8_t)bits, kind, square);
+    case AQG_UINT16: return val_operand_t((uint16_t)bits, kind, square);
+    case AQG_UINT32: return val_operand_t((uint32_t)bits, kind, square);
+    case AQG_UINT64: return val_operand_t((uint64_t)bits, kind, square, part);
+    case AQG_FLOAT: return val_operand_t(__uint_as_float((uint32_t)bits), kind, square);
+    default: return val_operand_t(__builtin_bit_cast(double, bits), kind, square);
+    }
+}
+
 // one workgroup per partition (grid-stride): LDS open addressing {key64, first_row, count, acc...}; groups are appended to `out`
 template <int NACC>
-__global__ void __launch_bounds__(PB) part_agg_kernel(const void* __restrict__ rkeys, int ksz, const uint32_t* __restrict__ rrows, AccSpec as,
+__global__ void __launch_bounds__(AB) part_agg_kernel(const void* __restrict__ rkeys, int ksz, const uint32_t* __restrict__ rrows, AccSpec as, AggIn in,
                                                       const uint32_t* __restrict__ pstart, uint32_t nparts, uint32_t lcap, int need_count,
                                                       GTable out, uint32_t out_cap) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -196,42 +273,97 @@ __global__ void __launch_bounds__(PB) part_agg_kernel(const void* __restrict__ r
     uint64_t* lacc = lkey + LT;
     uint32_t* lfirst = reinterpret_cast<uint32_t*>(lacc + (size_t)NACC * LT);
     uint32_t* lcount = lfirst + LT;
-    __shared__ uint32_t lused;
-    const uint32_t lmask = lcap - 1, llimit = lcap - (lcap >> 3);
+    __shared__ uint32_t lused, lemit, gbase;
+    const uint32_t llimit = lcap - (lcap >> 3);
     for (uint32_t part = blockIdx.x; part < nparts; part += gridDim.x) {
         const uint32_t b = pstart[part], e = pstart[part + 1];
         if (b == e) continue;
-        for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) {
+        for (uint32_t s = threadIdx.x; s < LT; s += AB) {
             lkey[s] = EMPTY64; lfirst[s] = NOROW; lcount[s] = 0;
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) lacc[(size_t)a * LT + s] = acc_init(as.kind[a]);
         }
-        if (threadIdx.x == 0) lused = 0;
+        if (threadIdx.x == 0) { lused = 0; lemit = 0; }
         __syncthreads();
-        for (uint32_t i = b + threadIdx.x; i < e; i += blockDim.x) {
-            const uint64_t key = ksz == 4 ? (uint64_t) static_cast<const uint32_t*>(rkeys)[i] : static_cast<const uint64_t*>(rkeys)[i];
-            uint32_t s = hash64(key) & lmask, found = FAIL;
-            if (key == EMPTY64) found = lcap;
-            else for (uint32_t p = 0; p <= lmask; ++p) {
-                uint64_t cur = lkey[s];
-                if (cur == key) { found = s; break; }
-                if (cur == EMPTY64) {
-                    if (lused >= llimit) break;
-                    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&lkey[s]), EMPTY64, key);
-                    if (old == EMPTY64) { atomicAdd(&lused, 1u); found = s; break; }
-                    if (old == key) { found = s; break; }
-                }
-                s = (s + 1) & lmask;
+        for (uint32_t i0 = b; i0 < e; i0 += AB * AR) {
+            size_t idx[AR];
+            bool live[AR];
+#pragma unroll
+            for (int q = 0; q < AR; ++q) { uint32_t i = i0 + q * AB + threadIdx.x; live[q] = i < e; idx[q] = live[q] ? i : e - 1; }
+            uint64_t key[AR], vb[NACC ? NACC : 1][AR];
+            uint32_t row[AR];
+            if (ksz == 4) {
+#pragma unroll
+                for (int q = 0; q < AR; ++q) key[q] = static_cast<const uint32_t*>(rkeys)[idx[q]];
+            } else {
+#pragma unroll
+                for (int q = 0; q < AR; ++q) key[q] = static_cast<const uint64_t*>(rkeys)[idx[q]];
             }
-            if (found == FAIL) { out.flags[0] = 1; continue; }      // partition holds more groups than the table: the host re-plans
-            atomicMin(&lfirst[found], rrows[i]);
-            if (need_count) atomicAdd(&lcount[found], 1u);
-            _Pragma("unroll") for (int a = 0; a < NACC; ++a)
-                acc_apply(&lacc[(size_t)a * LT + found], as.kind[a], val_operand(as.dt[a], as.col[a], i, as.kind[a], as.square[a], as.part[a]));
+#pragma unroll
+            for (int q = 0; q < AR; ++q) row[q] = rrows[idx[q]];
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                if (!in.col[a]) {
+#pragma unroll
+                    for (int q = 0; q < AR; ++q) vb[a][q] = row[q];
+                } else if (in.esz[a] == 4) {
+#pragma unroll
+                    for (int q = 0; q < AR; ++q) vb[a][q] = static_cast<const uint32_t*>(in.col[a])[idx[q]];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < AR; ++q) vb[a][q] = static_cast<const uint64_t*>(in.col[a])[idx[q]];
+                }
+            }
+            uint32_t slot[AR];
+            uint64_t w[AR];
+#pragma unroll
+            for (int q = 0; q < AR; ++q) { slot[q] = __umulhi(lds_h2(lds_h1<false>(key[q])), lcap); w[q] = lkey[slot[q]]; }   // AR probes in flight
+            // rows that missed on their first probe walk their probe sequences TOGETHER: one round trip to LDS per step for
+            // all of a lane's pending rows (a wavefront stays in this loop for its longest sequence, not for the sum of them)
+            uint32_t pend = 0;
+#pragma unroll
+            for (int q = 0; q < AR; ++q) {
+                if (!live[q]) slot[q] = FAIL;
+                else if (key[q] == EMPTY64) slot[q] = lcap;
+                else if (w[q] != key[q]) pend |= 1u << q;
+            }
+            for (uint32_t step = 0; pend && step <= lcap; ++step) {
+#pragma unroll
+                for (int q = 0; q < AR; ++q) {
+                    if (!(pend & (1u << q))) continue;
+                    uint64_t cur = w[q];
+                    if (cur == EMPTY64) {
+                        if (lused >= llimit) { slot[q] = FAIL; pend &= ~(1u << q); out.flags[0] = 1; continue; }   // the host re-plans
+                        cur = atomicCAS(reinterpret_cast<unsigned long long*>(&lkey[slot[q]]), EMPTY64, key[q]);
+                        if (cur == EMPTY64) { atomicAdd(&lused, 1u); cur = key[q]; }
+                    }
+                    if (cur == key[q]) { pend &= ~(1u << q); continue; }
+                    slot[q] = slot[q] + 1 == lcap ? 0 : slot[q] + 1;
+                }
+#pragma unroll
+                for (int q = 0; q < AR; ++q) if (pend & (1u << q)) w[q] = lkey[slot[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < AR; ++q) if (pend & (1u << q)) { slot[q] = FAIL; out.flags[0] = 1; }
+#pragma unroll
+            for (int q = 0; q < AR; ++q) if (slot[q] != FAIL && row[q] < lfirst[slot[q]]) atomicMin(&lfirst[slot[q]], row[q]);
+            if (need_count) {
+#pragma unroll
+                for (int q = 0; q < AR; ++q) if (slot[q] != FAIL) atomicAdd(&lcount[slot[q]], 1u);
+            }
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+#pragma unroll
+                for (int q = 0; q < AR; ++q)
+                    if (slot[q] != FAIL) acc_apply(&lacc[(size_t)a * LT + slot[q]], as.kind[a], val_operand_bits(as.dt[a] == AQG_NONE ? AQG_UINT32 : as.dt[a], vb[a][q], as.kind[a], as.square[a], as.part[a]));
+            }
         }
         __syncthreads();
-        for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) {
+        if (threadIdx.x == 0) {
+            const uint32_t used = lused + (lfirst[lcap] != NOROW ? 1u : 0u);
+            gbase = atomicAdd(&out.flags[1], used);
+        }
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s < LT; s += AB) {
             if (lfirst[s] == NOROW) continue;
-            uint32_t g = atomicAdd(&out.flags[1], 1u);
+            uint32_t g = gbase + atomicAdd(&lemit, 1u);
             if (g >= out_cap) { out.flags[0] = 1; continue; }
             *out.key_p(g) = lkey[s];
             *out.first_p(g) = lfirst[s];
@@ -242,21 +374,19 @@ __global__ void __launch_bounds__(PB) part_agg_kernel(const void* __restrict__ r
     }
 }
 
-__global__ void __launch_bounds__(256) iota_kernel(uint32_t* __restrict__ p, uint32_t n) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = i;
-}
-
 } // namespace
 
 // Partitioned aggregation of (ks, as) over n rows into the compact record table `out` (AoS records, `out_cap` slots,
 // flags[1] = number of groups written, flags[0] = overflow).  Needs packed (<= 8 byte) keys.
 // Workspace is taken from the context arena (caller has reset it and reserved `aqg_partition_ws_bytes`).
+static size_t part_val_bytes(int dt) { return aqg_dtype_size(dt) <= 4 ? 4 : 8; }   // narrow values travel widened to one dword
+
 size_t aqg_partition_ws_bytes(uint32_t n, int ksz, const AccSpec& as, uint32_t pbits) {
     size_t per_row = (size_t)ksz + 4;
     for (int a = 0; a < as.nacc; ++a) {
         bool dup = false;
         for (int b = 0; b < a; ++b) dup |= as.col[b] == as.col[a];
-        if (!dup && as.dt[a] != AQG_NONE) per_row += aqg_dtype_size(as.dt[a]);
+        if (!dup && as.dt[a] != AQG_NONE) per_row += part_val_bytes(as.dt[a]);
     }
     const size_t max_tiles = (size_t)n / PT + 258;
     return 2 * ((size_t)n + 64) * per_row + max_tiles * 256 * 4 + (max_tiles * 256 / 2048 + 64) * 4 + ((size_t)(1u << pbits) + 600) * 16 + 65536;
@@ -264,11 +394,11 @@ size_t aqg_partition_ws_bytes(uint32_t n, int ksz, const AccSpec& as, uint32_t p
 
 int aqg_partition_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as_in, uint32_t n, uint32_t pbits, uint32_t lcap, int need_count,
                             GTable out, uint32_t out_cap) {
-    if (pbits > 16) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "partitioned group-by: more than 65536 partitions needed");
+    if (pbits > 16 || pbits < 1) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "partitioned group-by: 2..65536 partitions");
     const int ksz = ks.total_bytes <= 4 ? 4 : 8;
     const uint32_t nparts = 1u << pbits;
-    const uint32_t bits1 = pbits > 8 ? pbits - 8 : pbits;     // level 1: the high bits of the partition id
-    const uint32_t bits2 = pbits - bits1;                     // level 2: up to 8 more
+    const uint32_t bits1 = pbits > 8 ? (pbits + 1) / 2 : pbits;   // level 1: the high bits of the partition id
+    const uint32_t bits2 = pbits - bits1;                         // level 2: the rest
     const size_t max_tiles = (size_t)n / PT + 258;
 
     AccSpec as = as_in;
@@ -280,11 +410,11 @@ int aqg_partition_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as_i
         for (int u = 0; u < ucols; ++u) if (ucol[u] == as.col[a]) acc_ucol[a] = u;
         if (acc_ucol[a] < 0) { ucol[ucols] = as.col[a]; udt[ucols] = as.dt[a]; acc_ucol[a] = ucols++; }
     }
-    void* bufs[2][MAXPAY];
+    void* bufs[2][2 + MAXACC];
     for (int set = 0; set < 2; ++set) {
         AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * ksz, &bufs[set][0]));
         AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * 4, &bufs[set][1]));
-        for (int u = 0; u < ucols; ++u) AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * aqg_dtype_size(udt[u]), &bufs[set][2 + u]));
+        for (int u = 0; u < ucols; ++u) AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * part_val_bytes(udt[u]), &bufs[set][2 + u]));
     }
     uint32_t *hist, *bsum, *seg0, *tp0, *seg1, *tp1, *pstart;
     AQG_TRY(aqg_ws_get(ctx, max_tiles * 256, &hist));
@@ -304,31 +434,41 @@ int aqg_partition_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as_i
     hipLaunchKernelGGL(tile_prefix_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)seg0, 1u, tp0);
 
     KeyIn kin;
-    kin.from_cols = 1; kin.ks = ks; kin.rec = nullptr; kin.ksz = ksz;
-    auto payload = [&](int src, int dst) {
-        Payload pay;
-        pay.ncols = 2 + ucols;
-        pay.esz[0] = ksz; pay.esz[1] = 4;
-        pay.in[0] = src < 0 ? nullptr : bufs[src][0]; pay.in[1] = src < 0 ? nullptr : bufs[src][1];
-        pay.out[0] = bufs[dst][0]; pay.out[1] = bufs[dst][1];
+    kin.from_cols = 1; kin.ks = ks; kin.rec = nullptr; kin.ksz = ksz; kin.pbits = pbits;
+    // planes of a pass: key (from registers), row id, then every distinct value column; src < 0: the user's columns
+    auto planes = [&](int src, int dst) {
+        Planes pl;
+        memset(&pl, 0, sizeof pl);
+        auto add = [&](int kind, const void* s, int esz, int stride, int off, void* d, int dstride, int doff) {
+            Plane& P = pl.p[pl.n++];
+            P.kind = kind; P.src = static_cast<const unsigned char*>(s); P.src_esz = esz; P.src_stride = stride; P.src_off = off;
+            P.dst = static_cast<uint32_t*>(d); P.dst_stride_dw = dstride; P.dst_off_dw = doff;
+        };
+        if (ksz == 4) add(PL_KEYLO, nullptr, 0, 0, 0, bufs[dst][0], 1, 0);
+        else { add(PL_KEYLO, nullptr, 0, 0, 0, bufs[dst][0], 2, 0); add(PL_KEYHI, nullptr, 0, 0, 0, bufs[dst][0], 2, 1); }
+        if (src < 0) add(PL_ROWIDX, nullptr, 0, 0, 0, bufs[dst][1], 1, 0);
+        else add(PL_LOAD, bufs[src][1], 4, 4, 0, bufs[dst][1], 1, 0);
         for (int u = 0; u < ucols; ++u) {
-            pay.esz[2 + u] = (int)aqg_dtype_size(udt[u]);
-            pay.in[2 + u] = src < 0 ? ucol[u] : bufs[src][2 + u];
-            pay.out[2 + u] = bufs[dst][2 + u];
+            const int usz = (int)aqg_dtype_size(udt[u]);                 // element size in the user's column
+            const int psz = (int)part_val_bytes(udt[u]);                 // element size in the partition buffers
+            const void* s = src < 0 ? ucol[u] : bufs[src][2 + u];
+            const int ssz = src < 0 ? usz : psz;
+            if (psz == 4) add(PL_LOAD, s, ssz < 4 ? ssz : 4, ssz, 0, bufs[dst][2 + u], 1, 0);
+            else { add(PL_LOAD, s, 4, 8, 0, bufs[dst][2 + u], 2, 0); add(PL_LOAD, s, 4, 8, 4, bufs[dst][2 + u], 2, 1); }
         }
-        return pay;
+        return pl;
     };
     const unsigned grid_tiles = (unsigned)max_tiles;
-    const size_t scatter_lds = (size_t)PT * 9;   // 8-byte stage slot + 1-byte bin id per row of a tile
+    const size_t scatter_lds = (size_t)PT * 8;   // stage + delta
+    AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&part_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds));
     // ---- level 1 -------------------------------------------------------------------------------------------------------
     Segs sg0{seg0, tp0, 1u};
     {
         const uint32_t shift = bits2;                        // high bits first
         const uint64_t hcount = ((uint64_t)n / PT + 2) * (1u << bits1);
-        hipLaunchKernelGGL(part_hist_kernel, dim3(grid_tiles), dim3(PB), 0, ctx->stream, kin, sg0, shift, bits1, hist);
+        hipLaunchKernelGGL(part_hist_kernel, dim3(grid_tiles), dim3(SB), 0, ctx->stream, kin, sg0, shift, bits1, hist);
         AQG_TRY(aqg_exclusive_scan_u32(ctx, hist, hcount, bsum));
-        AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&part_scatter_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds));
-        hipLaunchKernelGGL((part_scatter_kernel<true>), dim3(grid_tiles), dim3(PB), scatter_lds, ctx->stream, kin, payload(-1, 0), sg0, shift, bits1, (const uint32_t*)hist);
+        hipLaunchKernelGGL(part_scatter_kernel, dim3(grid_tiles), dim3(SB), scatter_lds, ctx->stream, kin, planes(-1, 0), sg0, shift, bits1, (const uint32_t*)hist);
         uint32_t* dst_start = bits2 ? seg1 : pstart;
         hipLaunchKernelGGL(bins_to_segments_kernel, dim3(1), dim3(256), 0, ctx->stream, sg0, bits1, (const uint32_t*)hist, n, dst_start);
         AQG_TRY(aqg_check_launch(ctx, "partition level 1"));
@@ -342,23 +482,27 @@ int aqg_partition_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as_i
         kin.from_cols = 0; kin.rec = bufs[0][0];
         const uint64_t hcount = (uint64_t)max_tiles * (1u << bits2);
         AQG_HIP(ctx, hipMemsetAsync(hist, 0, hcount * 4, ctx->stream));   // unused tail tiles must read as zero in the scan
-        hipLaunchKernelGGL(part_hist_kernel, dim3(grid_tiles), dim3(PB), 0, ctx->stream, kin, sg1, 0u, bits2, hist);
+        hipLaunchKernelGGL(part_hist_kernel, dim3(grid_tiles), dim3(SB), 0, ctx->stream, kin, sg1, 0u, bits2, hist);
         AQG_TRY(aqg_exclusive_scan_u32(ctx, hist, hcount, bsum));
-        AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&part_scatter_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scatter_lds));
-        hipLaunchKernelGGL((part_scatter_kernel<false>), dim3(grid_tiles), dim3(PB), scatter_lds, ctx->stream, kin, payload(0, 1), sg1, 0u, bits2, (const uint32_t*)hist);
+        hipLaunchKernelGGL(part_scatter_kernel, dim3(grid_tiles), dim3(SB), scatter_lds, ctx->stream, kin, planes(0, 1), sg1, 0u, bits2, (const uint32_t*)hist);
         hipLaunchKernelGGL(bins_to_segments_kernel, dim3(aqg_grid(ctx, nparts, 256, 1, 4)), dim3(256), 0, ctx->stream, sg1, bits2, (const uint32_t*)hist, n, pstart);
         AQG_TRY(aqg_check_launch(ctx, "partition level 2"));
         cur = 1;
     }
     // ---- aggregate each partition in LDS -------------------------------------------------------------------------------
-    for (int a = 0; a < as.nacc; ++a) if (acc_ucol[a] >= 0) as.col[a] = bufs[cur][2 + acc_ucol[a]];
-    for (int a = 0; a < as.nacc; ++a) if (as.dt[a] == AQG_NONE) { as.dt[a] = AQG_UINT32; as.col[a] = bufs[cur][1]; }   // row-index operands
+    AggIn in;
+    memset(&in, 0, sizeof in);
+    for (int a = 0; a < as.nacc; ++a) {
+        if (acc_ucol[a] >= 0) { in.col[a] = bufs[cur][2 + acc_ucol[a]]; in.esz[a] = (int)part_val_bytes(udt[acc_ucol[a]]); }
+        else { in.col[a] = nullptr; in.esz[a] = 4; }     // row-index operands: the carried row id
+    }
     const size_t lds = ((size_t)lcap + 1) * (8 + 8 * (size_t)as.nacc + 4 + 4);
-    unsigned grid = nparts < (unsigned)ctx->num_cu * 4 ? nparts : (unsigned)ctx->num_cu * 4;
+    const unsigned per_cu = lds <= 48 * 1024 ? 3 : lds <= 76 * 1024 ? 2 : 1;
+    unsigned grid = nparts < (unsigned)ctx->num_cu * per_cu ? nparts : (unsigned)ctx->num_cu * per_cu;
     auto launch = [&](auto kern) -> int {
         AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         aqg_kernel_timer_begin(ctx);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(PB), lds, ctx->stream, (const void*)bufs[cur][0], ksz, (const uint32_t*)bufs[cur][1], as, (const uint32_t*)pstart, nparts,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(AB), lds, ctx->stream, (const void*)bufs[cur][0], ksz, (const uint32_t*)bufs[cur][1], as, in, (const uint32_t*)pstart, nparts,
                            lcap, need_count, out, out_cap);
         aqg_kernel_timer_end(ctx);
         return aqg_check_launch(ctx, "part_agg_kernel");

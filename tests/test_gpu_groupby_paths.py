@@ -1,0 +1,97 @@
+"""GPU parity for the group-by paths that only large inputs reach (n >= 2^20 rows):
+  * the big LDS table with several passes over the rows (a few thousand to ~25,000 groups; agg_kernel<BLOCK = 512 / 1024>)
+  * the partition pipeline (more groups than that; partition.hip): 4- and 8-byte packed keys, the all-ones key, 1/2/4/8-byte
+    values, row-index operands (FIRST / LAST through aqg_grouped_reduce)
+against the oracle's first-occurrence group order, keys, first rows, counts and every aggregate."""
+import numpy as np
+import pytest
+
+import checker as ck
+import golden_util as gu
+from test_gpu_basic import check_agg, rand
+
+pytestmark = pytest.mark.gpu
+N = 1_300_003
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import aquery2_amd
+    d = aquery2_amd.Device(0)
+    yield d
+    d.close()
+
+
+def vals_of(rng, n):
+    return [rand(rng, np.int32, n, small=True), np.round(rng.uniform(0, 100, n), 6).astype(np.float32), rand(rng, np.int16, n), rand(rng, np.float64, n)]
+
+
+@pytest.mark.parametrize("hint", [0, 10000, 20000])
+def test_big_lds_table_multipass(gpu, oracle, hint):
+    rng = np.random.default_rng(21 + hint)
+    keys = [rng.integers(0, 100, N).astype(np.int32), rng.integers(0, 100, N).astype(np.int32)]
+    check_agg(gpu, oracle, keys, vals_of(rng, N), hint)
+
+
+def test_big_lds_table_few_accumulators(gpu, oracle):
+    """1 and 2 accumulators take the 1024-thread instantiation; one 4-byte key takes the K32 slot layout"""
+    rng = np.random.default_rng(22)
+    for keys in ([rng.integers(0, 9000, N).astype(np.int32)], [rng.integers(0, 90, N).astype(np.int16), rng.integers(0, 90, N).astype(np.int32)]):
+        o = oracle.groupby(keys)
+        v = rand(rng, np.int32, N, small=True)
+        w = rand(rng, np.float64, N)
+        for ops, vs in (([ck.RED_SUM], [v]), ([ck.RED_SUM, ck.RED_MIN], [v, w]), ([ck.RED_COUNT], [v])):
+            gb = gpu.groupby_agg(keys, ops, vs, hint=9000)
+            assert gb.ngroups == o["ngroups"]
+            assert np.array_equal(gb.first_rows(), o["first_rows"])
+            for j, (op, x) in enumerate(zip(ops, vs)):
+                assert gu.same_bits(gb.result(j, op, ck.tag_of(x)), oracle.grouped_reduce(op, x, o)), (op, x.dtype)
+            gb.destroy()
+
+
+@pytest.mark.parametrize("card", [60_000, 400_000])
+def test_partition_path_one_key(gpu, oracle, card):
+    rng = np.random.default_rng(card)
+    keys = [rng.integers(-card // 2, card // 2, N).astype(np.int32)]
+    check_agg(gpu, oracle, keys, vals_of(rng, N), card)
+
+
+def test_partition_path_wide_keys_and_sentinels(gpu, oracle):
+    rng = np.random.default_rng(5)
+    k64 = (rng.integers(0, 150_000, N).astype(np.int64) << 21) - 1          # includes -1: the packed key equal to the empty mark
+    assert (k64 == -1).any()
+    v = [rand(rng, np.int32, N, small=True), rng.integers(0, 255, N).astype(np.uint8)]
+    check_agg(gpu, oracle, [k64], v, 200_000)
+    k2 = [rng.integers(0, 700, N).astype(np.int32), rng.integers(-300, 300, N).astype(np.int32)]
+    check_agg(gpu, oracle, k2, v, 500_000)
+    # 8-byte values: sums keep two 64-bit accumulators (low / high halves), so fewer aggregates fit one call
+    x = rand(rng, np.int64, N)
+    o = oracle.groupby(k2)
+    ops = [ck.RED_SUM, ck.RED_MIN, ck.RED_MAX, ck.RED_AVG]
+    gb = gpu.groupby_agg(k2, ops, [x] * 4, hint=500_000)
+    assert gb.ngroups == o["ngroups"] and np.array_equal(gb.first_rows(), o["first_rows"])
+    for j, op in enumerate(ops):
+        assert gu.same_bits(gb.result(j, op, ck.INT64), oracle.grouped_reduce(op, x, o)), op
+    gb.destroy()
+    k3 = [rng.integers(0, 300, N).astype(np.int16), rng.integers(0, 200, N).astype(np.uint8), rng.integers(0, 2, N).astype(np.int32)]
+    check_agg(gpu, oracle, k3, v[:1], 150_000)
+
+
+def test_partition_path_retries_from_a_small_hint(gpu, oracle):
+    rng = np.random.default_rng(6)
+    keys = [rng.integers(0, 250_000, N).astype(np.int32)]
+    check_agg(gpu, oracle, keys, [rand(rng, np.int32, N, small=True)], 0)
+
+
+def test_grouped_reduce_first_last_high_cardinality(gpu, oracle):
+    """FIRST / LAST = arg-min / arg-max of the row id, which the partition pipeline carries with every record"""
+    rng = np.random.default_rng(8)
+    keys = [rng.integers(0, 180_000, N).astype(np.int32)]
+    x = rand(rng, np.int32, N)
+    o = oracle.groupby(keys)
+    g = gpu.groupby_build(keys)
+    assert g.ngroups == o["ngroups"]
+    assert np.array_equal(g.reversemap(), o["reversemap"])
+    for op in (ck.RED_FIRST, ck.RED_LAST, ck.RED_SUM, ck.RED_MAX):
+        assert gu.same_bits(gpu.grouped_reduce(g, op, x), oracle.grouped_reduce(op, x, o)), op
+    g.destroy()
