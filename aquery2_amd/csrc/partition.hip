@@ -265,7 +265,7 @@ __device__ inline uint64_t val_operand_bits(int dt, uint64_t bits, int kind, int
 // one workgroup per partition (grid-stride): LDS open addressing {key64, first_row, count, acc...}; groups are appended to `out`
 template <int NACC>
 __global__ void __launch_bounds__(AB) part_agg_kernel(const void* __restrict__ rkeys, int ksz, const uint32_t* __restrict__ rrows, AccSpec as, AggIn in,
-                                                      const uint32_t* __restrict__ pstart, uint32_t nparts, uint32_t lcap, int need_count,
+                                                      const uint32_t* __restrict__ pstart, uint32_t nparts, uint32_t pbits, uint32_t lcap, int need_count,
                                                       GTable out, uint32_t out_cap) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const uint32_t LT = lcap + 1;                 // slot lcap: the group whose packed key equals the empty mark
@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(AB) part_agg_kernel(const void* __restrict__ r
             uint32_t slot[AR];
             uint64_t w[AR];
 #pragma unroll
-            for (int q = 0; q < AR; ++q) { slot[q] = __umulhi(lds_h2(lds_h1<false>(key[q])), lcap); w[q] = lkey[slot[q]]; }   // AR probes in flight
+            for (int q = 0; q < AR; ++q) { slot[q] = __umulhi(lds_h1<false>(key[q]) << pbits, lcap); w[q] = lkey[slot[q]]; }   // AR probes in flight; slot = hash bits below the partition id
             // rows that missed on their first probe walk their probe sequences TOGETHER: one round trip to LDS per step for
             // all of a lane's pending rows (a wavefront stays in this loop for its longest sequence, not for the sum of them)
             uint32_t pend = 0;
@@ -503,7 +503,7 @@ int aqg_partition_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as_i
         AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         aqg_kernel_timer_begin(ctx);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(AB), lds, ctx->stream, (const void*)bufs[cur][0], ksz, (const uint32_t*)bufs[cur][1], as, in, (const uint32_t*)pstart, nparts,
-                           lcap, need_count, out, out_cap);
+                           pbits, lcap, need_count, out, out_cap);
         aqg_kernel_timer_end(ctx);
         return aqg_check_launch(ctx, "part_agg_kernel");
     };
