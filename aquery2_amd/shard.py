@@ -17,19 +17,26 @@ def shard_rows(n_total, world, rank):
     return lo, hi
 
 
-def gather_group_tables(dist, cols, ngroups):
+def gather_group_tables(dist, cols, ngroups, gmax=None):
     """all_gather the first `ngroups` rows of each 1-D int64 tensor in `cols` from every rank and return the
-    rank-ordered concatenations (padding removed).  Two collectives: the sizes, then one packed payload."""
+    rank-ordered concatenations (padding removed).
+    gmax given (an upper bound of every rank's group count, e.g. the group-by hint): ONE collective -- the payload's
+    first row carries the count.  Otherwise the sizes are exchanged first (two collectives)."""
     world = dist.get_world_size()
     dev = cols[0].device
-    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(sizes, torch.tensor([ngroups], dtype=torch.int64, device=dev))
-    sizes = sizes.tolist()
-    gmax = max(max(sizes), 1)
-    pack = torch.zeros(gmax, len(cols), dtype=torch.int64, device=dev)
+    if gmax is None:
+        sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(sizes, torch.tensor([ngroups], dtype=torch.int64, device=dev))
+        gmax = max(int(sizes.max().item()), 1)
+    if ngroups > gmax:
+        raise ValueError(f"gather_group_tables: {ngroups} groups exceed gmax={gmax}")
+    pack = torch.zeros(gmax + 1, len(cols), dtype=torch.int64, device=dev)
+    pack[0, 0] = ngroups
     for j, c in enumerate(cols):
-        pack[:ngroups, j] = c[:ngroups]
-    allp = torch.zeros(world * gmax, len(cols), dtype=torch.int64, device=dev)
+        pack[1:ngroups + 1, j] = c[:ngroups]
+    allp = torch.zeros(world * (gmax + 1), len(cols), dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(allp, pack)
-    rows = torch.cat([allp[r * gmax: r * gmax + sizes[r]] for r in range(world)])
+    allp = allp.view(world, gmax + 1, len(cols))
+    sizes = allp[:, 0, 0].tolist()
+    rows = torch.cat([allp[r, 1:1 + sizes[r]] for r in range(world)])
     return [rows[:, j].contiguous() for j in range(len(cols))]

@@ -14,6 +14,7 @@ kernel) and, on rank 0 at N=1, `cpu_baseline` (the reference's own headers, or t
 on a bounded sample of the same workload on the host cores).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -68,21 +69,30 @@ def main():
     from aquery2_amd import shard
     import checker as ck
 
+    # AQG_BENCH_REHEARSAL=1: every rank on GPU 0 and the exchange over gloo -- a way to run the N>1 code path on a one-GPU
+    # box (RCCL refuses two ranks on one device).  Never set by the driver; the numbers of such a run mean nothing.
+    rehearsal = world > 1 and os.environ.get("AQG_BENCH_REHEARSAL") == "1"
+    gpu = 0 if rehearsal else local_rank
+    xdev = "cpu" if rehearsal else "cuda"       # where the exchanged tensors live
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(gpu)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+    torch.cuda.set_device(gpu)
 
     # the library runs on torch's current stream so that torch.cuda.synchronize / RCCL order with it
     stream = torch.cuda.current_stream().cuda_stream
-    dev = aquery2_amd.Device(local_rank, stream=stream)
+    dev = aquery2_amd.Device(gpu, stream=stream)
     id1 = dev.gen_column(ck.GEN_ID1, 42, rank * n, n, n_total, 100)
     v1 = dev.gen_column(ck.GEN_V1, 42, rank * n, n, n_total, 100)
     dev.sync()
 
     state = {"gb": None, "merged": None}
+    GMAX = 128                     # the group-by hint: upper bound of a shard's group count (h2o K=100)
     kernel_ms = []
 
     def step(record):
@@ -95,13 +105,13 @@ def main():
             # shards are contiguous row ranges in rank order, so first occurrence in the concatenation
             # is the global first occurrence
             G = gb.ngroups
-            kbuf = dev.empty(G, np.int32)
-            dev._chk(dev.lib.aqg_groupby_keys(gb.h, 0, kbuf.ptr), "aqg_groupby_keys")
-            keys_t = torch.as_tensor(kbuf, device="cuda").to(torch.int64)
+            kbuf = state.setdefault("kbuf", dev.empty(GMAX, np.int32))
+            dev._chk(dev.lib.aqg_groupby_keys(gb.h, 0, ctypes.c_void_p(kbuf.ptr)), "aqg_groupby_keys")
+            keys_t = torch.as_tensor(kbuf, device="cuda")[:G].to(torch.int64)
             sums = aquery2_amd.DevBuf(dev, dev.lib.aqg_groupby_agg_result(gb.h, 0), ck.I128, G, owned=False)
-            sums_lo = torch.as_tensor(sums, device="cuda").reshape(G, 2)[:, 0].contiguous()   # partial sums fit 63 bits
-            mk, ms = shard.gather_group_tables(dist, [keys_t, sums_lo], G)
-            mk = mk.to(torch.int32).contiguous()
+            sums_lo = torch.as_tensor(sums, device="cuda").reshape(G, 2)[:, 0]   # partial sums fit 63 bits
+            mk, ms = shard.gather_group_tables(dist, [keys_t.to(xdev), sums_lo.to(xdev)], G, gmax=GMAX)
+            mk, ms = mk.to("cuda").to(torch.int32).contiguous(), ms.to("cuda").contiguous()
             kd = aquery2_amd.DevBuf(dev, mk.data_ptr(), np.int32, mk.numel(), owned=False)
             sd = aquery2_amd.DevBuf(dev, ms.data_ptr(), np.int64, ms.numel(), owned=False)
             state["merged"] = dev.groupby_agg([kd], [ck.RED_SUM], [sd], hint=128, handle=state["merged"])
@@ -122,7 +132,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -131,7 +141,7 @@ def main():
     total = sum(ck.i128_to_int(final.result(0, ck.RED_SUM, ck.INT64 if world > 1 else ck.INT32)))
     local_sum = int(dev.reduce(ck.RED_SUM, v1))
     if world > 1:
-        t = torch.tensor([local_sum], dtype=torch.int64, device="cuda")
+        t = torch.tensor([local_sum], dtype=torch.int64, device=xdev)
         dist.all_reduce(t)
         local_sum = int(t.item())
     assert total == local_sum, (total, local_sum)
