@@ -1,0 +1,258 @@
+// dense.hip -- group-by over a DENSE key domain: the device form of the reference's PerfectHashTable plan
+// (server/hasher.h:201-357 packs key columns by `TableStats` minima and bit widths, server/table.h:76-91 populate_stats).
+//
+// A pass over the key columns finds every column's [min, max]; if the product of the ranges D is small, a key tuple maps to
+//     idx = sum_j (key_j - min_j) * mult_j          (mixed radix, mult_j = product of the ranges before j)
+// and the group table is a direct-indexed array: no key storage, no probing, no insert race.  Every workgroup keeps
+// {first_row, count, accumulators}[idx] in LDS (up to 150 KB: gfx950 gives a workgroup 160 KB) and merges it into the global
+// array at the end; domains beyond one LDS table take up to DENSE_MAX_PASSES passes, pass p owning idx in
+// [p * per_pass, (p + 1) * per_pass).  h2o Q2 (id1, id2: 100 x 100 values, 1e9 rows): see DESIGN.md for the measured time
+// against the hashed LDS table (18 ms) and the HBM table (54 ms).
+// HBM traffic: the range pass reads the key columns once more (Q2: +8 B/row on 12 B/row algorithmic).
+#include "groupby_dev.hpp"
+#include "dense.hpp"
+
+namespace {
+
+// ---- [min, max] of every key column, as int64 -------------------------------------------------------------------------------
+template <class T>
+__device__ inline void col_range(const void* col, uint32_t n, long long& mn, long long& mx) {
+    const T* p = static_cast<const T*>(col);
+    const uint32_t nchunk = n >> 2;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+        pack<T, 4> v = *reinterpret_cast<const pack<T, 4>*>(p + (size_t)c * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { long long x = (long long)v.v[j]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { long long x = (long long)p[(nchunk << 2) + threadIdx.x]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
+}
+__global__ void __launch_bounds__(256) key_range_kernel(KeySpec ks, uint32_t n, long long* __restrict__ out /* [2 * nkeys]: min_j, max_j */) {
+    __shared__ long long smn[4], smx[4];
+    for (int c = 0; c < ks.nkeys; ++c) {
+        long long mn = INT64_MAX, mx = INT64_MIN;
+        switch (ks.dt[c]) {
+        case AQG_INT8: col_range<int8_t>(ks.col[c], n, mn, mx); break;
+        case AQG_INT16: col_range<int16_t>(ks.col[c], n, mn, mx); break;
+        case AQG_INT32: col_range<int32_t>(ks.col[c], n, mn, mx); break;
+        case AQG_INT64: col_range<int64_t>(ks.col[c], n, mn, mx); break;
+        case AQG_UINT8: case AQG_BOOL: col_range<uint8_t>(ks.col[c], n, mn, mx); break;
+        case AQG_UINT16: col_range<uint16_t>(ks.col[c], n, mn, mx); break;
+        default: col_range<uint32_t>(ks.col[c], n, mn, mx); break;      // AQG_UINT32 (uint64 keys never come here)
+        }
+        mn = wave_reduce((int64_t)mn, OpMin{});
+        mx = wave_reduce((int64_t)mx, OpMax{});
+        if (lane_id() == 0) { smn[wave_id()] = mn; smx[wave_id()] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) { mn = smn[w] < mn ? smn[w] : mn; mx = smx[w] > mx ? smx[w] : mx; }
+            atomicMin(&out[2 * c], mn);
+            atomicMax(&out[2 * c + 1], mx);
+        }
+        __syncthreads();
+    }
+}
+__global__ void range_init_kernel(long long* out, int nkeys) {
+    if ((int)threadIdx.x < nkeys) { out[2 * threadIdx.x] = INT64_MAX; out[2 * threadIdx.x + 1] = INT64_MIN; }
+}
+
+// ---- dense index of four consecutive rows ------------------------------------------------------------------------------------
+template <class T> __device__ inline void add_digit4(const void* col, size_t base, long long kmin, uint32_t mult, uint32_t (&idx)[4]) {
+    pack<T, 4> v = *reinterpret_cast<const pack<T, 4>*>(static_cast<const T*>(col) + base);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) idx[j] += (uint32_t)((long long)v.v[j] - kmin) * mult;
+}
+template <class T> __device__ inline uint32_t digit1(const void* col, size_t i, long long kmin, uint32_t mult) {
+    return (uint32_t)((long long)static_cast<const T*>(col)[i] - kmin) * mult;
+}
+__device__ inline void dense_idx4(const KeySpec& ks, const DenseSpec& ds, size_t base, uint32_t (&idx)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) idx[j] = 0;
+    for (int c = 0; c < ks.nkeys; ++c) {
+        switch (ks.dt[c]) {
+        case AQG_INT8: add_digit4<int8_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
+        case AQG_INT16: add_digit4<int16_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
+        case AQG_INT32: add_digit4<int32_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
+        case AQG_INT64: add_digit4<int64_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
+        case AQG_UINT8: case AQG_BOOL: add_digit4<uint8_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
+        case AQG_UINT16: add_digit4<uint16_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
+        default: add_digit4<uint32_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
+        }
+    }
+}
+__device__ inline uint32_t dense_idx1(const KeySpec& ks, const DenseSpec& ds, size_t i) {
+    uint32_t idx = 0;
+    for (int c = 0; c < ks.nkeys; ++c) {
+        switch (ks.dt[c]) {
+        case AQG_INT8: idx += digit1<int8_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
+        case AQG_INT16: idx += digit1<int16_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
+        case AQG_INT32: idx += digit1<int32_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
+        case AQG_INT64: idx += digit1<int64_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
+        case AQG_UINT8: case AQG_BOOL: idx += digit1<uint8_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
+        case AQG_UINT16: idx += digit1<uint16_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
+        default: idx += digit1<uint32_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
+        }
+    }
+    return idx;
+}
+// the packed key word the emit kernel expects in the table (wide tuples: any row of the group)
+__device__ inline uint64_t dense_key_word(const KeySpec& ks, const DenseSpec& ds, uint32_t idx, uint32_t some_row) {
+    if (ks.wide) return some_row;
+    uint64_t key = 0;
+    uint32_t rem = idx;
+    for (int c = ks.nkeys - 1; c >= 0; --c) {
+        const uint32_t digit = rem / ds.mult[c];
+        rem -= digit * ds.mult[c];
+        const int bytes = aqg_dtype_size_dev(ks.dt[c]);
+        const uint64_t mask = bytes == 8 ? ~0ull : ((1ull << (8 * bytes)) - 1ull);
+        key |= ((uint64_t)(ds.kmin[c] + (long long)digit) & mask) << ks.shift[c];
+    }
+    return key;
+}
+
+template <int NACC, int BLOCK>
+__global__ void __launch_bounds__(BLOCK) dense_agg_kernel(KeySpec ks, DenseSpec ds, AccSpec as, GTable gt, uint32_t n, int need_count) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const uint32_t PP = ds.per_pass;
+    uint64_t* lacc = reinterpret_cast<uint64_t*>(smem_raw);                  // [NACC][PP]
+    uint32_t* lfirst = reinterpret_cast<uint32_t*>(lacc + (size_t)NACC * PP);   // [PP]
+    uint32_t* lcount = lfirst + PP;                                          // [PP] if need_count
+    const uint32_t nchunk = n >> 2;
+    for (uint32_t pass = 0; pass < ds.npass; ++pass) {
+        const uint32_t lo = pass * PP;
+        if (pass) __syncthreads();
+        for (uint32_t s = threadIdx.x; s < PP; s += BLOCK) {
+            lfirst[s] = NOROW;
+            if (need_count) lcount[s] = 0;
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) lacc[(size_t)a * PP + s] = acc_init(as.kind[a]);
+        }
+        __syncthreads();
+        for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < nchunk; c += gridDim.x * BLOCK) {
+            const size_t base = (size_t)c * 4;
+            uint32_t idx[4];
+            dense_idx4(ks, ds, base, idx);
+            uint64_t vals[NACC ? NACC : 1][4];
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) val_operand4(as.dt[a], as.col[a], base, as.kind[a], as.square[a], as.part[a], vals[a]);
+            uint32_t f[4];
+            bool in[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { idx[j] -= lo; in[j] = idx[j] < PP; f[j] = lfirst[in[j] ? idx[j] : 0]; }   // four LDS reads in flight
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (in[j] && (uint32_t)base + j < f[j]) atomicMin(&lfirst[idx[j]], (uint32_t)base + j);
+            if (need_count) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (in[j]) atomicAdd(&lcount[idx[j]], 1u);
+            }
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                uint64_t* la = lacc + (size_t)a * PP;
+                switch (as.kind[a]) {   // wave-uniform
+                case ACC_ADD_I:
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (in[j]) atomicAdd(reinterpret_cast<unsigned long long*>(&la[idx[j]]), (unsigned long long)vals[a][j]);
+                    break;
+                case ACC_ADD_F:
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (in[j]) atomicAdd(reinterpret_cast<double*>(&la[idx[j]]), __builtin_bit_cast(double, vals[a][j]));
+                    break;
+                case ACC_MIN:
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (in[j]) atomicMin(reinterpret_cast<unsigned long long*>(&la[idx[j]]), (unsigned long long)vals[a][j]);
+                    break;
+                default:
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (in[j]) atomicMax(reinterpret_cast<unsigned long long*>(&la[idx[j]]), (unsigned long long)vals[a][j]);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        // merge this workgroup's table into the global direct-indexed one (slot = idx)
+        for (uint32_t s = threadIdx.x; s < PP; s += BLOCK) {
+            const uint32_t first = lfirst[s];
+            if (first == NOROW) continue;
+            const uint32_t g = lo + s;
+            *gt.key_p(g) = dense_key_word(ks, ds, g, first);
+            atomicMin(gt.first_p(g), first);
+            if (need_count) atomicAdd(gt.count_p(g), lcount[s]);
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) acc_apply(gt.acc_p(a, g), as.kind[a], lacc[(size_t)a * PP + s]);
+        }
+    }
+    // tail rows (< 4): straight to the global table
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const uint32_t row = (nchunk << 2) + threadIdx.x;
+        const uint32_t g = dense_idx1(ks, ds, row);
+        *gt.key_p(g) = dense_key_word(ks, ds, g, row);
+        atomicMin(gt.first_p(g), row);
+        if (need_count) atomicAdd(gt.count_p(g), 1u);
+        _Pragma("unroll") for (int a = 0; a < NACC; ++a)
+            acc_apply(gt.acc_p(a, g), as.kind[a], val_operand(as.dt[a], as.col[a], row, as.kind[a], as.square[a], as.part[a]));
+    }
+}
+
+} // namespace
+
+// Ranges of the key columns over n rows (synchronises).  Returns false when some column cannot take part (uint64 keys).
+int aqg_key_ranges(aqg_ctx* ctx, const KeySpec& ks, uint32_t n, long long* mins, long long* maxs, bool* ok) {
+    *ok = false;
+    for (int c = 0; c < ks.nkeys; ++c) if (ks.dt[c] == AQG_UINT64) return AQG_OK;
+    long long* d = nullptr;
+    AQG_TRY(aqg_ws_get(ctx, 2 * MAXKEYS, &d));
+    hipLaunchKernelGGL(range_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d, ks.nkeys);
+    hipLaunchKernelGGL(key_range_kernel, dim3(aqg_grid(ctx, n / 4 + 1, 256, 4, 8)), dim3(256), 0, ctx->stream, ks, n, d);
+    AQG_TRY(aqg_check_launch(ctx, "key_range_kernel"));
+    long long h[2 * MAXKEYS];
+    AQG_TRY(aqg_d2h(ctx, h, d, sizeof(long long) * 2 * ks.nkeys));
+    for (int c = 0; c < ks.nkeys; ++c) { mins[c] = h[2 * c]; maxs[c] = h[2 * c + 1]; }
+    *ok = true;
+    return AQG_OK;
+}
+
+size_t aqg_dense_slot_bytes(const AccSpec& as, int need_count) { return 8 * (size_t)as.nacc + 4 + (need_count ? 4 : 0); }
+
+// plan: fills ds and returns true when the domain fits DENSE_MAX_PASSES LDS tables
+bool aqg_dense_plan(const KeySpec& ks, const long long* mins, const long long* maxs, const AccSpec& as, int need_count, DenseSpec* ds) {
+    memset(ds, 0, sizeof *ds);
+    const size_t sb = aqg_dense_slot_bytes(as, need_count);
+    const uint64_t cap = (uint64_t)(DENSE_LDS_BYTES / sb) * DENSE_MAX_PASSES;
+    uint64_t D = 1;
+    for (int c = 0; c < ks.nkeys; ++c) {
+        if (maxs[c] < mins[c]) return false;
+        const unsigned long long range = (unsigned long long)maxs[c] - (unsigned long long)mins[c] + 1ull;
+        if (range == 0 || range > cap) return false;
+        ds->kmin[c] = mins[c];
+        ds->mult[c] = (uint32_t)D;
+        D *= range;
+        if (D > cap) return false;
+    }
+    ds->D = (uint32_t)D;
+    const uint32_t max_pp = (uint32_t)(DENSE_LDS_BYTES / sb);
+    ds->npass = (uint32_t)((D + max_pp - 1) / max_pp);
+    ds->per_pass = (uint32_t)((D + ds->npass - 1) / ds->npass);
+    return true;
+}
+
+int aqg_dense_aggregate(aqg_ctx* ctx, const KeySpec& ks, const DenseSpec& ds, const AccSpec& as, uint32_t n, int need_count, GTable gt) {
+    const size_t lds = (size_t)ds.per_pass * aqg_dense_slot_bytes(as, need_count);
+    const unsigned block = as.nacc <= 2 ? 1024 : 512;
+    unsigned per_cu = (unsigned)((160 * 1024) / (lds + 1024));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * block > 2048) per_cu = 2048 / block;
+    const unsigned grid = (unsigned)ctx->num_cu * per_cu;
+    auto launch = [&](auto kern) -> int {
+        AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        aqg_kernel_timer_begin(ctx);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, ctx->stream, ks, ds, as, gt, n, need_count);
+        aqg_kernel_timer_end(ctx);
+        return aqg_check_launch(ctx, "dense_agg_kernel");
+    };
+    switch (as.nacc) {
+    case 0: return launch(&dense_agg_kernel<0, 1024>);
+    case 1: return launch(&dense_agg_kernel<1, 1024>);
+    case 2: return launch(&dense_agg_kernel<2, 1024>);
+    case 3: return launch(&dense_agg_kernel<3, 512>);
+    case 4: return launch(&dense_agg_kernel<4, 512>);
+    case 5: return launch(&dense_agg_kernel<5, 512>);
+    case 6: return launch(&dense_agg_kernel<6, 512>);
+    case 7: return launch(&dense_agg_kernel<7, 512>);
+    default: return launch(&dense_agg_kernel<8, 512>);
+    }
+}

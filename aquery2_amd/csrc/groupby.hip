@@ -20,6 +20,7 @@
 //   radix passes      aqg_groupby_postproc: stable partition of row ids by group id.
 // HBM roofline: agg = sum of key and value bytes per row (h2o Q1: 8 B/row); build = 12 B/row.
 #include "groupby_dev.hpp"
+#include "dense.hpp"
 
 // partition.hip
 size_t aqg_partition_ws_bytes(uint32_t n, int ksz, const AccSpec& as, uint32_t pbits);
@@ -779,7 +780,23 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (use_lds && (size_t)(lcap + 1) * lds_slot_bytes > LDS_SMALL) { use_lds = false; lcap = 0; }
     uint32_t npass = 1;
     bool big_lds = false;
-    if (!use_lds && !ks.wide && n >= (1u << 20)) {
+    // dense key domain (dense.hip): direct-indexed tables when the product of the key columns' value ranges is small --
+    // also for tuples wider than 64 bits.  Costs one more pass over the key columns, so it is only tried where the
+    // alternatives are the multi-pass hashed table or the partition pipeline.
+    bool dense = false;
+    DenseSpec dspec;
+    static const bool dense_off = getenv("AQG_DISABLE_DENSE") != nullptr;    // A/B measurements only
+    if (!dense_off && !use_lds && !for_build && n >= (1u << 20) &&
+        (uint64_t)hint <= (uint64_t)(DENSE_LDS_BYTES / aqg_dense_slot_bytes(as, plan.need_count)) * DENSE_MAX_PASSES) {
+        long long mins[MAXKEYS], maxs[MAXKEYS];
+        bool ok = false;
+        AQG_TRY(aqg_ws_reset(ctx));
+        AQG_TRY(aqg_ws_ensure(ctx, 4096));
+        AQG_TRY(aqg_key_ranges(ctx, ks, n, mins, maxs, &ok));
+        dense = ok && aqg_dense_plan(ks, mins, maxs, as, plan.need_count, &dspec);
+        if (dense) gcap = dspec.D;
+    }
+    if (!dense && !use_lds && !ks.wide && n >= (1u << 20)) {
         const uint32_t max_slots = (uint32_t)(LDS_BIG / lds_slot_bytes) - 1;
         const uint32_t per_pass = max_slots - (max_slots >> 2);
         const uint64_t want = ((uint64_t)hint + per_pass - 1) / per_pass;
@@ -792,7 +809,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     // (partition.hip: h2o Q5, 1e9 rows, 1e7 groups: 42 ms against 141 ms); the build path keeps the HBM table because
     // its second pass looks keys up in it.  AQG_DISABLE_PARTITION=1 forces the HBM table (A/B measurements only).
     static const bool part_off = getenv("AQG_DISABLE_PARTITION") != nullptr;
-    const bool use_part = !part_off && !use_lds && !ks.wide && !for_build && n >= (1u << 20) && hint <= (1u << 25);
+    const bool use_part = !part_off && !dense && !use_lds && !ks.wide && !for_build && n >= (1u << 20) && hint <= (1u << 25);
     uint32_t part_lcap = 0, pbits = 0;
     if (use_part) {
         // LDS table of one partition: as many slots as fit 72 KB (two 512-thread workgroups per CU); the slot of a hash is
@@ -880,6 +897,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
                                default: rc = launch(&agg32_kernel<3, false>); break; }
         }
         AQG_TRY(rc);
+    } else if (n && dense) {
+        AQG_TRY(aqg_dense_aggregate(ctx, ks, dspec, as, n, plan.need_count, gt));
     } else if (n && use_part) {
         AQG_TRY(aqg_partition_aggregate(ctx, ks, as, n, pbits, part_lcap, plan.need_count, gt, gcap));
         hipLaunchKernelGGL(occ_iota_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, occ, (uint32_t)slots);

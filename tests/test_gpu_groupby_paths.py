@@ -27,16 +27,35 @@ def vals_of(rng, n):
 
 
 @pytest.mark.parametrize("hint", [0, 10000, 20000])
-def test_big_lds_table_multipass(gpu, oracle, hint):
+def test_dense_domain_direct_indexed(gpu, oracle, hint):
+    """100 x 100 key values: the product of the column ranges fits the LDS tables -> direct-indexed (dense.hip)"""
     rng = np.random.default_rng(21 + hint)
-    keys = [rng.integers(0, 100, N).astype(np.int32), rng.integers(0, 100, N).astype(np.int32)]
+    keys = [rng.integers(-50, 50, N).astype(np.int32), rng.integers(1000, 1100, N).astype(np.int32)]
+    check_agg(gpu, oracle, keys, vals_of(rng, N), hint)
+
+
+def test_dense_domain_wide_tuple_and_passes(gpu, oracle):
+    """five narrow columns (a tuple wider than 64 bits once an int64 column is in it) with a 40 x 12 x 5 x 2 x 9 = 43,200-slot
+    domain: several passes of the direct-indexed table; keys are emitted from a representative row"""
+    rng = np.random.default_rng(23)
+    keys = [rng.integers(-20, 20, N).astype(np.int64), rng.integers(0, 12, N).astype(np.uint8), rng.integers(-2, 3, N).astype(np.int16),
+            rng.integers(0, 2, N).astype(np.int32), rng.integers(100, 109, N).astype(np.uint16)]
+    check_agg(gpu, oracle, keys, [rand(rng, np.int32, N, small=True)], 43_200)
+
+
+@pytest.mark.parametrize("hint", [0, 10000, 20000])
+def test_big_lds_table_multipass(gpu, oracle, hint):
+    """sparse key values (huge ranges, so no dense domain): the hashed 150 KB LDS table with several passes"""
+    rng = np.random.default_rng(21 + hint)
+    keys = [rng.integers(0, 100, N).astype(np.int32) * 9_999_991, rng.integers(0, 100, N).astype(np.int32) * -7_777_777]
     check_agg(gpu, oracle, keys, vals_of(rng, N), hint)
 
 
 def test_big_lds_table_few_accumulators(gpu, oracle):
     """1 and 2 accumulators take the 1024-thread instantiation; one 4-byte key takes the K32 slot layout"""
     rng = np.random.default_rng(22)
-    for keys in ([rng.integers(0, 9000, N).astype(np.int32)], [rng.integers(0, 90, N).astype(np.int16), rng.integers(0, 90, N).astype(np.int32)]):
+    for keys in ([rng.integers(0, 9000, N).astype(np.int32) * 100_003], [rng.integers(0, 90, N).astype(np.int16), rng.integers(0, 90, N).astype(np.int32) * 1_000_003],
+                 [rng.integers(0, 9000, N).astype(np.int32)]):
         o = oracle.groupby(keys)
         v = rand(rng, np.int32, N, small=True)
         w = rand(rng, np.float64, N)
