@@ -8,16 +8,18 @@
 // FIRST OCCURRENCE of the key tuple; row-id lists are DESCENDING inside a group.  The hash function
 // is not observable in results (only dense ids are), so the device uses its own.
 //
-// Kernels
-//   agg_kernel<LDS>   one pass over keys (+ value columns).  Low cardinality: every workgroup keeps a
-//                     {key, first_row, accumulators} open-addressing table in LDS (LDS atomics, no
-//                     HBM traffic beyond the 16-byte column loads), then merges it into the global
-//                     table with device-scope atomics.  High cardinality: rows go straight to the
-//                     global table in HBM.
+// Plans (run_agg picks by the group-count hint, key shape and row count)
+//   agg32_kernel       one 4-byte key, 4-byte SUM/AVG/COUNT values, <= 3072 groups: LDS table, 8 probes in flight (h2o Q1/Q4)
+//   agg_kernel<LDS>    any dtypes / MIN / MAX / VAR, packed tuples: {key, first_row, accumulators} open-addressing table in
+//                      LDS (64 KB tables, several workgroups per CU; or one 150 KB table per CU and up to 4 passes over
+//                      the rows), merged into the global table with device-scope atomics
+//   dense.hip          small key DOMAIN (product of the column ranges): direct-indexed LDS tables (h2o Q2)
+//   partition.hip      more groups than LDS holds: radix-partition the rows, aggregate each partition in LDS (h2o Q3/Q5/Q7)
+//   agg_kernel<HBM>    rows straight to the global table (wide sparse tuples, the build path at high cardinality)
 //   collect / rank / emit   occupied slots -> dense ids ordered by first row -> output columns.
 //   assign_kernel     second pass for aqg_groupby_build: reversemap[i] = dense id, counts.
-//   grouped_kernel    aqg_grouped_reduce: accumulators indexed by dense id.
-//   radix passes      aqg_groupby_postproc: stable partition of row ids by group id.
+//   aqg_grouped_reduce: accumulators indexed by dense id (groups by the reversemap column).
+//   postproc.hip      aqg_groupby_postproc: stable partition of row ids by group id.
 // HBM roofline: agg = sum of key and value bytes per row (h2o Q1: 8 B/row); build = 12 B/row.
 #include "groupby_dev.hpp"
 #include "dense.hpp"

@@ -5,8 +5,9 @@
 // Stable LSD radix sort, 8 bits per pass, over the sequence p -> (key = reversemap[n-1-p], value = n-1-p):
 // a stable sort of that reversed sequence yields descending row ids inside each group.  Per pass:
 //   digit histogram per 4096-row tile -> exclusive scan of the (digit-major, tile-minor) counts ->
-//   stable scatter: 256 rows per round, wavefront match-any by 8 ballots gives the rank among equal
-//   digits inside a wave, LDS per-wave counts order the 4 waves, running counts order the rounds.
+//   stable scatter: 1024 lanes x 4 rows, all loaded up front; wavefront match-any by 8 ballots gives the rank among equal
+//   digits inside a wave, an LDS (round, wavefront, digit) count matrix orders the cells; the tile is staged digit-major
+//   in LDS and streamed out in runs.
 // One pass when G <= 256 (h2o Q1): 12 B/row (4 B histogram read + 4 B read + 4 B write).
 #include "aqg_internal.hpp"
 #include "dev_common.hpp"
