@@ -319,6 +319,16 @@ class Device:
         gb._ops = list(ops)
         return gb
 
+    def join_groupby_sum(self, dim_keys, dim_vals, fact_fk, group_keys, fact_vals, hint=0, handle=None):
+        """fact JOIN dim ON fk = key, then sum(val * w) by group key -- one fused pass (aqg_join_groupby_sum)"""
+        dk, dv, fk, gk, fv = (self._dev(a) for a in (dim_keys, dim_vals, fact_fk, group_keys, fact_vals))
+        h = handle.h if handle is not None else C.c_void_p()
+        self._chk(self.lib.aqg_join_groupby_sum(self.ctx, dk.tag, C.c_void_p(dk.ptr), dv.tag, C.c_void_p(dv.ptr), C.c_uint32(dk.n),
+                                                C.c_void_p(fk.ptr), gk.tag, C.c_void_p(gk.ptr), fv.tag, C.c_void_p(fv.ptr), C.c_uint32(fk.n),
+                                                C.c_uint32(hint), C.byref(h)), "aqg_join_groupby_sum")
+        gb = handle if handle is not None else GroupBy(self, h)
+        gb._keep = (dk, dv, fk, gk, fv)
+        return gb
     def grouped_reduce(self, gb, op, x):
         xd = self._dev(x)
         ot = self.lib.aqg_reduce_out_dtype(op, xd.tag)

@@ -11,8 +11,22 @@ namespace {
 
 constexpr int CB = 256, CIT = 8, CTS = CB * CIT;
 
+// four consecutive outputs per lane: one 16-byte index load, four gathers in flight, one vector store
 template <class W> __global__ void __launch_bounds__(256) gather_kernel(const W* __restrict__ x, const uint32_t* __restrict__ idx, uint32_t m, W* __restrict__ out) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) out[i] = x[idx[i]];
+    const uint32_t nchunk = m >> 2;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (aligned) {
+        for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+            const pack<uint32_t, 4> i4 = *reinterpret_cast<const pack<uint32_t, 4>*>(idx + (size_t)c * 4);
+            pack<W, 4> o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o.v[j] = x[i4.v[j]];
+            *reinterpret_cast<pack<W, 4>*>(out + (size_t)c * 4) = o;
+        }
+        for (uint32_t i = (nchunk << 2) + blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) out[i] = x[idx[i]];
+    } else {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) out[i] = x[idx[i]];
+    }
 }
 
 __global__ void __launch_bounds__(CB) mask_count_kernel(const uint8_t* __restrict__ mask, uint32_t n, uint32_t* __restrict__ tile_cnt) {
@@ -60,9 +74,29 @@ __global__ void __launch_bounds__(CB) compact_kernel(const W* __restrict__ x, co
     __shared__ uint32_t ws[4];
     const uint32_t base = blockIdx.x * CTS + threadIdx.x * CIT;
     bool keep[CIT];
+    W v[CIT];
     uint32_t c = 0;
+    const bool full = base + CIT <= n;
+    if (full && ((reinterpret_cast<uintptr_t>(mask + base)) & 7) == 0) {      // eight mask bytes with one load
+        const uint64_t w = *reinterpret_cast<const uint64_t*>(mask + base);
 #pragma unroll
-    for (int j = 0; j < CIT; ++j) { keep[j] = base + j < n && mask[base + j] != 0; c += keep[j]; }
+        for (int j = 0; j < CIT; ++j) keep[j] = ((w >> (8 * j)) & 0xFF) != 0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < CIT; ++j) keep[j] = base + j < n && mask[base + j] != 0;
+    }
+    if constexpr (!INDEX) {                                                    // every value is loaded (no load behind a branch)
+        if (full && (reinterpret_cast<uintptr_t>(x + base) & (sizeof(W) * 4 > 16 ? 15 : sizeof(W) * 4 - 1)) == 0) {
+            const pack<W, 4> a = *reinterpret_cast<const pack<W, 4>*>(x + base), b = *reinterpret_cast<const pack<W, 4>*>(x + base + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = a.v[j]; v[4 + j] = b.v[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CIT; ++j) v[j] = x[base + j < n ? base + j : n - 1];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < CIT; ++j) c += keep[j];
     uint32_t incl = wave_scan_incl(c, OpAdd{}, lane_id());
     if (lane_id() == 63) ws[wave_id()] = incl;
     __syncthreads();
@@ -71,7 +105,7 @@ __global__ void __launch_bounds__(CB) compact_kernel(const W* __restrict__ x, co
 #pragma unroll
     for (int j = 0; j < CIT; ++j) {
         if (keep[j]) {
-            if constexpr (INDEX) idx_out[pos] = base + j; else out[pos] = x[base + j];
+            if constexpr (INDEX) idx_out[pos] = base + j; else out[pos] = v[j];
             ++pos;
         }
     }
@@ -85,11 +119,18 @@ int run_compact(aqg_ctx* ctx, int t, const void* x, const uint8_t* mask, uint32_
     if (n == 0) return AQG_OK;
     uint32_t ntiles = (n + CTS - 1) / CTS;
     AQG_TRY(aqg_ws_reset(ctx));
-    AQG_TRY(aqg_ws_ensure(ctx, (size_t)(ntiles + 1) * 4 + 4096));
+    AQG_TRY(aqg_ws_ensure(ctx, (size_t)(ntiles + 1) * 4 + ((size_t)ntiles / 2048 + 4) * 4 + 8192));
     uint32_t* tcnt;
     AQG_TRY(aqg_ws_get(ctx, ntiles + 1, &tcnt));
     hipLaunchKernelGGL(mask_count_kernel, dim3(ntiles), dim3(CB), 0, ctx->stream, mask, n, tcnt);
-    hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, tcnt, ntiles);
+    if (ntiles > 8192) {     // large inputs: the three-kernel scan (the single-workgroup one took 0.56 ms at 1e9 rows)
+        uint32_t* bsum;
+        AQG_TRY(aqg_ws_get(ctx, (size_t)ntiles / 2048 + 4, &bsum));
+        AQG_HIP(ctx, hipMemsetAsync(tcnt + ntiles, 0, 4, ctx->stream));
+        AQG_TRY(aqg_exclusive_scan_u32(ctx, tcnt, (uint64_t)ntiles + 1, bsum));
+    } else {
+        hipLaunchKernelGGL(count_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, tcnt, ntiles);
+    }
     if constexpr (INDEX) {
         hipLaunchKernelGGL((compact_kernel<uint32_t, true>), dim3(ntiles), dim3(CB), 0, ctx->stream, (const uint32_t*)nullptr, mask, n, tcnt, (uint32_t*)nullptr, idx_out);
     } else {

@@ -360,6 +360,144 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
     }
 }
 
+// ---- fused star join + group-by sum (BASELINE config 4: fact JOIN small(key, w) ON fk, sum(val * w) BY gkey) -----------------
+// 12 B/row of HBM traffic (fk, gkey, val) instead of the 44 B/row of the composed lookup -> gather -> multiply -> group-by:
+// the dimension side {key -> w} is an LDS open-addressing table built by every workgroup from the (small) dimension columns,
+// the group table is the K32 LDS table of agg_kernel ({key, first_row} in one 8-byte word), and the exact 64-bit product is
+// accumulated as two 64-bit sums of its 32-bit halves (no overflow for n < 2^32).  Fact rows without a partner are dropped
+// (inner join); of duplicate dimension keys the lowest row wins (aqg_join_lookup's contract).
+struct StarJoin {
+    const uint32_t* dim_keys; const uint32_t* dim_vals; uint32_t nb; uint32_t dcap;   // dcap: power of two >= 2 * nb
+    const uint32_t* fk; const uint32_t* vals; int val_signed; int dim_signed;
+};
+
+__global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restrict__ gkeys, StarJoin sj, GTable gt, uint32_t n, uint32_t lcap) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const uint32_t LT = lcap + 1;
+    uint64_t* lkey = reinterpret_cast<uint64_t*>(smem_raw);          // [LT] {first_row << 32 | key}
+    uint64_t* lacc = lkey + LT;                                      // [2][LT] sums of the low / high halves of the products
+    uint32_t* dkey = reinterpret_cast<uint32_t*>(lacc + 2 * (size_t)LT);   // [dcap]
+    uint32_t* dval = dkey + sj.dcap;                                 // [dcap] row while building, then w
+    __shared__ uint32_t lused, dsent;                                // dsent: row / w of the dimension key equal to EMPTY32
+    const uint32_t lmask = lcap - 1, llimit = lcap - (lcap >> 2), dmask = sj.dcap - 1;
+    for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) { lkey[s] = ((uint64_t)NOROW << 32) | EMPTY32; lacc[s] = 0; lacc[LT + s] = 0; }
+    for (uint32_t s = threadIdx.x; s < sj.dcap; s += blockDim.x) { dkey[s] = EMPTY32; dval[s] = NOROW; }
+    if (threadIdx.x == 0) { lused = 0; dsent = NOROW; }
+    __syncthreads();
+    for (uint32_t r = threadIdx.x; r < sj.nb; r += blockDim.x) {     // dimension table: key -> lowest row
+        const uint32_t k = sj.dim_keys[r];
+        if (k == EMPTY32) { atomicMin(&dsent, r); continue; }
+        uint32_t s = hash32(k) & dmask;
+        while (true) {
+            uint32_t cur = dkey[s];
+            if (cur == EMPTY32) { uint32_t old = atomicCAS(&dkey[s], EMPTY32, k); cur = old == EMPTY32 ? k : old; }
+            if (cur == k) { atomicMin(&dval[s], r); break; }
+            s = (s + 1) & dmask;
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < sj.dcap; s += blockDim.x) if (dval[s] != NOROW) dval[s] = sj.dim_vals[dval[s]];
+    const bool has_sent = dsent != NOROW;
+    const uint32_t sent_w = has_sent ? sj.dim_vals[dsent] : 0;
+    __syncthreads();
+
+    auto group_slot = [&](uint32_t k) -> uint32_t {                  // insert path of the group table
+        if (k == EMPTY32) return lcap;
+        uint32_t* kw = reinterpret_cast<uint32_t*>(lkey);
+        uint32_t s = hash32(k) & lmask;
+        for (uint32_t p = 0; p <= lmask; ++p) {
+            uint32_t cur = kw[2 * s];
+            if (cur == k) return s;
+            if (cur == EMPTY32) {
+                if (lused >= llimit) return FAIL;
+                uint32_t old = atomicCAS(&kw[2 * s], EMPTY32, k);
+                if (old == EMPTY32) { atomicAdd(&lused, 1u); return s; }
+                if (old == k) return s;
+            }
+            s = (s + 1) & lmask;
+        }
+        return FAIL;
+    };
+    const bool any_signed = sj.val_signed || sj.dim_signed;
+    auto product = [&](uint32_t vbits, uint32_t wbits) -> uint64_t {   // exact 64-bit product (bits)
+        const int64_t v = sj.val_signed ? (int64_t)(int32_t)vbits : (int64_t)vbits;
+        const int64_t w = sj.dim_signed ? (int64_t)(int32_t)wbits : (int64_t)wbits;
+        return (uint64_t)v * (uint64_t)w;
+    };
+    auto lo_half = [&](uint64_t p) -> unsigned long long { return p & 0xFFFFFFFFull; };
+    auto hi_half = [&](uint64_t p) -> unsigned long long { return any_signed ? (unsigned long long)((int64_t)p >> 32) : p >> 32; };
+    auto to_global = [&](uint32_t k, uint32_t row, uint64_t p) {     // LDS table at its load limit, or tail rows
+        uint32_t g = gt_find_or_insert(gt, (uint64_t)k);
+        if (g == FAIL) return;
+        gt_touch_first(gt, g, row);
+        atomicAdd(reinterpret_cast<unsigned long long*>(gt.acc_p(0, g)), lo_half(p));
+        atomicAdd(reinterpret_cast<unsigned long long*>(gt.acc_p(1, g)), hi_half(p));
+    };
+    auto dim_lookup = [&](uint32_t k, uint32_t first_probe, uint32_t s, uint32_t& w) -> bool {   // first_probe = dkey[s]
+        if (k == EMPTY32) { w = sent_w; return has_sent; }
+        uint32_t cur = first_probe;
+        for (uint32_t p = 0; p <= dmask; ++p) {
+            if (cur == k) { w = dval[s]; return true; }
+            if (cur == EMPTY32) return false;
+            s = (s + 1) & dmask;
+            cur = dkey[s];
+        }
+        return false;
+    };
+
+    const uint32_t nchunk = n >> 2;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+        const size_t base = (size_t)c * 4;
+        const pack<uint32_t, 4> f4 = *reinterpret_cast<const pack<uint32_t, 4>*>(sj.fk + base);
+        const pack<uint32_t, 4> g4 = *reinterpret_cast<const pack<uint32_t, 4>*>(gkeys + base);
+        const pack<uint32_t, 4> v4 = *reinterpret_cast<const pack<uint32_t, 4>*>(sj.vals + base);
+        uint32_t ds[4], dk[4], gs[4];
+        uint64_t gw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                // eight LDS probes in flight
+            ds[j] = hash32(f4.v[j]) & dmask; dk[j] = dkey[ds[j]];
+            gs[j] = hash32(g4.v[j]) & lmask; gw[j] = lkey[gs[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t w;
+            if (!dim_lookup(f4.v[j], dk[j], ds[j], w)) continue;     // no partner: the row is not in the join
+            const uint64_t p = product(v4.v[j], w);
+            const uint32_t row = (uint32_t)base + j, k = g4.v[j];
+            uint32_t s = gs[j];
+            if ((uint32_t)gw[j] == k && k != EMPTY32) {
+                if (row < (uint32_t)(gw[j] >> 32)) atomicMin(reinterpret_cast<uint32_t*>(lkey) + 2 * s + 1, row);
+            } else {
+                s = group_slot(k);
+                if (s == FAIL) { to_global(k, row, p); continue; }
+                uint32_t* f = reinterpret_cast<uint32_t*>(lkey) + 2 * s + 1;
+                if (row < *f) atomicMin(f, row);
+            }
+            atomicAdd(reinterpret_cast<unsigned long long*>(&lacc[s]), lo_half(p));
+            atomicAdd(reinterpret_cast<unsigned long long*>(&lacc[LT + s]), hi_half(p));
+        }
+    }
+    if (blockIdx.x == 0) {                                           // tail rows (< 4)
+        const uint32_t row = (nchunk << 2) + threadIdx.x;
+        if (row < n) {
+            const uint32_t k = sj.fk[row], s0 = hash32(k) & dmask;
+            uint32_t w;
+            if (dim_lookup(k, dkey[s0], s0, w)) to_global(gkeys[row], row, product(sj.vals[row], w));
+        }
+    }
+    __syncthreads();
+    for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) {        // merge into the global table
+        const uint64_t wd = lkey[s];
+        const uint32_t first = (uint32_t)(wd >> 32);
+        if (first == NOROW) continue;
+        uint32_t g = gt_find_or_insert(gt, (uint64_t)(uint32_t)wd);
+        if (g == FAIL) continue;
+        atomicMin(gt.first_p(g), first);
+        atomicAdd(reinterpret_cast<unsigned long long*>(gt.acc_p(0, g)), (unsigned long long)lacc[s]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(gt.acc_p(1, g)), (unsigned long long)lacc[LT + s]);
+    }
+}
+
 // first row of every group, after the fact: tiles are scanned in order by a small grid; once every group has a candidate,
 // a workgroup stops as soon as its next tile starts beyond the largest candidate (no later row can lower any of them).
 __global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restrict__ keys, uint32_t n, GTable gt, const uint32_t* __restrict__ occ) {
@@ -719,6 +857,7 @@ struct Plan {
     int need_count;
     int nagg;
     AggOut agg[MAXAGG];
+    const StarJoin* sj;        // aqg_join_groupby_sum: the row pass is starjoin_kernel
 };
 
 int add_acc(Plan* p, int kind, int dt, const void* col, int square, int part = 0) {
@@ -780,6 +919,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (use_lds && lcap < 256) lcap = 256;
     const size_t lds_slot_bytes = 8 + 8 * (size_t)as.nacc + (k32 ? 0 : 4) + (plan.need_count ? 4 : 0);
     if (use_lds && (size_t)(lcap + 1) * lds_slot_bytes > LDS_SMALL) { use_lds = false; lcap = 0; }
+    if (plan.sj && !(use_lds && k32))
+        return aqg_fail(ctx, AQG_ERR_ARG, "aqg_join_groupby_sum: needs one 4-byte group key and at most 3072 groups (compose aqg_join_lookup / aqg_gather / aqg_ewise / aqg_groupby_agg beyond that)");
     uint32_t npass = 1;
     bool big_lds = false;
     // dense key domain (dense.hip): direct-indexed tables when the product of the key columns' value ranges is small --
@@ -788,7 +929,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     bool dense = false;
     DenseSpec dspec;
     static const bool dense_off = getenv("AQG_DISABLE_DENSE") != nullptr;    // A/B measurements only
-    if (!dense_off && !use_lds && !for_build && n >= (1u << 20) &&
+    if (!dense_off && !plan.sj && !use_lds && !for_build && n >= (1u << 20) &&
         (uint64_t)hint <= (uint64_t)(DENSE_LDS_BYTES / aqg_dense_slot_bytes(as, plan.need_count)) * DENSE_MAX_PASSES) {
         long long mins[MAXKEYS], maxs[MAXKEYS];
         bool ok = false;
@@ -867,7 +1008,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (bitmap) AQG_HIP(ctx, hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, ctx->stream));
 
     // fast path eligibility: LDS mode, one 4-byte integer key, 1..3 four-byte value columns, plain additive accumulators
-    bool fast = use_lds && !big_lds && k32 && n >= 8 && as.nacc >= (plan.need_count ? 0 : 1) && as.nacc <= 3 && !for_build &&
+    bool fast = use_lds && !plan.sj && !big_lds && k32 && n >= 8 && as.nacc >= (plan.need_count ? 0 : 1) && as.nacc <= 3 && !for_build &&
                 (ks.dt[0] == AQG_INT32 || ks.dt[0] == AQG_UINT32) && ((uintptr_t)ks.col[0] & 15) == 0;
     FastVals fv;
     memset(&fv, 0, sizeof fv);
@@ -879,7 +1020,15 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         fv.vkind[a] = dt == AQG_INT32 ? 0 : dt == AQG_UINT32 ? 1 : 2;
     }
     // ---- pass over the rows ---------------------------------------------------------------------
-    if (n && fast) {
+    if (n && plan.sj) {
+        const size_t lds = (size_t)(lcap + 1) * 24 + (size_t)plan.sj->dcap * 8 + 64;
+        unsigned bpc = lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : lds <= 80 * 1024 ? 2 : 1;
+        AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&starjoin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        aqg_kernel_timer_begin(ctx);
+        hipLaunchKernelGGL(starjoin_kernel, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, bpc)), dim3(256), lds, ctx->stream, static_cast<const uint32_t*>(ks.col[0]), *plan.sj, gt, n, lcap);
+        aqg_kernel_timer_end(ctx);
+        AQG_TRY(aqg_check_launch(ctx, "starjoin_kernel"));
+    } else if (n && fast) {
         const size_t lds = (size_t)(lcap + 1) * (4 + 8 * (size_t)as.nacc + (plan.need_count ? 4 : 0)) + 64;
         unsigned bpc = lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : 2;
         unsigned grid = aqg_grid(ctx, n / 8 + 1, 256, 2, bpc);
@@ -1062,6 +1211,39 @@ int aqg_groupby_agg(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* 
     AQG_TRY(make_keyspec(ctx, nkeys, key_dtypes, keys, n, &ks));
     Plan plan;
     AQG_TRY(make_plan(ctx, naggs, ops, val_dtypes, vals, n, &plan));
+    aqg_groupby* h = *out ? *out : new aqg_groupby();
+    h->ctx = ctx; h->n = n; h->has_reversemap = false;
+    int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, false, h, nullptr, nullptr);
+    if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
+    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = h;
+    return AQG_OK;
+}
+
+int aqg_join_groupby_sum(aqg_ctx* ctx, int key_dtype, const void* dim_keys, int dim_val_dtype, const void* dim_vals, uint32_t nb,
+                         const void* fact_fk, int group_key_dtype, const void* group_keys, int val_dtype, const void* fact_vals, uint32_t n,
+                         uint32_t max_groups_hint, aqg_groupby** out) {
+    if (!ctx || !out || ((!dim_keys || !dim_vals) && nb) || ((!fact_fk || !group_keys || !fact_vals) && n))
+        return aqg_fail(ctx, AQG_ERR_ARG, "aqg_join_groupby_sum: bad argument");
+    auto i32 = [](int t) { return t == AQG_INT32 || t == AQG_UINT32; };
+    if (!i32(key_dtype) || !i32(dim_val_dtype) || !i32(group_key_dtype) || !i32(val_dtype))
+        return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_join_groupby_sum: 4-byte integer columns only");
+    if (nb > 4096) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_join_groupby_sum: the dimension side must fit LDS (<= 4096 rows)");
+    StarJoin sj;
+    sj.dim_keys = static_cast<const uint32_t*>(dim_keys); sj.dim_vals = static_cast<const uint32_t*>(dim_vals); sj.nb = nb;
+    sj.dcap = next_pow2((uint64_t)(nb < 8 ? 8 : nb) * 2);
+    sj.fk = static_cast<const uint32_t*>(fact_fk); sj.vals = static_cast<const uint32_t*>(fact_vals);
+    sj.val_signed = val_dtype == AQG_INT32; sj.dim_signed = dim_val_dtype == AQG_INT32;
+    KeySpec ks;
+    const void* kcols[1] = {group_keys};
+    AQG_TRY(make_keyspec(ctx, 1, &group_key_dtype, kcols, n, &ks));
+    // the sum of the exact products is an 8-byte-integer SUM: two accumulators (low / high halves), emitted as 128 bits;
+    // unsigned x unsigned products are summed as unsigned
+    Plan plan;
+    const int op = AQG_RED_SUM, pdt = (sj.val_signed || sj.dim_signed) ? AQG_INT64 : AQG_UINT64;
+    const void* pv[1] = {fact_vals};
+    AQG_TRY(make_plan(ctx, 1, &op, &pdt, pv, n, &plan));
+    plan.sj = &sj;
     aqg_groupby* h = *out ? *out : new aqg_groupby();
     h->ctx = ctx; h->n = n; h->has_reversemap = false;
     int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, false, h, nullptr, nullptr);

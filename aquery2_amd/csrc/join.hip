@@ -32,6 +32,25 @@ __device__ inline uint64_t key_bits(int dt, const void* col, size_t i) {   // si
     }
 }
 
+template <class T> __device__ inline void key_bits4_t(const void* col, const size_t (&ix)[4], uint64_t (&k)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const T v = static_cast<const T*>(col)[ix[q]];
+        if constexpr (std::is_signed_v<T>) k[q] = (uint64_t)(int64_t)v; else k[q] = (uint64_t)v;
+    }
+}
+__device__ inline void key_bits4(int dt, const void* col, const size_t (&ix)[4], uint64_t (&k)[4]) {
+    switch (dt) {
+    case AQG_INT8: key_bits4_t<int8_t>(col, ix, k); break;
+    case AQG_INT16: key_bits4_t<int16_t>(col, ix, k); break;
+    case AQG_INT32: key_bits4_t<int32_t>(col, ix, k); break;
+    case AQG_UINT8: case AQG_BOOL: key_bits4_t<uint8_t>(col, ix, k); break;
+    case AQG_UINT16: key_bits4_t<uint16_t>(col, ix, k); break;
+    case AQG_UINT32: key_bits4_t<uint32_t>(col, ix, k); break;
+    default: key_bits4_t<uint64_t>(col, ix, k); break;
+    }
+}
+
 struct JTable { uint64_t* keys; uint32_t* val; uint32_t cap; uint32_t* sentinel_val; };   // sentinel: the key equal to JEMPTY
 
 __global__ void __launch_bounds__(256) jt_build_kernel(int dt, const void* __restrict__ col, uint32_t n, JTable t) {
@@ -51,22 +70,66 @@ __global__ void __launch_bounds__(256) jt_build_kernel(int dt, const void* __res
         }
     }
 }
-__global__ void __launch_bounds__(256) jt_probe_kernel(int dt, const void* __restrict__ col, uint32_t n, JTable t, uint32_t* __restrict__ out) {
+// Probe: four CONSECUTIVE rows per lane per step (one vector load of the keys, one 16-byte store of the results), the four
+// first slots read before the first compare.  LDS: the whole table is copied into LDS first (dimension sides of a few
+// thousand rows: every probe is an LDS access instead of an L2 round trip).
+template <bool LDS, class T>
+__device__ inline void probe_rows(const T* __restrict__ col, uint32_t n, const JTable& t, const uint64_t* keys, const uint32_t* val, uint32_t* __restrict__ out) {
     const uint32_t mask = t.cap - 1;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        uint64_t k = key_bits(dt, col, i);
-        uint32_t r = NONE;
-        if (k == JEMPTY) r = *t.sentinel_val;
-        else {
-            uint32_t s = jhash(k) & mask;
-            for (uint32_t p = 0; p < t.cap; ++p) {
-                uint64_t cur = t.keys[s];
-                if (cur == k) { r = t.val[s]; break; }
-                if (cur == JEMPTY) break;
-                s = (s + 1) & mask;
-            }
+    const uint32_t sentinel = *t.sentinel_val;
+    auto key_of = [](T v) -> uint64_t { if constexpr (std::is_signed_v<T>) return (uint64_t)(int64_t)v; else return (uint64_t)v; };
+    auto finish = [&](uint64_t k, uint32_t sl, uint64_t c) -> uint32_t {
+        if (k == JEMPTY) return sentinel;
+        for (uint32_t p = 0; p < t.cap; ++p) {
+            if (c == k) return val[sl];
+            if (c == JEMPTY) return NONE;
+            sl = (sl + 1) & mask;
+            c = keys[sl];
         }
-        out[i] = r;
+        return NONE;
+    };
+    const uint32_t nchunk = n >> 2;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(col) & (sizeof(T) * 4 > 16 ? 15 : sizeof(T) * 4 - 1)) | (reinterpret_cast<uintptr_t>(out) & 15)) == 0;
+    if (aligned) {
+        for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+            const pack<T, 4> kv = *reinterpret_cast<const pack<T, 4>*>(col + (size_t)c * 4);
+            uint64_t k[4], cur[4];
+            uint32_t s[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { k[q] = key_of(kv.v[q]); s[q] = jhash(k[q]) & mask; cur[q] = keys[s[q]]; }
+            pack<uint32_t, 4> o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o.v[q] = finish(k[q], s[q], cur[q]);
+            *reinterpret_cast<pack<uint32_t, 4>*>(out + (size_t)c * 4) = o;
+        }
+    }
+    for (uint32_t i = (aligned ? nchunk << 2 : 0u) + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint64_t k = key_of(col[i]);
+        const uint32_t sl = jhash(k) & mask;
+        out[i] = finish(k, sl, keys[sl]);
+    }
+}
+template <bool LDS>
+__global__ void __launch_bounds__(256) jt_probe_kernel(int dt, const void* __restrict__ col, uint32_t n, JTable t, uint32_t* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint64_t* lk = reinterpret_cast<uint64_t*>(smem_raw);
+    uint32_t* lv = reinterpret_cast<uint32_t*>(lk + (LDS ? t.cap : 0));
+    const uint64_t* keys = t.keys;
+    const uint32_t* val = t.val;
+    if constexpr (LDS) {
+        for (uint32_t s = threadIdx.x; s < t.cap; s += blockDim.x) { lk[s] = t.keys[s]; lv[s] = t.val[s]; }
+        __syncthreads();
+        keys = lk; val = lv;
+    }
+    switch (dt) {       // one dtype switch per launch, not per row
+    case AQG_INT8: probe_rows<LDS>(static_cast<const int8_t*>(col), n, t, keys, val, out); break;
+    case AQG_INT16: probe_rows<LDS>(static_cast<const int16_t*>(col), n, t, keys, val, out); break;
+    case AQG_INT32: probe_rows<LDS>(static_cast<const int32_t*>(col), n, t, keys, val, out); break;
+    case AQG_UINT8: case AQG_BOOL: probe_rows<LDS>(static_cast<const uint8_t*>(col), n, t, keys, val, out); break;
+    case AQG_UINT16: probe_rows<LDS>(static_cast<const uint16_t*>(col), n, t, keys, val, out); break;
+    case AQG_UINT32: probe_rows<LDS>(static_cast<const uint32_t*>(col), n, t, keys, val, out); break;
+    case AQG_INT64: probe_rows<LDS>(static_cast<const int64_t*>(col), n, t, keys, val, out); break;
+    default: probe_rows<LDS>(static_cast<const uint64_t*>(col), n, t, keys, val, out); break;
     }
 }
 __global__ void __launch_bounds__(256) match_count_kernel(const uint32_t* __restrict__ gid, uint32_t np, const uint32_t* __restrict__ counts, uint32_t* __restrict__ cnt) {
@@ -102,6 +165,15 @@ int make_table(aqg_ctx* ctx, int t, const void* col, uint32_t n, JTable* jt) {
     return aqg_check_launch(ctx, "jt_build_kernel");
 }
 
+void launch_probe(aqg_ctx* ctx, int t, const void* pk, uint32_t np, const JTable& jt, uint32_t* out) {
+    const size_t lds = (size_t)jt.cap * 12;
+    if (lds <= 48 * 1024 && np >= (1u << 16)) {
+        hipLaunchKernelGGL((jt_probe_kernel<true>), dim3(aqg_grid(ctx, np / 4 + 1, 256, 2, lds <= 20 * 1024 ? 8 : 3)), dim3(256), lds, ctx->stream, t, pk, np, jt, out);
+    } else {
+        hipLaunchKernelGGL((jt_probe_kernel<false>), dim3(aqg_grid(ctx, np / 4 + 1, 256, 2, 8)), dim3(256), 0, ctx->stream, t, pk, np, jt, out);
+    }
+}
+
 int join_core(aqg_ctx* ctx, int t, const void* bk, uint32_t nb, const void* pk, uint32_t np, uint32_t* probe_rows, uint32_t* build_rows,
               uint64_t capacity, uint64_t* m_host) {
     *m_host = 0;
@@ -133,7 +205,7 @@ int join_core(aqg_ctx* ctx, int t, const void* bk, uint32_t nb, const void* pk, 
     if (rc == AQG_OK) rc = aqg_ws_get(ctx, ((size_t)np + 1) / 2048 + 2, &bsum);
     if (rc != AQG_OK) { cleanup(); return rc; }
     unsigned pg = aqg_grid(ctx, np, 256, 4, 8);
-    hipLaunchKernelGGL(jt_probe_kernel, dim3(pg), dim3(256), 0, ctx->stream, t, pk, np, jt, gid);
+    launch_probe(ctx, t, pk, np, jt, gid);
     hipLaunchKernelGGL(match_count_kernel, dim3(pg), dim3(256), 0, ctx->stream, gid, np, aqg_groupby_counts(gb), cnt);
     rc = aqg_exclusive_scan_u32(ctx, cnt, (uint64_t)np + 1, bsum);
     uint32_t m32 = 0;
@@ -163,7 +235,7 @@ int aqg_join_lookup(aqg_ctx* ctx, int t, const void* bk, uint32_t nb, const void
     JTable jt;
     AQG_TRY(make_table(ctx, t, bk, nb, &jt));
     aqg_kernel_timer_begin(ctx);
-    hipLaunchKernelGGL(jt_probe_kernel, dim3(aqg_grid(ctx, np, 256, 4, 8)), dim3(256), 0, ctx->stream, t, pk, np, jt, out);
+    launch_probe(ctx, t, pk, np, jt, out);
     aqg_kernel_timer_end(ctx);
     return aqg_check_launch(ctx, "jt_probe_kernel");
 }

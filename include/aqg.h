@@ -210,6 +210,18 @@ int aqg_join_pairs(aqg_ctx* ctx, int t, const void* build_keys, uint32_t nb,
 int aqg_join_lookup(aqg_ctx* ctx, int t, const void* build_keys, uint32_t nb,
                     const void* probe_keys, uint32_t np, uint32_t* build_row_of_probe);
 
+/* Fused star join + grouped sum (BASELINE config 4: `fact JOIN small(key, w) ON fact.fk = small.key`, then
+ * `sum(fact.val * small.w) BY fact.gkey`): one pass over fk, gkey and val (12 B/row) instead of lookup -> gather ->
+ * multiply -> group-by (44 B/row).  The reference emits this as SQL for MonetDB (engine/ast.py:874-1085) followed by
+ * the generated group loop (engine/ast.py:722-789); `val * w` is the free operator* of table.h:866-876 (exact product in
+ * GetLongType) and the sum is aggregations.h:62-70.  All five columns are 4-byte integers; the dimension side has at
+ * most 4096 rows (it lives in LDS), unique keys (of duplicates the lowest row wins, as in aqg_join_lookup); fact rows
+ * without a partner are dropped (inner join).  Result: a group-by handle whose keys / first rows are in first-occurrence
+ * order among the JOINED rows and whose aqg_groupby_agg_result(h, 0) is the 128-bit sum per group.  At most 3072 groups. */
+int aqg_join_groupby_sum(aqg_ctx* ctx, int key_dtype, const void* dim_keys, int dim_val_dtype, const void* dim_vals, uint32_t nb,
+                         const void* fact_fk, int group_key_dtype, const void* group_keys, int val_dtype, const void* fact_vals,
+                         uint32_t n, uint32_t max_groups_hint, aqg_groupby** out);
+
 /* ---- synthetic h2o / time-series columns (bench + parity inputs) ---
  * Counter-based: row i of column `col` depends only on (seed, col, row_base+i),
  * so shards are reproducible independent of the GPU count.  The oracle carries

@@ -114,6 +114,59 @@ def test_config4_join_then_groupby(gpu, oracle):
     assert gu.same_bits(gb.result(0, ck.RED_SUM, ck.INT64), oracle.grouped_reduce(ck.RED_SUM, want_prod, o))
 
 
+def test_config4_fused_star_join_groupby_sum(gpu, oracle):
+    """aqg_join_groupby_sum == the composed pipeline == the oracle, incl. unmatched fact rows (inner join), duplicate and
+    sentinel dimension keys, negative values and the first-occurrence order among JOINED rows"""
+    rng = np.random.default_rng(44)
+    for n, nb, lo in ((2_000_003, 100, 1), (50_001, 37, -5), (7, 3, 0), (3, 4096, 0)):
+        fk = rng.integers(lo, lo + nb + 20, n).astype(np.int32)                # some keys have no partner
+        gkey = rng.integers(-40, 40, n).astype(np.int32)
+        val = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+        dim_key = rng.permutation(np.arange(lo, lo + nb, dtype=np.int32))
+        if nb == 37:
+            dim_key[5] = dim_key[30]                                             # duplicate: the lowest row wins
+            dim_key[7] = np.iinfo(np.int32).min                                 # the LDS empty mark as a key
+            fk[::11] = np.iinfo(np.int32).min
+        dim_w = rng.integers(-2**31, 2**31 - 1, nb).astype(np.int32)
+        gb = gpu.join_groupby_sum(dim_key, dim_w, fk, gkey, val)
+        # oracle: lookup (lowest build row), drop unmatched rows, exact products, grouped sum in first-occurrence order
+        first = {}
+        for r, k in enumerate(dim_key.tolist()):
+            first.setdefault(k, r)
+        look = np.array([first.get(k, -1) for k in fk.tolist()], dtype=np.int64)
+        m = look >= 0
+        rows = np.nonzero(m)[0]
+        if len(rows) == 0:
+            assert gb.ngroups == 0
+            continue
+        prod = [int(v) * int(w) for v, w in zip(val[m].tolist(), dim_w[look[m]].tolist())]
+        o = oracle.groupby([np.ascontiguousarray(gkey[m])])
+        assert gb.ngroups == o["ngroups"]
+        assert np.array_equal(gb.keys(0, np.int32), gkey[m][o["first_rows"]])
+        assert np.array_equal(gb.first_rows(), rows[o["first_rows"]].astype(np.uint32))      # row ids of the FACT table
+        want = [0] * o["ngroups"]
+        for g, p_ in zip(o["reversemap"].tolist(), prod):
+            want[g] += p_
+        assert ck.i128_to_int(gb.result(0, ck.RED_SUM, ck.INT64)) == want
+        gb.destroy()
+
+
+def test_config4_fused_unsigned(gpu):
+    rng = np.random.default_rng(45)
+    n, nb = 300_000, 64
+    fk = rng.integers(0, nb, n).astype(np.uint32)
+    gkey = rng.integers(0, 9, n).astype(np.uint32)
+    val = rng.integers(0, 2**32 - 1, n, dtype=np.uint64).astype(np.uint32)
+    dim_key = np.arange(nb, dtype=np.uint32)
+    dim_w = rng.integers(0, 2**32 - 1, nb, dtype=np.uint64).astype(np.uint32)
+    gb = gpu.join_groupby_sum(dim_key, dim_w, fk, gkey, val)
+    want = {}
+    for g, v, f in zip(gkey.tolist(), val.tolist(), fk.tolist()):
+        want[g] = want.get(g, 0) + v * int(dim_w[f])
+    keys = gb.keys(0, np.uint32).tolist()
+    assert ck.i128_to_int(gb.result(0, ck.RED_SUM, ck.UINT64)) == [want[k] for k in keys]
+
+
 def test_full_size_properties_q5_and_windows(gpu):
     """1e8 rows: Q5 invariants (sums of group sums, counts) and window invariants"""
     n = 100_000_000

@@ -94,3 +94,36 @@ if which in ("all", "ew"):
     timeit("max(price)", 4, lambda: d.reduce(ck.RED_MAX, price), kernel=False)
     timeit("sum(v3) float", 4, lambda: d.reduce(ck.RED_SUM, v3), kernel=False)
     for k in list(outs): outs[k].free()
+if which in ("all", "join"):
+    # config 4: fact JOIN small(id4, w) ON id4, then sum(v1 * w) by id1 -- composed from the C-ABI pieces
+    import ctypes as C
+    id1, id4, v1 = col(ck.GEN_ID1), col(ck.GEN_ID4), col(ck.GEN_V1)
+    rng = np.random.default_rng(4)
+    dim_key = d.to_device(rng.permutation(np.arange(1, K + 1, dtype=np.int32)))
+    dim_w = d.to_device(rng.integers(1, 50, K).astype(np.int32))
+    look = d.empty(n, np.uint32); wrow = d.empty(n, np.int32); prod = d.empty(n, np.int64)
+    def lookup():
+        d._chk(d.lib.aqg_join_lookup(d.ctx, ck.INT32, C.c_void_p(dim_key.ptr), C.c_uint32(K), C.c_void_p(id4.ptr), C.c_uint32(n), C.c_void_p(look.ptr)), "lookup")
+    def gather():
+        d._chk(d.lib.aqg_gather(d.ctx, ck.INT32, C.c_void_p(dim_w.ptr), C.c_void_p(look.ptr), C.c_uint32(n), C.c_void_p(wrow.ptr)), "gather")
+    timeit("join_lookup(dim.id4, fact.id4)", 8, lookup, kernel=False)
+    timeit("gather w[lookup]", 12, gather, kernel=False)
+    timeit("v1 * w -> int64", 16, lambda: d.ewise(ck.OP_MUL, v1, wrow, ot=ck.INT64, keep=True, out=prod), kernel=False)
+    hj = {}
+    def agg():
+        hj["h"] = d.groupby_agg([id1], [ck.RED_SUM], [prod], hint=128, handle=hj.get("h"))
+    timeit("sum(prod int64) by id1", 12, agg)
+    def whole():
+        lookup(); gather(); d.ewise(ck.OP_MUL, v1, wrow, ot=ck.INT64, keep=True, out=prod); agg()
+    timeit("config 4 composed (12 B/row alg.)", 12, whole, kernel=False)
+    hf = {}
+    def fused():
+        hf["h"] = d.join_groupby_sum(dim_key, dim_w, id4, id1, v1, hint=128, handle=hf.get("h"))
+    timeit("config 4 fused aqg_join_groupby_sum", 12, fused)
+    assert ck.i128_to_int(hf["h"].result(0, ck.RED_SUM, ck.INT64)) == ck.i128_to_int(hj["h"].result(0, ck.RED_SUM, ck.INT64))
+    big = d.gen_column(ck.GEN_ID3, 42, 0, n, n, K)       # random row ids in [1, n/K]
+    timeit("gather v1[random idx]", 12, lambda: d._chk(d.lib.aqg_gather(d.ctx, ck.INT32, C.c_void_p(v1.ptr), C.c_void_p(big.ptr), C.c_uint32(n), C.c_void_p(wrow.ptr)), "g"), kernel=False)
+    mask = d.empty(n, np.uint8)
+    d.ewise(ck.OP_GT, v1, np.int32(2), keep=True, out=A.DevBuf(d, mask.ptr, np.bool_, n, owned=False))
+    mh = C.c_uint32()
+    timeit("compact v1[v1 > 2] (60 % kept)", 5 + 2.4, lambda: d._chk(d.lib.aqg_compact(d.ctx, ck.INT32, C.c_void_p(v1.ptr), C.c_void_p(mask.ptr), C.c_uint32(n), C.c_void_p(wrow.ptr), C.byref(mh)), "c"), kernel=False)
