@@ -52,6 +52,8 @@ static inline int aqg_fail(aqg_ctx* ctx, int code, const char* msg) {
     if (ctx) ctx->err = msg;
     return code;
 }
+#define AQG_CHECK_ROWS(ctx, n, what) do { if ((uint64_t)(n) > (uint64_t)AQG_MAX_ROWS) return aqg_fail(ctx, AQG_ERR_ARG, what ": more than AQG_MAX_ROWS rows"); } while (0)
+static inline uint32_t aqg_ceil_div(uint32_t n, uint32_t d) { return (uint32_t)(((uint64_t)n + d - 1) / d); }
 
 // workspace: reset at the start of an API call, then bump.  Growing synchronises the
 // stream (earlier kernels may still read the old arena) -- call aqg_reserve_workspace

@@ -262,6 +262,7 @@ int aqg_ewise_out_dtype(int op, int lt, int rt) {
 int aqg_ewise(aqg_ctx* ctx, int op, int kind, int lt, const void* l, int rt, const void* r, int ot, void* out, uint32_t n) {
     if (!ctx || op < 0 || op > AQG_OP_NE || kind < 0 || kind > 2) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_ewise: bad argument");
     if (!l || !r || (!out && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_ewise: null operand");
+    AQG_CHECK_ROWS(ctx, n, "aqg_ewise");
     if (!(dt_is_num(lt) || lt == AQG_BOOL) || !(dt_is_num(rt) || rt == AQG_BOOL)) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_ewise: operand dtype");
     if (n == 0) return AQG_OK;
     int c = usual_conv(lt, rt);
@@ -283,10 +284,12 @@ int aqg_ewise(aqg_ctx* ctx, int op, int kind, int lt, const void* l, int rt, con
 
 int aqg_unary(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, uint32_t param, int ot, void* out) {
     if (!ctx || (!x && n) || (!out && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_unary: bad argument");
+    AQG_CHECK_ROWS(ctx, n, "aqg_unary");
     if (n == 0) return AQG_OK;
     unsigned grid = aqg_grid(ctx, n, 256, 4, 16);
     if (op == AQG_UN_SQRT) {
         if (ot != AQG_DOUBLE) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_unary: sqrt yields double");
+        if (!dt_is_num(t)) return aqg_fail(ctx, AQG_ERR_DTYPE, "unary: the column dtype is not numeric (128-bit results are not inputs)");
         return aqg_dispatch_num(t, [&](auto tt) -> int {
             using T = typename decltype(tt)::type;
             hipLaunchKernelGGL(sqrt_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, (const T*)x, (double*)out, n);

@@ -117,7 +117,7 @@ template <bool INDEX>
 int run_compact(aqg_ctx* ctx, int t, const void* x, const uint8_t* mask, uint32_t n, void* out, uint32_t* idx_out, uint32_t* m_host) {
     *m_host = 0;
     if (n == 0) return AQG_OK;
-    uint32_t ntiles = (n + CTS - 1) / CTS;
+    uint32_t ntiles = aqg_ceil_div(n, CTS);
     AQG_TRY(aqg_ws_reset(ctx));
     AQG_TRY(aqg_ws_ensure(ctx, (size_t)(ntiles + 1) * 4 + ((size_t)ntiles / 2048 + 4) * 4 + 8192));
     uint32_t* tcnt;
@@ -154,6 +154,7 @@ extern "C" {
 int aqg_gather(aqg_ctx* ctx, int t, const void* x, const uint32_t* idx, uint32_t m, void* out) {
     if (!ctx || ((!x || !idx || !out) && m)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_gather: bad argument");
     if (m == 0) return AQG_OK;
+    AQG_CHECK_ROWS(ctx, m, "aqg_gather");
     unsigned grid = aqg_grid(ctx, m, 256, 4, 16);
     switch (aqg_dtype_size(t)) {
     case 1: hipLaunchKernelGGL((gather_kernel<uint8_t>), dim3(grid), dim3(256), 0, ctx->stream, (const uint8_t*)x, idx, m, (uint8_t*)out); break;
@@ -168,11 +169,13 @@ int aqg_gather(aqg_ctx* ctx, int t, const void* x, const uint32_t* idx, uint32_t
 
 int aqg_compact(aqg_ctx* ctx, int t, const void* x, const uint8_t* mask, uint32_t n, void* out, uint32_t* m_host) {
     if (!ctx || !m_host || ((!x || !mask || !out) && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_compact: bad argument");
+    AQG_CHECK_ROWS(ctx, n, "aqg_compact");
     return run_compact<false>(ctx, t, x, mask, n, out, nullptr, m_host);
 }
 
 int aqg_mask_to_index(aqg_ctx* ctx, const uint8_t* mask, uint32_t n, uint32_t* idx_out, uint32_t* m_host) {
     if (!ctx || !m_host || ((!mask || !idx_out) && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_mask_to_index: bad argument");
+    AQG_CHECK_ROWS(ctx, n, "aqg_mask_to_index");
     return run_compact<true>(ctx, AQG_UINT32, nullptr, mask, n, nullptr, idx_out, m_host);
 }
 

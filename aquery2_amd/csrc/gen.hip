@@ -60,6 +60,7 @@ extern "C" int aqg_gen_column(aqg_ctx* ctx, int col, uint64_t seed, uint64_t row
                               uint32_t K, void* out_dev) {
     if (!ctx || (!out_dev && n) || K == 0 || col < 0 || col > AQG_GEN_PRICE) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_gen_column: bad argument");
     if (n == 0) return AQG_OK;
+    AQG_CHECK_ROWS(ctx, n, "aqg_gen_column");
     if ((uintptr_t)out_dev & 15) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_gen_column: output must be 16-byte aligned");
     uint64_t big = n_total / K;
     if (big < 1) big = 1;

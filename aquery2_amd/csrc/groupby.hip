@@ -947,7 +947,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     }
     const uint64_t lds_group_cap = use_lds ? (uint64_t)npass * (lcap - (lcap >> 2)) : 0;
     const bool small_rank = hint <= 4096;
-    const uint32_t nwords = (n + 31) / 32, ntiles = (nwords + 1023) / 1024;
+    const uint32_t nwords = aqg_ceil_div(n, 32), ntiles = aqg_ceil_div(nwords, 1024);
     // groups beyond the LDS tables: partition the rows instead of hammering an HBM table with scattered atomics
     // (partition.hip: h2o Q5, 1e9 rows, 1e7 groups: 42 ms against 141 ms); the build path keeps the HBM table because
     // its second pass looks keys up in it.  AQG_DISABLE_PARTITION=1 forces the HBM table (A/B measurements only).
@@ -1207,6 +1207,7 @@ int aqg_groupby_keys(aqg_groupby* g, int k, void* out_dev) {
 int aqg_groupby_agg(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* const* keys, int naggs, const int* ops,
                     const int* val_dtypes, const void* const* vals, uint32_t n, uint32_t max_groups_hint, aqg_groupby** out) {
     if (!ctx || !out || !key_dtypes || !keys) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_agg: bad argument");
+    AQG_CHECK_ROWS(ctx, n, "aqg_groupby_agg");
     KeySpec ks;
     AQG_TRY(make_keyspec(ctx, nkeys, key_dtypes, keys, n, &ks));
     Plan plan;
@@ -1229,6 +1230,7 @@ int aqg_join_groupby_sum(aqg_ctx* ctx, int key_dtype, const void* dim_keys, int 
     if (!i32(key_dtype) || !i32(dim_val_dtype) || !i32(group_key_dtype) || !i32(val_dtype))
         return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_join_groupby_sum: 4-byte integer columns only");
     if (nb > 4096) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_join_groupby_sum: the dimension side must fit LDS (<= 4096 rows)");
+    AQG_CHECK_ROWS(ctx, n, "aqg_join_groupby_sum");
     StarJoin sj;
     sj.dim_keys = static_cast<const uint32_t*>(dim_keys); sj.dim_vals = static_cast<const uint32_t*>(dim_vals); sj.nb = nb;
     sj.dcap = next_pow2((uint64_t)(nb < 8 ? 8 : nb) * 2);
@@ -1256,6 +1258,7 @@ int aqg_join_groupby_sum(aqg_ctx* ctx, int key_dtype, const void* dim_keys, int 
 int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* const* keys, uint32_t n,
                       uint32_t max_groups_hint, aqg_groupby** out) {
     if (!ctx || !out || !key_dtypes || !keys) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_build: bad argument");
+    AQG_CHECK_ROWS(ctx, n, "aqg_groupby_build");
     KeySpec ks;
     AQG_TRY(make_keyspec(ctx, nkeys, key_dtypes, keys, n, &ks));
     Plan plan;

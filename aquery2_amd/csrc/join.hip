@@ -178,6 +178,8 @@ int join_core(aqg_ctx* ctx, int t, const void* bk, uint32_t nb, const void* pk, 
               uint64_t capacity, uint64_t* m_host) {
     *m_host = 0;
     if (!key_dtype_ok(t)) return aqg_fail(ctx, AQG_ERR_DTYPE, "join: integer key columns only");
+    AQG_CHECK_ROWS(ctx, nb, "join");
+    AQG_CHECK_ROWS(ctx, np, "join");
     if (nb == 0 || np == 0) return AQG_OK;
     // 1. group the build side (dense ids, counts, descending row lists)
     aqg_groupby* gb = nullptr;
@@ -229,6 +231,8 @@ extern "C" {
 int aqg_join_lookup(aqg_ctx* ctx, int t, const void* bk, uint32_t nb, const void* pk, uint32_t np, uint32_t* out) {
     if (!ctx || (!bk && nb) || (!pk && np) || (!out && np)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_join_lookup: bad argument");
     if (!key_dtype_ok(t)) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_join_lookup: integer key columns only");
+    AQG_CHECK_ROWS(ctx, nb, "aqg_join_lookup");
+    AQG_CHECK_ROWS(ctx, np, "aqg_join_lookup");
     if (np == 0) return AQG_OK;
     AQG_TRY(aqg_ws_reset(ctx));
     AQG_TRY(aqg_ws_ensure(ctx, (size_t)pow2_at_least((uint64_t)nb * 2) * 12 + 8192));

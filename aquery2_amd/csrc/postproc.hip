@@ -199,7 +199,7 @@ extern "C" int aqg_groupby_postproc(aqg_groupby* g, uint32_t* offsets_dev, uint3
     aqg_ctx* ctx = g->ctx;
     if (!g->has_reversemap || !g->has_counts) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_postproc: handle was not made by aqg_groupby_build");
     const uint32_t n = g->n, G = g->ngroups;
-    const uint32_t ntiles = (n + RT - 1) / RT;
+    const uint32_t ntiles = aqg_ceil_div(n, RT);
     uint32_t bits = 0;
     while (bits < 32 && (1ull << bits) < G) ++bits;
     const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;

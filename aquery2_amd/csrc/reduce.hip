@@ -257,7 +257,9 @@ int aqg_reduce_out_dtype(int op, int t) {
 int aqg_reduce(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, void* out_host16) {
     if (!ctx || !out_host16 || (!x && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_reduce: bad argument");
     if (op < 0 || op > AQG_RED_LAST) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_reduce: bad op");
+    AQG_CHECK_ROWS(ctx, n, "aqg_reduce");
     memset(out_host16, 0, 16);
+    if (!dt_is_num(t)) return aqg_fail(ctx, AQG_ERR_DTYPE, "reduction: the column dtype is not numeric (128-bit results are not inputs)");
     return aqg_dispatch_num(t, [&](auto tt) -> int {
         using T = typename decltype(tt)::type;
         constexpr bool FP = std::is_floating_point_v<T>;
@@ -315,7 +317,9 @@ int aqg_reduce(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, void* out
 int aqg_reduce_dev(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, void* out_dev16) {
     if (!ctx || !out_dev16 || (!x && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_reduce_dev: bad argument");
     if (op == AQG_RED_AVG || op == AQG_RED_VAR || op == AQG_RED_STDDEV) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_reduce_dev: op needs the host epilogue");
+    AQG_CHECK_ROWS(ctx, n, "aqg_reduce_dev");
     AQG_HIP(ctx, hipMemsetAsync(out_dev16, 0, 16, ctx->stream));
+    if (!dt_is_num(t)) return aqg_fail(ctx, AQG_ERR_DTYPE, "reduction: the column dtype is not numeric (128-bit results are not inputs)");
     return aqg_dispatch_num(t, [&](auto tt) -> int {
         using T = typename decltype(tt)::type;
         const T* xp = static_cast<const T*>(x);
@@ -341,6 +345,7 @@ int aqg_reduce_dev(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, void*
 
 int aqg_corr(aqg_ctx* ctx, int tx, const void* x, int ty, const void* y, uint32_t n, double* out_host) {
     if (!ctx || !out_host || ((!x || !y) && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_corr: bad argument");
+    AQG_CHECK_ROWS(ctx, n, "aqg_corr");
     if (dt_is_fp(tx) || dt_is_fp(ty)) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_corr: floating inputs are accumulated with per-step truncation in the reference; not offered on device");
     int inner = aqg_coercion(tx, ty);
     if (inner == AQG_ERROR || inner == AQG_STR) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_corr: no coercion");

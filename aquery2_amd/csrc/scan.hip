@@ -581,7 +581,7 @@ template <class T> struct sq_alg {   // tile aggregate of x*x in double
 template <class T, class ALG, int WR>
 int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out) {
     using A = typename ALG::A;
-    uint32_t ntiles = (n + TS - 1) / TS;
+    uint32_t ntiles = aqg_ceil_div(n, TS);
     const uint32_t nlinks = (ntiles + chain_m<T>() - 1) / chain_m<T>();
     constexpr size_t osz = WR == W_SUMS ? (std::is_floating_point_v<T> ? 8 : 16) : WR == W_AVGS ? 8 : sizeof(T);
     constexpr int PW = std::is_same_v<A, aqg_i128> ? 2 : 1;
@@ -644,14 +644,16 @@ int aqg_scan_out_dtype(int op, int t) {
 int aqg_scan(aqg_ctx* ctx, int op, int t, const void* xv, uint32_t n, uint32_t w, void* out) {
     if (!ctx || (!xv && n) || (!out && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_scan: bad argument");
     if (op < 0 || op > AQG_SCAN_STDDEVW) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_scan: bad op");
+    AQG_CHECK_ROWS(ctx, n, "aqg_scan");
     // w == 0 is undefined in the reference for sumw/avgw/varw (reads ret[-1], divides by zero)
     if (w == 0 && (op == AQG_SCAN_SUMW || op == AQG_SCAN_AVGW || op == AQG_SCAN_VARW || op == AQG_SCAN_STDDEVW))
         return aqg_fail(ctx, AQG_ERR_ARG, "aqg_scan: window 0 is undefined for sumw/avgw/varw");
     if (n == 0) return AQG_OK;
+    if (!dt_is_num(t)) return aqg_fail(ctx, AQG_ERR_DTYPE, "scan: the column dtype is not numeric (128-bit results are not inputs)");
     return aqg_dispatch_num(t, [&](auto tt) -> int {
         using T = typename decltype(tt)::type;
         const T* x = static_cast<const T*>(xv);
-        const uint32_t ntiles = (n + TS - 1) / TS;
+        const uint32_t ntiles = aqg_ceil_div(n, TS);
         unsigned sgrid = aqg_grid(ctx, n, SB, 4, 16);
         switch (op) {
         case AQG_SCAN_SUMS: return run_prefix<T, sum_alg<T>, W_SUMS>(ctx, x, n, out);

@@ -52,6 +52,11 @@ enum {
     AQG_ERR_OVERFLOW = 6   /* table / workspace capacity exceeded              */
 };
 
+/* Largest supported row count of one column.  Sizes are uint32_t like the reference's (server/vector_type.hpp:66); the tile
+ * kernels compute row indices in 32 bits with up to one tile / one grid stride of slack, so counts within 2^20 of 2^32 are
+ * rejected with AQG_ERR_ARG instead of wrapping. */
+#define AQG_MAX_ROWS 4293918720u   /* 2^32 - 2^20 */
+
 typedef struct aqg_ctx aqg_ctx;
 
 /* ---- type rules (host, pure) ----------------------------------------------

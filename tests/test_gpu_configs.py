@@ -192,3 +192,58 @@ def test_full_size_properties_q5_and_windows(gpu):
     sw = gpu.scan(ck.SCAN_SUMW, price, n, keep=True)      # window = whole column: last element is the column sum
     last = sw.to_host()[-1]
     assert (int(last["hi"]) << 64) + int(last["lo"]) == int(gpu.reduce(ck.RED_SUM, price))
+
+
+def test_maximum_row_count(gpu):
+    """n = AQG_MAX_ROWS - 1 = 2^32 - 2^20 - 1 rows (sizes are uint32_t, server/vector_type.hpp:66; the last 2^20 counts are
+    rejected, see include/aqg.h): every index computation near the 32-bit limit.
+    Properties only (17 GB per column): Q1 sums add up to the column sum, counts to n; scans / windows / shifts agree at
+    the far end with values recomputed on the host from the device's own tail; unaligned tail (n % 4 == 3)."""
+    import aquery2_amd
+    n = 2**32 - 2**20 - 1
+    with pytest.raises(aquery2_amd.capi.AqgError, match="AQG_MAX_ROWS"):
+        gpu.gen_column(ck.GEN_V1, 42, 0, 2**32 - 1, 2**32 - 1, K)
+    id1 = gpu.gen_column(ck.GEN_ID1, 42, 0, n, n, K)
+    v1 = gpu.gen_column(ck.GEN_V1, 42, 0, n, n, K)
+    total = int(gpu.reduce(ck.RED_SUM, v1))
+    assert n <= total <= 5 * n
+    gb = gpu.groupby_agg([id1], [ck.RED_SUM, ck.RED_COUNT], [v1, v1], hint=128)
+    assert gb.ngroups == 100
+    assert sum(ck.i128_to_int(gb.result(0, ck.RED_SUM, ck.INT32))) == total
+    assert int(gb.result(1, ck.RED_COUNT, ck.INT32).astype(np.uint64).sum()) == n
+    assert int(gb.counts().astype(np.uint64).sum()) == n
+    assert np.array_equal(np.sort(gb.keys(0, np.int32)), np.arange(1, 101))
+    assert gb.first_rows().max() < 5000
+    gb.destroy()
+    # last rows of running sum / max / window sum / deltas against a host recomputation of the tail
+    tail = 1000
+    sums = gpu.scan(ck.SCAN_SUMS, v1, keep=True)
+    got_last = ck.i128_to_int(aquery2_amd.DevBuf(gpu, sums.ptr + (n - tail) * 16, ck.I128, tail, owned=False).to_host())
+    assert got_last[-1] == total
+    v_tail = aquery2_amd.DevBuf(gpu, v1.ptr + (n - tail) * 4, np.int32, tail, owned=False).to_host().astype(np.int64)
+    assert got_last == list(np.int64(total) - np.concatenate([np.cumsum(v_tail[::-1])[::-1][1:], [0]]))
+    sums.free()
+    w = gpu.scan(ck.SCAN_SUMW, v1, 7, keep=True)
+    w_tail = ck.i128_to_int(aquery2_amd.DevBuf(gpu, w.ptr + (n - 100) * 16, ck.I128, 100, owned=False).to_host())
+    ref = np.convolve(v_tail, np.ones(7, dtype=np.int64))[: tail][-100:]
+    assert w_tail == ref.tolist()
+    w.free()
+    dl = gpu.scan(ck.SCAN_DELTAS, v1, keep=True)
+    d_tail = aquery2_amd.DevBuf(gpu, dl.ptr + (n - 100) * 4, np.int32, 100, owned=False).to_host()
+    assert np.array_equal(d_tail, np.diff(v_tail)[-100:].astype(np.int32))
+    dl.free()
+    mx = gpu.scan(ck.SCAN_MAXS, v1, keep=True)
+    assert int(aquery2_amd.DevBuf(gpu, mx.ptr + (n - 1) * 4, np.int32, 1, owned=False).to_host()[0]) == 5
+    mx.free()
+    plus = gpu.ewise(ck.OP_ADD, v1, np.int32(1), keep=True)                 # int32 + int32 -> int32
+    assert int(gpu.reduce(ck.RED_SUM, plus)) == total + n
+    plus.free()
+    import ctypes
+    kept = ctypes.c_uint32()
+    mask = gpu.ewise(ck.OP_GT, v1, np.int32(4), keep=True)
+    out = gpu.empty(n, np.int32)
+    gpu._chk(gpu.lib.aqg_compact(gpu.ctx, ck.INT32, ctypes.c_void_p(v1.ptr), ctypes.c_void_p(mask.ptr), ctypes.c_uint32(n), ctypes.c_void_p(out.ptr),
+                                 ctypes.byref(kept)), "aqg_compact")
+    fives = aquery2_amd.DevBuf(gpu, out.ptr, np.int32, kept.value, owned=False)
+    assert int(gpu.reduce(ck.RED_MIN, fives)) == 5 and int(gpu.reduce(ck.RED_SUM, fives)) == 5 * kept.value
+    assert abs(kept.value / n - 0.2) < 1e-3
