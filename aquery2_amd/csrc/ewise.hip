@@ -99,10 +99,10 @@ template <int OP, class C, class OT> __device__ inline OT apply(C a, C b) {
 }
 
 template <int OP, class C, class OT>
-__device__ inline void ewise_body(int kind, int lt, const void* l, int rt, const void* r, C sc, OT* out, uint32_t n) {
+__device__ inline void ewise_body(int kind, int lt, const void* l, int rt, const void* r, C sc, OT* out, uint32_t n, int vec_ok) {
     constexpr int E = elems_for<OT>();
     constexpr int UNR = E >= 16 ? 1 : (16 / E > 8 ? 8 : 16 / E);   // ~16 elements in flight per lane
-    const uint32_t nvec = n / E;
+    const uint32_t nvec = vec_ok ? n / E : 0;                       // operands not 16-byte aligned: everything goes the scalar way
     const uint32_t stride = blockDim.x;                      // a workgroup covers UNR * 256 consecutive vectors per step (one 4-64 KB span)
     for (uint64_t c = blockIdx.x; c * UNR * blockDim.x < nvec; c += gridDim.x) {
         const uint32_t v0 = (uint32_t)(c * UNR * blockDim.x) + threadIdx.x;
@@ -133,34 +133,31 @@ __device__ inline void ewise_body(int kind, int lt, const void* l, int rt, const
             }
         }
     }
-    if (blockIdx.x == 0) {
-        uint32_t i = nvec * E + threadIdx.x;
-        if (i < n) {
-            C a = kind == AQG_SCALAR_VEC ? sc : load_one<C>(l, lt, i);
-            C b = kind == AQG_VEC_SCALAR ? sc : load_one<C>(r, rt, i);
-            out[i] = apply<OP, C, OT>(a, b);
-        }
+    for (uint64_t i = (uint64_t)nvec * E + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        C a = kind == AQG_SCALAR_VEC ? sc : load_one<C>(l, lt, i);
+        C b = kind == AQG_VEC_SCALAR ? sc : load_one<C>(r, rt, i);
+        out[i] = apply<OP, C, OT>(a, b);
     }
 }
 
 template <class C, class OT>
 __global__ void __launch_bounds__(256) ewise_kernel(int op, int kind, int lt, const void* __restrict__ l, int rt,
-                                                    const void* __restrict__ r, C sc, OT* __restrict__ out, uint32_t n) {
+                                                    const void* __restrict__ r, C sc, OT* __restrict__ out, uint32_t n, int vec_ok) {
     switch (op) { // wave-uniform
-    case AQG_OP_ADD: ewise_body<AQG_OP_ADD>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_SUB: ewise_body<AQG_OP_SUB>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_MUL: ewise_body<AQG_OP_MUL>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_DIV: ewise_body<AQG_OP_DIV>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_MOD: ewise_body<AQG_OP_MOD>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_AND: ewise_body<AQG_OP_AND>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_OR: ewise_body<AQG_OP_OR>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_XOR: ewise_body<AQG_OP_XOR>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_GT: ewise_body<AQG_OP_GT>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_LT: ewise_body<AQG_OP_LT>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_GE: ewise_body<AQG_OP_GE>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_LE: ewise_body<AQG_OP_LE>(kind, lt, l, rt, r, sc, out, n); break;
-    case AQG_OP_EQ: ewise_body<AQG_OP_EQ>(kind, lt, l, rt, r, sc, out, n); break;
-    default: ewise_body<AQG_OP_NE>(kind, lt, l, rt, r, sc, out, n); break;
+    case AQG_OP_ADD: ewise_body<AQG_OP_ADD>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_SUB: ewise_body<AQG_OP_SUB>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_MUL: ewise_body<AQG_OP_MUL>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_DIV: ewise_body<AQG_OP_DIV>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_MOD: ewise_body<AQG_OP_MOD>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_AND: ewise_body<AQG_OP_AND>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_OR: ewise_body<AQG_OP_OR>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_XOR: ewise_body<AQG_OP_XOR>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_GT: ewise_body<AQG_OP_GT>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_LT: ewise_body<AQG_OP_LT>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_GE: ewise_body<AQG_OP_GE>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_LE: ewise_body<AQG_OP_LE>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    case AQG_OP_EQ: ewise_body<AQG_OP_EQ>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
+    default: ewise_body<AQG_OP_NE>(kind, lt, l, rt, r, sc, out, n, vec_ok); break;
     }
 }
 
@@ -196,7 +193,7 @@ template <class C> C host_scalar(int dt, const void* p) {
 }
 
 template <class C, class OT>
-int launch_ewise(aqg_ctx* ctx, int op, int kind, int lt, const void* l, int rt, const void* r, void* out, uint32_t n) {
+int launch_ewise(aqg_ctx* ctx, int op, int kind, int lt, const void* l, int rt, const void* r, void* out, uint32_t n, int vec_ok) {
     if constexpr (std::is_same_v<OT, aqg_i128> && std::is_floating_point_v<C>) {
         return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_ewise: 128-bit result from floating arithmetic");
     } else {
@@ -206,25 +203,25 @@ int launch_ewise(aqg_ctx* ctx, int op, int kind, int lt, const void* l, int rt, 
         unsigned grid = aqg_grid(ctx, n / 8 + 1, 256, 1, 16);
         hipLaunchKernelGGL((ewise_kernel<C, OT>), dim3(grid), dim3(256), 0, ctx->stream, op, kind, lt,
                            kind == AQG_SCALAR_VEC ? nullptr : l, rt, kind == AQG_VEC_SCALAR ? nullptr : r, sc,
-                           static_cast<OT*>(out), n);
+                           static_cast<OT*>(out), n, vec_ok);
         return aqg_check_launch(ctx, "ewise_kernel");
     }
 }
 
-template <class C> int dispatch_ot(aqg_ctx* ctx, int ot, int op, int kind, int lt, const void* l, int rt, const void* r, void* out, uint32_t n) {
+template <class C> int dispatch_ot(aqg_ctx* ctx, int ot, int op, int kind, int lt, const void* l, int rt, const void* r, void* out, uint32_t n, int vec_ok) {
     switch (ot) {
-    case AQG_INT8: return launch_ewise<C, int8_t>(ctx, op, kind, lt, l, rt, r, out, n);
-    case AQG_INT16: return launch_ewise<C, int16_t>(ctx, op, kind, lt, l, rt, r, out, n);
-    case AQG_INT32: return launch_ewise<C, int32_t>(ctx, op, kind, lt, l, rt, r, out, n);
-    case AQG_INT64: return launch_ewise<C, int64_t>(ctx, op, kind, lt, l, rt, r, out, n);
-    case AQG_UINT8: return launch_ewise<C, uint8_t>(ctx, op, kind, lt, l, rt, r, out, n);
-    case AQG_UINT16: return launch_ewise<C, uint16_t>(ctx, op, kind, lt, l, rt, r, out, n);
-    case AQG_UINT32: return launch_ewise<C, uint32_t>(ctx, op, kind, lt, l, rt, r, out, n);
-    case AQG_UINT64: return launch_ewise<C, uint64_t>(ctx, op, kind, lt, l, rt, r, out, n);
-    case AQG_FLOAT: return launch_ewise<C, float>(ctx, op, kind, lt, l, rt, r, out, n);
-    case AQG_DOUBLE: return launch_ewise<C, double>(ctx, op, kind, lt, l, rt, r, out, n);
-    case AQG_BOOL: return launch_ewise<C, bool>(ctx, op, kind, lt, l, rt, r, out, n);
-    case AQG_INT128: case AQG_UINT128: return launch_ewise<C, aqg_i128>(ctx, op, kind, lt, l, rt, r, out, n);
+    case AQG_INT8: return launch_ewise<C, int8_t>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_INT16: return launch_ewise<C, int16_t>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_INT32: return launch_ewise<C, int32_t>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_INT64: return launch_ewise<C, int64_t>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_UINT8: return launch_ewise<C, uint8_t>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_UINT16: return launch_ewise<C, uint16_t>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_UINT32: return launch_ewise<C, uint32_t>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_UINT64: return launch_ewise<C, uint64_t>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_FLOAT: return launch_ewise<C, float>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_DOUBLE: return launch_ewise<C, double>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_BOOL: return launch_ewise<C, bool>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_INT128: case AQG_UINT128: return launch_ewise<C, aqg_i128>(ctx, op, kind, lt, l, rt, r, out, n, vec_ok);
     }
     return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_ewise: unsupported result dtype");
 }
@@ -268,17 +265,17 @@ int aqg_ewise(aqg_ctx* ctx, int op, int kind, int lt, const void* l, int rt, con
     int c = usual_conv(lt, rt);
     if ((c == AQG_FLOAT || c == AQG_DOUBLE) && (op == AQG_OP_MOD || op == AQG_OP_AND || op == AQG_OP_OR || op == AQG_OP_XOR))
         return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_ewise: bitwise/mod on floating operands");
-    // chunk loads need E*sizeof(T)-aligned bases (capped at 16): device allocations always are
-    auto aligned = [](const void* p, int) { return ((uintptr_t)p & 15) == 0; };
-    if ((kind != AQG_SCALAR_VEC && !aligned(l, lt)) || (kind != AQG_VEC_SCALAR && !aligned(r, rt)) || !aligned(out, ot))
-        return aqg_fail(ctx, AQG_ERR_ARG, "aqg_ewise: operands must be 16-byte aligned");
+    // chunk loads need 16-byte aligned bases (device allocations are; sub-views of a column may not be: those take the
+    // element-at-a-time path of the same kernel)
+    auto aligned = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    const int vec_ok = (kind == AQG_SCALAR_VEC || aligned(l)) && (kind == AQG_VEC_SCALAR || aligned(r)) && aligned(out);
     switch (c) {
-    case AQG_INT32: return dispatch_ot<int32_t>(ctx, ot, op, kind, lt, l, rt, r, out, n);
-    case AQG_UINT32: return dispatch_ot<uint32_t>(ctx, ot, op, kind, lt, l, rt, r, out, n);
-    case AQG_INT64: return dispatch_ot<int64_t>(ctx, ot, op, kind, lt, l, rt, r, out, n);
-    case AQG_UINT64: return dispatch_ot<uint64_t>(ctx, ot, op, kind, lt, l, rt, r, out, n);
-    case AQG_FLOAT: return dispatch_ot<float>(ctx, ot, op, kind, lt, l, rt, r, out, n);
-    default: return dispatch_ot<double>(ctx, ot, op, kind, lt, l, rt, r, out, n);
+    case AQG_INT32: return dispatch_ot<int32_t>(ctx, ot, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_UINT32: return dispatch_ot<uint32_t>(ctx, ot, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_INT64: return dispatch_ot<int64_t>(ctx, ot, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_UINT64: return dispatch_ot<uint64_t>(ctx, ot, op, kind, lt, l, rt, r, out, n, vec_ok);
+    case AQG_FLOAT: return dispatch_ot<float>(ctx, ot, op, kind, lt, l, rt, r, out, n, vec_ok);
+    default: return dispatch_ot<double>(ctx, ot, op, kind, lt, l, rt, r, out, n, vec_ok);
     }
 }
 

@@ -1,0 +1,120 @@
+"""GPU parity at the edges: empty and tiny inputs, sizes around every tile boundary (64 / 256 / 2048 / 4096 / 8192) and columns
+that start at addresses aligned only to their element size (the vector paths need 16 bytes and must fall back cleanly)."""
+import numpy as np
+import pytest
+
+import checker as ck
+import golden_util as gu
+from test_gpu_basic import rand
+
+pytestmark = pytest.mark.gpu
+SIZES = [0, 1, 2, 3, 5, 63, 64, 65, 255, 257, 2047, 2049, 4097, 8193, 12289]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import aquery2_amd
+    d = aquery2_amd.Device(0)
+    yield d
+    d.close()
+
+
+def view(gpu, a, off):
+    """device copy of `a` whose first element sits `off` elements past a 256-byte aligned allocation"""
+    import aquery2_amd
+    pad = np.concatenate([np.zeros(off, a.dtype), a]) if off else a
+    base = gpu.to_device(pad if len(pad) else np.zeros(1, a.dtype))
+    v = aquery2_amd.DevBuf(gpu, base.ptr + off * a.itemsize, a.dtype, len(a), owned=False)
+    v._base = base
+    return v
+
+
+@pytest.mark.parametrize("off", [0, 1, 3])
+def test_ewise_and_reduce_sizes(gpu, oracle, off):
+    rng = np.random.default_rng(100 + off)
+    for n in SIZES:
+        for lt, rt, op in ((np.int32, np.int32, ck.OP_ADD), (np.int8, np.int16, ck.OP_MUL), (np.float32, np.float64, ck.OP_DIV),
+                           (np.int64, np.int32, ck.OP_GT), (np.uint8, np.uint8, ck.OP_SUB)):
+            x, y = rand(rng, lt, n, small=True), rand(rng, rt, n, small=True)
+            if op == ck.OP_DIV:
+                y = np.where(y == 0, 1, y).astype(rt)
+            assert gu.same_bits(gpu.ewise(op, view(gpu, x, off), view(gpu, y, off)), oracle.ewise(op, x, y)), (n, lt, rt, op)
+            assert gu.same_bits(gpu.ewise(op, view(gpu, x, off), y[:1][0] if n else rt(3)), oracle.ewise(op, x, y[:1][0] if n else rt(3))), (n, "scalar")
+        for dt in (np.int32, np.int8, np.uint64, np.float32):
+            x = rand(rng, dt, n, small=True)
+            for op in (ck.RED_SUM, ck.RED_MIN, ck.RED_MAX, ck.RED_COUNT) + ((ck.RED_AVG, ck.RED_FIRST, ck.RED_LAST) if n else ()):
+                a, b = gpu.reduce(op, view(gpu, x, off)), oracle.reduce(op, x)
+                if np.dtype(dt).kind == "f" and op in (ck.RED_SUM, ck.RED_AVG):
+                    assert abs(float(a) - float(b)) <= 1e-6 * max(1.0, abs(float(b))), (n, dt, op)
+                else:
+                    assert np.asarray(a).tobytes() == np.asarray(b).tobytes() or a == b, (n, dt, op, a, b)
+
+
+@pytest.mark.parametrize("off", [0, 1])
+def test_scan_sizes_and_windows(gpu, oracle, off):
+    rng = np.random.default_rng(200 + off)
+    for n in SIZES:
+        x = rand(rng, np.int32, n, small=True)
+        xv = view(gpu, x, off)
+        for name in ("sums", "mins", "maxs", "avgs", "deltas", "prev", "aggnext"):
+            assert gu.same_bits(gpu.scan(ck.SCAN_NAMES[name], xv), oracle.scan(ck.SCAN_NAMES[name], x)), (n, name)
+        for w in (1, 2, 3, 7, 64, 100, max(n, 1), n + 5):
+            for name in ("sumw", "minw", "maxw"):
+                assert gu.same_bits(gpu.scan(ck.SCAN_NAMES[name], xv, w), oracle.scan(ck.SCAN_NAMES[name], x, w)), (n, name, w)
+            a, b = gpu.scan(ck.SCAN_AVGW, xv, w), oracle.scan(ck.SCAN_AVGW, x, w)
+            assert np.all(np.abs(a - b) <= 1e-9 * np.maximum(1.0, np.abs(b)) * (np.arange(n) + 2)), (n, "avgw", w)
+        f = np.round(rng.uniform(-50, 50, n), 3).astype(np.float64)
+        fv = view(gpu, f, off)
+        for name in ("mins", "maxs", "deltas"):
+            assert gu.same_bits(gpu.scan(ck.SCAN_NAMES[name], fv), oracle.scan(ck.SCAN_NAMES[name], f)), (n, name, "f64")
+        for w in (1, 3, 100):
+            assert gu.same_bits(gpu.scan(ck.SCAN_MINW, fv, w), oracle.scan(ck.SCAN_MINW, f, w)), (n, "minw f64", w)
+
+
+@pytest.mark.parametrize("off", [0, 1])
+def test_gather_compact_sizes(gpu, off):
+    rng = np.random.default_rng(300 + off)
+    for n in SIZES:
+        for dt in (np.int32, np.int8, np.float64):
+            x = rand(rng, dt, max(n, 1), small=True)
+            idx = rng.integers(0, len(x), n).astype(np.uint32)
+            assert gu.same_bits(gpu.gather(view(gpu, x, off), view(gpu, idx, off)), x[idx]), (n, dt)
+            m = rng.integers(0, 2, n).astype(np.uint8)
+            xs = x[:n]
+            assert gu.same_bits(gpu.compact(view(gpu, xs, off), view(gpu, m, off)), xs[m != 0]), (n, dt)
+        m = rng.integers(0, 2, n).astype(np.uint8)
+        assert np.array_equal(gpu.mask_to_index(view(gpu, m, off)), np.nonzero(m)[0].astype(np.uint32)), n
+
+
+@pytest.mark.parametrize("off", [0, 1])
+def test_groupby_and_join_sizes(gpu, oracle, off):
+    rng = np.random.default_rng(400 + off)
+    for n in SIZES:
+        k1 = rng.integers(-3, 4, n).astype(np.int32)
+        k2 = rng.integers(0, 3, n).astype(np.int16)
+        v = rand(rng, np.int32, n, small=True)
+        for keys in ([k1], [k1, k2]):
+            o = oracle.groupby(keys)
+            g = gpu.groupby_build([view(gpu, k, off) for k in keys])
+            assert g.ngroups == o["ngroups"], n
+            if n:
+                assert np.array_equal(g.reversemap(), o["reversemap"]) and np.array_equal(g.counts(), o["counts"])
+                offs, rows = g.postproc()
+                assert np.array_equal(offs, np.concatenate([[0], np.cumsum(o["counts"])]).astype(np.uint32))
+                for gi in range(o["ngroups"]):
+                    seg = rows[offs[gi]:offs[gi + 1]]
+                    assert np.all(np.diff(seg.astype(np.int64)) < 0) and np.all(o["reversemap"][seg] == gi)
+            g.destroy()
+            gb = gpu.groupby_agg([view(gpu, k, off) for k in keys], [ck.RED_SUM, ck.RED_MAX, ck.RED_COUNT], [view(gpu, v, off)] * 3)
+            assert gb.ngroups == o["ngroups"], n
+            if n:
+                assert np.array_equal(gb.first_rows(), o["first_rows"])
+                for j, op in enumerate((ck.RED_SUM, ck.RED_MAX, ck.RED_COUNT)):
+                    assert gu.same_bits(gb.result(j, op, ck.INT32), oracle.grouped_reduce(op, v, o)), (n, op)
+            gb.destroy()
+        nb = n // 3
+        bk = rng.permutation(np.arange(nb + 2, dtype=np.int32))[:nb]
+        pk = rng.integers(0, nb + 4, n).astype(np.int32)
+        look = gpu.join_lookup(view(gpu, bk, off), view(gpu, pk, off))
+        pos = {int(k): i for i, k in enumerate(bk.tolist())}
+        assert np.array_equal(look, np.array([pos.get(int(k), 0xFFFFFFFF) for k in pk.tolist()], dtype=np.uint32)), n
