@@ -4,6 +4,9 @@
 // follow the reference: `+ -` Coercion, `*` GetLongType, `/` GetFPType, comparisons bool.
 #pragma once
 #include <algorithm>
+#include <map>
+#include <memory>
+#include <unordered_set>
 #include <cstdarg>
 #include <cstdio>
 #include <iostream>
@@ -172,6 +175,39 @@ public:
     ColRef_cstorage s() { ColRef_cstorage c{this->container, this->size, this->capacity, name, (int)ty}; return c; }
 };
 template <> class ColRef<void> : public ColRef<int> {};
+
+// ColView: a column seen through a row-id list (reference :262-343).  Element access goes through the host copies; converting
+// to a ColRef materialises the view with one device gather.
+template <typename _Ty>
+class ColView : public vector_base<_Ty> {
+public:
+    typedef ColRef<_Ty> Decayed_t;
+    const uint32_t size;
+    const ColRef<_Ty>& orig;
+    vector_type<uint32_t> idxs;
+    ColView(const ColRef<_Ty>& o, vector_type<uint32_t>&& ix) : size(ix.size), orig(o), idxs(std::move(ix)) {}
+    ColView(const ColRef<_Ty>& o, const vector_type<uint32_t>& ix) : size(ix.size), orig(o), idxs(ix) {}
+    ColView(const ColView<_Ty>& v, const vector_type<uint32_t>& ix) : size(ix.size), orig(v.orig), idxs(ix) {
+        for (uint32_t i = 0; i < size; ++i) idxs[i] = v.idxs[ix[i]];
+    }
+    _Ty& operator[](const uint32_t& i) const { return orig[idxs[i]]; }
+    operator ColRef<_Ty>() { ColRef<_Ty> ret; static_cast<vector_type<_Ty>&>(ret) = orig[idxs]; return ret; }
+    ColView<_Ty> subvec(uint32_t start, uint32_t end) const { return ColView<_Ty>(orig, idxs.subvec(start, end)); }
+    ColRef<_Ty> subvec_deep(uint32_t start, uint32_t end) const {
+        ColRef<_Ty> sub(end - start);
+        for (uint32_t i = 0; i < end - start; ++i) sub[i] = (*this)[start + i];
+        return sub;
+    }
+    std::unordered_set<_Ty> distinct_common() const { std::unordered_set<_Ty> s; for (uint32_t i = 0; i < size; ++i) s.insert((*this)[i]); return s; }
+    uint32_t distinct_size() const { return (uint32_t)distinct_common().size(); }
+    void out(uint32_t n = 1000, const char* sep = " ") const {
+        n = n > size ? size : n;
+        std::cout << '(';
+        for (uint32_t i = 0; i < n; ++i) std::cout << (*this)[i] << sep;
+        std::cout << ')';
+    }
+};
+template <class V> struct is_vector_impl<ColView<V>> : std::true_type {};
 using uColRef = ColRef<void>;
 
 template <class V> struct is_vector_impl<ColRef<V>> : std::true_type {};
@@ -233,6 +269,72 @@ struct TableInfo {
     TableInfo<Types...>* rename(const char* nm) { name = nm; return this; }
     uint32_t rows() const { return std::get<0>(cols).size; }
 
+    // ---- host utilities of the reference (:429-461, :601-614) ------------------------------------------------------------
+    // materialize: every column gathered by the same row ids (one device gather per column)
+    template <int prog = 0>
+    inline void materialize(const vector_type<uint32_t>& idxs, TableInfo<Types...>* tbl = nullptr) {
+        if constexpr (prog == 0) tbl = (tbl == nullptr ? this : tbl);
+        if constexpr (prog == sizeof...(Types)) return;
+        else {
+            auto& col = std::get<prog>(cols);
+            auto gathered = col[idxs];
+            const char* nm = col.name;
+            static_cast<std::remove_reference_t<decltype(gathered)>&>(std::get<prog>(tbl->cols)) = std::move(gathered);
+            std::get<prog>(tbl->cols).name = nm;
+            materialize<prog + 1>(idxs, tbl);
+        }
+    }
+    inline TableInfo<Types...>* materialize_copy(const vector_type<uint32_t>& idxs) {
+        auto tbl = new TableInfo<Types...>(this->name, (uint32_t)sizeof...(Types));
+        materialize<0>(idxs, tbl);
+        return tbl;
+    }
+    // order_by<c0, c1, ...>: row ids sorted by the listed columns (column c >= 0 ascending; -1 - c descending), std::sort on
+    // the host like the reference (not stable, ties in unspecified order)
+    template <int... ocols>
+    inline vector_type<uint32_t>* order_by(vector_type<uint32_t>* ord = nullptr) {
+        const uint32_t n = rows();
+        if (!ord) {
+            ord = new vector_type<uint32_t>(n);
+            for (uint32_t i = 0; i < n; ++i) (*ord)[i] = i;
+        }
+        std::sort(ord->begin(), ord->end(), [this](const uint32_t& l, const uint32_t& r) {
+            return std::make_tuple(order_key<ocols>(l)...) < std::make_tuple(order_key<ocols>(r)...);
+        });
+        return ord;
+    }
+    template <int... ocols> auto order_by_view();
+    // distinct rows, in place.  The reference iterates an unordered_set (order unspecified); here: first-occurrence order --
+    // one device group-by over all columns when they are all integral, a host pass otherwise.
+    TableInfo<Types...>* distinct() {
+        const uint32_t n = rows();
+        if (n == 0) return this;
+        vector_type<uint32_t> keep(0u);
+        if constexpr ((std::is_integral_v<Types> && ...) && (aq::dev::on_device<Types> && ...)) {
+            auto& rt = aq::dev::Runtime::get();
+            int dts[sizeof...(Types)];
+            const void* ptrs[sizeof...(Types)];
+            std::vector<std::unique_ptr<aq::dev::In>> ins;
+            distinct_bind(dts, ptrs, ins, std::index_sequence_for<Types...>{});
+            aqg_groupby* h = nullptr;
+            aq::dev::check(aqg_groupby_build(rt.ctx(), (int)sizeof...(Types), dts, ptrs, n, 0, &h), "aqg_groupby_build");
+            const uint32_t G = aqg_groupby_ngroups(h);
+            keep = vector_type<uint32_t>(G);
+            aq::dev::check(aqg_d2h(rt.ctx(), keep.container, aqg_groupby_first_rows(h), (size_t)G * 4), "aqg_d2h");
+            aq::dev::check(aqg_sync(rt.ctx()), "aqg_sync");
+            aqg_groupby_destroy(h);
+        } else {
+            std::map<tuple_type, uint32_t> seen;
+            std::vector<uint32_t> firsts;
+            for (uint32_t i = 0; i < n; ++i)
+                if (seen.emplace(row_tuple(i, std::index_sequence_for<Types...>{}), i).second) firsts.push_back(i);
+            keep = vector_type<uint32_t>((uint32_t)firsts.size());
+            for (uint32_t i = 0; i < keep.size; ++i) keep[i] = firsts[i];
+        }
+        materialize<0>(keep);
+        return this;
+    }
+
     std::string get_header_string(const char* __restrict sep, const char* __restrict end) const {
         std::string h;
         header_names(h, sep, std::index_sequence_for<Types...>{});
@@ -263,6 +365,17 @@ struct TableInfo {
     }
 
 private:
+    template <int c> auto order_key(uint32_t i) {
+        if constexpr (c >= 0) return std::get<(size_t)c>(cols)[i];
+        else return -std::get<(size_t)(-1 - c)>(cols)[i];
+    }
+    template <size_t... Is> tuple_type row_tuple(uint32_t i, std::index_sequence<Is...>) { return tuple_type(std::get<Is>(cols)[i]...); }
+    template <size_t... Is> void distinct_bind(int* dts, const void** ptrs, std::vector<std::unique_ptr<aq::dev::In>>& ins, std::index_sequence<Is...>) {
+        ((dts[Is] = aq::dev::tag_of<std::tuple_element_t<Is, tuple_type>>::value,
+          ins.push_back(std::make_unique<aq::dev::In>(std::get<Is>(cols).container, (size_t)std::get<Is>(cols).size * sizeof(std::tuple_element_t<Is, tuple_type>),
+                                                      std::get<Is>(cols).capacity == 0)),
+          ptrs[Is] = ins.back()->d), ...);
+    }
     template <size_t... Is> void init_names(const char** names, std::index_sequence<Is...>) { (std::get<Is>(cols).init(names ? names[Is] : ""), ...); }
     template <size_t... Is> void header_names(std::string& h, const char* sep, std::index_sequence<Is...>) const {
         size_t k = 0;
@@ -300,6 +413,22 @@ private:
         }
     }
 };
+
+// TableView: a table seen through a row-id list (reference :620-690); printing goes through `printall`'s view argument
+template <class... Types>
+struct TableView {
+    typedef std::tuple<Types...> tuple_type;
+    const vector_type<uint32_t>* idxs;
+    const TableInfo<Types...>& info;
+    constexpr TableView(const vector_type<uint32_t>* ix, const TableInfo<Types...>& t) noexcept : idxs(ix), info(t) {}
+    void print(const char* __restrict sep, const char* __restrict end) const { info.printall(sep, end, idxs); }
+    TableInfo<Types...>* materialize(const char* name = nullptr, const char** = nullptr) {
+        auto t = const_cast<TableInfo<Types...>&>(info).materialize_copy(*idxs);
+        if (name) t->name = name;
+        return t;
+    }
+};
+template <class... Types> template <int... ocols> auto TableInfo<Types...>::order_by_view() { return TableView<Types...>(order_by<ocols...>(), *this); }
 
 template <class... Types> void print(const TableInfo<Types...>& v, const char* delimiter = " ", const char* endline = "\n") { v.print(delimiter, endline); }
 template <class T, std::enable_if_t<!aq::is_column<T>::value>* = nullptr> void print(const T& v, const char* delimiter = " ") { std::cout << v << delimiter; }

@@ -25,7 +25,7 @@ def run(module, dataset, *funcs, cwd=None):
 def test_emitted_modules_compile():
     """CPU: the generated-shape translation units compile and link against the new library"""
     build()
-    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "host_main"):
+    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "distinct_orderby.so", "host_main"):
         assert os.path.exists(os.path.join(EM, "build", m))
 
 
@@ -123,3 +123,27 @@ def test_group_loop_many_groups_uses_one_kernel_per_aggregate():
     assert [int(r[3]) for r in rows] == [cnts[k] for k in order]
     assert all(abs(float(r[4]) - sums[k] / cnts[k]) < 1e-3 for r, k in zip(rows, order))
     assert dt < 60
+
+
+@pytest.mark.gpu
+def test_distinct_order_by_materialize_colview():
+    """TableInfo::distinct (one device group-by over all columns, first-occurrence order), order_by, materialize_copy, ColView"""
+    build()
+    out = run("distinct_orderby.so", "synthetic", "dll_distinct").strip().splitlines()
+    x = 12345
+    seen = {}
+    for _ in range(200000):
+        x = (x * 6364136223846793005 + 1442695040888963407) % (1 << 64)
+        seen.setdefault(((x >> 33) % 1000, (x >> 20) % 97), None)
+    rows = sorted(seen, key=lambda r: (-r[0], r[1]))
+    assert out[0] == f"distinct rows {len(rows)}"
+    assert out[1] == "top a " + " ".join(str(r[0]) for r in rows[:3])
+    assert out[2].split()[0].startswith("a")
+    body = [l for l in out[3:] if "," in l][:5]
+    assert body == [f"{a},{c}" for a, c in rows[:5]]
+    chk = 0
+    for a, c in rows:
+        chk = (chk * 31 + a * 131 + c)
+        chk = (chk + 2**63) % 2**64 - 2**63          # long long wrap
+    assert out[-2] == f"checksum {chk}"
+    assert out[-1] == "done."
