@@ -29,43 +29,45 @@ struct KeyIn {            // where a pass reads the packed key of row i from
 };
 __device__ inline uint32_t part_id(uint64_t key, uint32_t pbits) { return lds_h1<false>(key) >> (32 - pbits); }
 
-// keys of this thread's SR rows of the tile [rb, re): row r*SB + tid, index clamped into the tile so every load is issued
-__device__ inline void load_keys(const KeyIn& k, uint32_t rb, uint32_t re, uint64_t (&key)[SR]) {
-    size_t idx[SR];
+// A lane owns SR / 4 groups of FOUR consecutive rows of a tile: group c covers rows c*4*SB + tid*4 .. +3, so every 4-byte column
+// is read with one 16-byte load per group and the lanes of a wavefront read 1 KB contiguously (rows of a partition start at
+// arbitrary offsets: the loads are only element-aligned, which gfx950 global loads allow).  Groups that run past the tile's
+// end read a clamped index row by row instead.
+__device__ inline uint32_t tile_row(int r) { return (uint32_t)(r >> 2) * (SB * 4) + threadIdx.x * 4 + (r & 3); }
+template <class T> __device__ inline void load_rows(const T* __restrict__ p, size_t tile_first, uint32_t nrows, T (&t)[SR]) {
 #pragma unroll
-    for (int r = 0; r < SR; ++r) { uint32_t j = rb + r * SB + threadIdx.x; idx[r] = j < re ? j : re - 1; }
-    if (!k.from_cols) {
-        if (k.ksz == 4) {
+    for (int c = 0; c < SR / 4; ++c) {
+        const uint32_t o = tile_row(4 * c);
+        if (o + 4 <= nrows) __builtin_memcpy(&t[4 * c], p + tile_first + o, 4 * sizeof(T));
+        else {
 #pragma unroll
-            for (int r = 0; r < SR; ++r) key[r] = static_cast<const uint32_t*>(k.rec)[idx[r]];
-        } else {
-#pragma unroll
-            for (int r = 0; r < SR; ++r) key[r] = static_cast<const uint64_t*>(k.rec)[idx[r]];
+            for (int q = 0; q < 4; ++q) t[4 * c + q] = p[tile_first + (o + q < nrows ? o + q : nrows - 1)];
         }
-        return;
     }
+}
+template <class T> __device__ inline void or_key_rows(const void* col, size_t tile_first, uint32_t nrows, int sh, uint64_t (&key)[SR]) {
+    T t[SR];
+    load_rows(static_cast<const T*>(col), tile_first, nrows, t);
+#pragma unroll
+    for (int r = 0; r < SR; ++r) key[r] |= (uint64_t)t[r] << sh;
+}
+// packed keys of this lane's SR rows of the tile [rb, re)
+__device__ inline void load_keys(const KeyIn& k, uint32_t rb, uint32_t re, uint64_t (&key)[SR]) {
+    const uint32_t nrows = re - rb;
 #pragma unroll
     for (int r = 0; r < SR; ++r) key[r] = 0;
+    if (!k.from_cols) {
+        if (k.ksz == 4) or_key_rows<uint32_t>(k.rec, rb, nrows, 0, key);
+        else or_key_rows<uint64_t>(k.rec, rb, nrows, 0, key);
+        return;
+    }
     for (int c = 0; c < k.ks.nkeys; ++c) {
         const int sh = c ? k.ks.shift[c] : 0;
-        const void* col = k.ks.col[c];
         switch (aqg_dtype_size_dev(k.ks.dt[c])) {
-        case 1:
-#pragma unroll
-            for (int r = 0; r < SR; ++r) key[r] |= (uint64_t) static_cast<const uint8_t*>(col)[idx[r]] << sh;
-            break;
-        case 2:
-#pragma unroll
-            for (int r = 0; r < SR; ++r) key[r] |= (uint64_t) static_cast<const uint16_t*>(col)[idx[r]] << sh;
-            break;
-        case 4:
-#pragma unroll
-            for (int r = 0; r < SR; ++r) key[r] |= (uint64_t) static_cast<const uint32_t*>(col)[idx[r]] << sh;
-            break;
-        default:
-#pragma unroll
-            for (int r = 0; r < SR; ++r) key[r] |= static_cast<const uint64_t*>(col)[idx[r]] << sh;
-            break;
+        case 1: or_key_rows<uint8_t>(k.ks.col[c], rb, nrows, sh, key); break;
+        case 2: or_key_rows<uint16_t>(k.ks.col[c], rb, nrows, sh, key); break;
+        case 4: or_key_rows<uint32_t>(k.ks.col[c], rb, nrows, sh, key); break;
+        default: or_key_rows<uint64_t>(k.ks.col[c], rb, nrows, sh, key); break;
         }
     }
 }
@@ -111,10 +113,10 @@ __global__ void __launch_bounds__(SB) part_hist_kernel(KeyIn kin, Segs sg, uint3
     if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
     uint64_t key[SR];
-    load_keys(kin, rb, re, key);
+    load_keys(kin, rb, re, key);       // which rows a lane counts is irrelevant here: same loader as the scatter
 #pragma unroll
     for (int r = 0; r < SR; ++r)
-        if (rb + r * SB + threadIdx.x < re) atomicAdd(&h[(part_id(key[r], kin.pbits) >> shift) & (nb - 1)], 1u);
+        if (rb + tile_row(r) < re) atomicAdd(&h[(part_id(key[r], kin.pbits) >> shift) & (nb - 1)], 1u);
     __syncthreads();
     if (threadIdx.x < nb) hist[(size_t)sg.tile_prefix[seg] * nb + (size_t)threadIdx.x * ntseg + tin] = h[threadIdx.x];
 }
@@ -141,7 +143,7 @@ __global__ void __launch_bounds__(SB) part_scatter_kernel(KeyIn kin, Planes pl, 
 #pragma unroll
     for (int r = 0; r < SR; ++r) {
         const uint32_t d = (part_id(key[r], kin.pbits) >> shift) & (nb - 1);
-        pos[r] = r * SB + threadIdx.x < nrows ? (d << 16) | atomicAdd(&cnt[d], 1u) : 0;
+        pos[r] = tile_row(r) < nrows ? (d << 16) | atomicAdd(&cnt[d], 1u) : 0;
     }
     __syncthreads();
     uint32_t c = 0, incl = 0;
@@ -159,7 +161,7 @@ __global__ void __launch_bounds__(SB) part_scatter_kernel(KeyIn kin, Planes pl, 
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SR; ++r) {
-        if (r * SB + threadIdx.x < nrows) {
+        if (tile_row(r) < nrows) {
             const uint32_t d = pos[r] >> 16, lb = lbase[d], p = lb + (pos[r] & 0xFFFF);
             pos[r] = p;
             delta[p] = gbase[d] - lb;
@@ -176,27 +178,28 @@ __global__ void __launch_bounds__(SB) part_scatter_kernel(KeyIn kin, Planes pl, 
             for (int r = 0; r < SR; ++r) v[r] = (uint32_t)(key[r] >> 32);
         } else if (P.kind == PL_ROWIDX) {
 #pragma unroll
-            for (int r = 0; r < SR; ++r) v[r] = rb + r * SB + threadIdx.x;
+            for (int r = 0; r < SR; ++r) v[r] = rb + tile_row(r);
+        } else if (P.src_stride == 8) {              // one half of an 8-byte column
+            uint64_t t[SR];
+            load_rows(reinterpret_cast<const uint64_t*>(P.src), rb, nrows, t);
+#pragma unroll
+            for (int r = 0; r < SR; ++r) v[r] = P.src_off ? (uint32_t)(t[r] >> 32) : (uint32_t)t[r];
+        } else if (P.src_esz == 4) {
+            load_rows(reinterpret_cast<const uint32_t*>(P.src), rb, nrows, v);
+        } else if (P.src_esz == 2) {
+            uint16_t t[SR];
+            load_rows(reinterpret_cast<const uint16_t*>(P.src), rb, nrows, t);
+#pragma unroll
+            for (int r = 0; r < SR; ++r) v[r] = t[r];
         } else {
-            const unsigned char* src = P.src + P.src_off;
-            const size_t st = (size_t)P.src_stride;
-            size_t idx[SR];
+            uint8_t t[SR];
+            load_rows(P.src, rb, nrows, t);
 #pragma unroll
-            for (int r = 0; r < SR; ++r) { uint32_t j = r * SB + threadIdx.x; idx[r] = (size_t)rb + (j < nrows ? j : nrows - 1); }
-            if (P.src_esz == 4) {
-#pragma unroll
-                for (int r = 0; r < SR; ++r) v[r] = *reinterpret_cast<const uint32_t*>(src + idx[r] * st);
-            } else if (P.src_esz == 2) {
-#pragma unroll
-                for (int r = 0; r < SR; ++r) v[r] = *reinterpret_cast<const uint16_t*>(src + idx[r] * st);
-            } else {
-#pragma unroll
-                for (int r = 0; r < SR; ++r) v[r] = src[idx[r] * st];
-            }
+            for (int r = 0; r < SR; ++r) v[r] = t[r];
         }
         __syncthreads();                       // the previous plane has left `stage` (and, first time, `delta` is complete)
 #pragma unroll
-        for (int r = 0; r < SR; ++r) if (r * SB + threadIdx.x < nrows) stage[pos[r]] = v[r];
+        for (int r = 0; r < SR; ++r) if (tile_row(r) < nrows) stage[pos[r]] = v[r];
         __syncthreads();
         uint32_t* dst = P.dst + P.dst_off_dw;
         const size_t dstride = (size_t)P.dst_stride_dw;
