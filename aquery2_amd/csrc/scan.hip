@@ -414,32 +414,48 @@ __global__ void __launch_bounds__(SB) window_sum_kernel(const T* __restrict__ x,
     __shared__ A lds_w[8];
     __shared__ A lds_w2[8];
     const uint32_t tile_start = blockIdx.x * TS, tile_end = tile_start + TS < n ? tile_start + TS : n;
-    const uint32_t ext_start = tile_start >= w - 1 ? tile_start - (w - 1) : 0;
-    const uint32_t ext_len = tile_end - ext_start;
+    // LDS position p <-> row tile_start - H + p, with the halo H = w - 1 rounded up to whole blocks of IT rows; rows before
+    // row 0 count as zeros, so the growing prefix of the first w rows needs no special case below
+    const uint32_t H = (w - 1 + IT - 1) / IT * IT;
+    const uint32_t L = H + TS, nblk = L / IT;
     A* S = reinterpret_cast<A*>(smem_raw);                       // inclusive prefix of x over the extended tile
-    A* Q = S + (MODE >= 2 ? ext_len : 0);                        // inclusive prefix of x*x (variance modes)
-    const uint32_t per = (ext_len + SB - 1) / SB;                // consecutive elements per lane
-    const uint32_t b = threadIdx.x * per, e = b + per < ext_len ? b + per : ext_len;
-    // coalesced load of the extended tile into LDS, then every lane scans its own run of `per` elements in place
-    for (uint32_t k = threadIdx.x; k < ext_len; k += SB) {
-        T v = x[ext_start + k];
-        S[k] = ALG::lift(v);
-        if constexpr (MODE >= 2) Q[k] = (double)v * (double)v;
+    A* Q = S + (MODE >= 2 ? L : 0);                              // inclusive prefix of x*x (variance modes)
+    // a lane takes blocks of IT consecutive rows straight from HBM (vector load), scans them in registers and writes the
+    // prefixes to LDS once; blocks beyond the first SB (the halo's worth) take further rounds with a running carry
+    A carry = ALG::identity(), carry2 = ALG::identity();
+    for (uint32_t blk0 = 0; blk0 < nblk; blk0 += SB) {
+        const uint32_t blk = blk0 + threadIdx.x;
+        const int64_t g0 = (int64_t)tile_start - (int64_t)H + (int64_t)blk * IT;
+        T v[IT];
+        if (blk < nblk && g0 >= 0 && g0 + IT <= (int64_t)n && (((uintptr_t)(x + g0)) & (sizeof(T) * IT > 16 ? 15 : sizeof(T) * IT - 1)) == 0) {
+            pack<T, IT> pk = *reinterpret_cast<const pack<T, IT>*>(x + g0);
+#pragma unroll
+            for (int j = 0; j < IT; ++j) v[j] = pk.v[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < IT; ++j) { const int64_t g = g0 + j; v[j] = (blk < nblk && g >= 0 && g < (int64_t)n) ? x[g] : (T)0; }
+        }
+        A loc[IT], loc2[IT];
+        A a = ALG::identity(), q = ALG::identity();
+#pragma unroll
+        for (int j = 0; j < IT; ++j) {
+            a = ALG::op(a, ALG::lift(v[j])); loc[j] = a;
+            if constexpr (MODE >= 2) { q = q + (double)v[j] * (double)v[j]; loc2[j] = q; }
+        }
+        A tot, tot2;
+        A excl = ALG::op(carry, block_scan_excl<ALG>(a, lds_w, tot));
+        A excl2 = ALG::identity();
+        if constexpr (MODE >= 2) excl2 = ALG::op(carry2, block_scan_excl<ALG>(q, lds_w2, tot2));
+        if (blk < nblk) {
+#pragma unroll
+            for (int j = 0; j < IT; ++j) { S[blk * IT + j] = ALG::op(excl, loc[j]); if constexpr (MODE >= 2) Q[blk * IT + j] = ALG::op(excl2, loc2[j]); }
+        }
+        carry = ALG::op(carry, tot);
+        if constexpr (MODE >= 2) carry2 = ALG::op(carry2, tot2);
     }
-    __syncthreads();
-    A a = ALG::identity(), q = ALG::identity();
-    for (uint32_t k = b; k < e; ++k) {
-        a = ALG::op(a, S[k]); S[k] = a;
-        if constexpr (MODE >= 2) { q = q + Q[k]; Q[k] = q; }
-    }
-    A tot, tot2;
-    A excl = block_scan_excl<ALG>(a, lds_w, tot);
-    A excl2 = ALG::identity();
-    if constexpr (MODE >= 2) excl2 = block_scan_excl<ALG>(q, lds_w2, tot2);
-    for (uint32_t k = b; k < e; ++k) { S[k] = ALG::op(excl, S[k]); if constexpr (MODE >= 2) Q[k] = ALG::op(excl2, Q[k]); }
     __syncthreads();
     for (uint32_t i = tile_start + threadIdx.x; i < tile_end; i += SB) {
-        const uint32_t idx = i - ext_start;
+        const uint32_t idx = i - tile_start + H;
         const uint32_t len = i + 1 < w ? i + 1 : w;               // growing prefix for i < w
         A s = idx >= len ? ALG::sub(S[idx], S[idx - len]) : S[idx];
         if constexpr (MODE == 0) {
@@ -741,7 +757,8 @@ int aqg_scan(aqg_ctx* ctx, int op, int t, const void* xv, uint32_t n, uint32_t w
             using A = typename sum_alg<T>::A;
             uint32_t ww = w > n ? n : w;                                        // w clamped to len (:241,264)
             const bool var = op == AQG_SCAN_VARW || op == AQG_SCAN_STDDEVW;
-            size_t lds = var ? (size_t)(TS + ww - 1) * sizeof(double) * 2 : (size_t)(TS + ww - 1) * sizeof(A);
+            const size_t ext = (size_t)TS + (ww - 1 + IT - 1) / IT * IT;            // tile + halo rounded up to whole blocks
+            size_t lds = var ? ext * sizeof(double) * 2 : ext * sizeof(A);
             if constexpr (std::is_floating_point_v<T>) {
                 if (!var && ww <= 64) {
                     aqg_kernel_timer_begin(ctx);
