@@ -370,20 +370,41 @@ __global__ void __launch_bounds__(SB) shift_kernel(const T* __restrict__ x, uint
     };
     const uint32_t nv = n / V;
     const bool aligned = (((uintptr_t)x | (uintptr_t)out) & 15) == 0;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nv && aligned; c += gridDim.x * blockDim.x) {
-        const uint32_t base = c * V;
-        pack<T, V> cur = *reinterpret_cast<const pack<T, V>*>(x + base);
-        pack<O, V> o;
+    // the neighbour across a vector boundary comes from the adjacent lane's registers (wave shuffle); only the first / last
+    // lane of a wavefront reads it from memory.  The loop bound is wavefront-uniform so that every lane takes part in the shuffle.
+    const uint32_t nv_wave = (nv + 63) & ~63u;
+    constexpr int U = 1;                                          // vectors per lane per step (4 measured slower: 1.76 vs 1.66 ms per 1e9 rows)
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t c0 = blockIdx.x * blockDim.x + threadIdx.x; c0 < nv_wave && aligned; c0 += stride * U) {
+        pack<T, V> cur[U];
+        uint32_t base[U];
+        bool live[U];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const uint32_t i = base + j;
-            T prv, nxt = cur.v[j];
-            if constexpr (OP == AQG_SCAN_RATIOW) prv = i < w ? x[0] : x[i - w];
-            else prv = j ? cur.v[j - 1] : (i ? x[i - 1] : cur.v[0]);
-            if constexpr (OP == AQG_SCAN_NEXT) nxt = j + 1 < V ? cur.v[j + 1] : (i + 1 < n ? x[i + 1] : cur.v[j]);
-            o.v[j] = one(i, cur.v[j], prv, nxt);
+        for (int u = 0; u < U; ++u) {
+            const uint32_t c = c0 + u * stride;                   // c0 < nv_wave does not bound c: clamp
+            live[u] = c < nv;
+            base[u] = (live[u] ? c : nv - 1) * V;
+            cur[u] = *reinterpret_cast<const pack<T, V>*>(x + base[u]);
         }
-        *reinterpret_cast<pack<O, V>*>(static_cast<O*>(out) + base) = o;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t c = c0 + u * stride;
+            T left = shfl_up_t(cur[u].v[V - 1], 1), right = __shfl_down(cur[u].v[0], 1, 64);
+            if constexpr (OP == AQG_SCAN_DELTAS || OP == AQG_SCAN_PREV) { if (lane_id() == 0) left = base[u] ? x[base[u] - 1] : cur[u].v[0]; }
+            if constexpr (OP == AQG_SCAN_NEXT) { if (lane_id() == 63 || c + 1 >= nv) right = base[u] + V < n ? x[base[u] + V] : cur[u].v[V - 1]; }
+            if (!live[u]) continue;
+            pack<O, V> o;
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const uint32_t i = base[u] + j;
+                T prv, nxt = cur[u].v[j];
+                if constexpr (OP == AQG_SCAN_RATIOW) prv = i < w ? x[0] : x[i - w];
+                else prv = j ? cur[u].v[j - 1] : left;
+                if constexpr (OP == AQG_SCAN_NEXT) nxt = j + 1 < V ? cur[u].v[j + 1] : right;
+                o.v[j] = one(i, cur[u].v[j], prv, nxt);
+            }
+            *reinterpret_cast<pack<O, V>*>(static_cast<O*>(out) + base[u]) = o;
+        }
     }
     // tail (and the whole column when the buffers are not 16-byte aligned)
     const uint32_t start = aligned ? nv * V : 0;
