@@ -166,6 +166,42 @@ template <class ALG> __global__ void __launch_bounds__(SB) agg_scan_kernel(typen
     }
 }
 
+// K2 for many tiles: chunks of CH aggregates are reduced by one workgroup each, the few chunk totals are scanned by one
+// workgroup, then every chunk is scanned with its carry-in (one workgroup over 488k aggregates took 0.57 ms at 1e9 rows)
+constexpr uint32_t CH = SB * IT;
+template <class ALG> __global__ void __launch_bounds__(SB) agg_chunk_sum_kernel(const typename ALG::A* __restrict__ tile_agg, uint32_t ntiles, typename ALG::A* __restrict__ chunk_tot) {
+    using A = typename ALG::A;
+    __shared__ A lds_w[8];
+    const uint32_t b = blockIdx.x * CH + threadIdx.x * IT;
+    A a = ALG::identity();
+#pragma unroll
+    for (int j = 0; j < IT; ++j) if (b + j < ntiles) a = ALG::op(a, tile_agg[b + j]);
+    A total;
+    block_scan_excl<ALG>(a, lds_w, total);
+    if (threadIdx.x == 0) chunk_tot[blockIdx.x] = total;
+}
+template <class ALG> __global__ void __launch_bounds__(SB) agg_chunk_scan_kernel(typename ALG::A* __restrict__ tile_agg, uint32_t ntiles, const typename ALG::A* __restrict__ chunk_excl) {
+    using A = typename ALG::A;
+    __shared__ A lds_w[8];
+    const uint32_t b = blockIdx.x * CH + threadIdx.x * IT;
+    A v[IT];
+    A a = ALG::identity();
+#pragma unroll
+    for (int j = 0; j < IT; ++j) { v[j] = (b + j < ntiles) ? tile_agg[b + j] : ALG::identity(); a = ALG::op(a, v[j]); }
+    A total;
+    A run = ALG::op(chunk_excl[blockIdx.x], block_scan_excl<ALG>(a, lds_w, total));
+#pragma unroll
+    for (int j = 0; j < IT; ++j) { if (b + j < ntiles) tile_agg[b + j] = run; run = ALG::op(run, v[j]); }
+}
+// exclusive scan of the tile aggregates in place; `chunk_tot` holds ceil(ntiles / CH) + 1 values of workspace
+template <class ALG> void launch_agg_scan(aqg_ctx* ctx, typename ALG::A* tile_agg, uint32_t ntiles, typename ALG::A* chunk_tot) {
+    if (ntiles <= 4 * CH || !chunk_tot) { hipLaunchKernelGGL((agg_scan_kernel<ALG>), dim3(1), dim3(SB), 0, ctx->stream, tile_agg, ntiles); return; }
+    const uint32_t nch = aqg_ceil_div(ntiles, CH);
+    hipLaunchKernelGGL((agg_chunk_sum_kernel<ALG>), dim3(nch), dim3(SB), 0, ctx->stream, tile_agg, ntiles, chunk_tot);
+    hipLaunchKernelGGL((agg_scan_kernel<ALG>), dim3(1), dim3(SB), 0, ctx->stream, chunk_tot, nch);
+    hipLaunchKernelGGL((agg_chunk_scan_kernel<ALG>), dim3(nch), dim3(SB), 0, ctx->stream, tile_agg, ntiles, chunk_tot);
+}
+
 // K3: scan inside the tile with the carry-in; WRITER(out, i, inclusive_value)
 enum : int { W_SUMS = 0, W_AVGS = 1, W_MINS = 2, W_MAXS = 3, W_MAXP = 4 /* running max without the reference's seed (maxw, w >= n) */ };
 
@@ -689,15 +725,16 @@ int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out) {
     constexpr size_t osz = WR == W_SUMS ? (std::is_floating_point_v<T> ? 8 : 16) : WR == W_AVGS ? 8 : sizeof(T);
     constexpr int PW = std::is_same_v<A, aqg_i128> ? 2 : 1;
     AQG_TRY(aqg_ws_reset(ctx));
-    AQG_TRY(aqg_ws_ensure(ctx, (size_t)ntiles * (4 + 16 * PW + sizeof(A)) + 8192));
+    AQG_TRY(aqg_ws_ensure(ctx, (size_t)ntiles * (4 + 16 * PW + sizeof(A)) + ((size_t)ntiles / CH + 2) * sizeof(A) + 16384));
     // Measured at 1e9 int32 rows (whole call): mins 2.49 ms chained vs 3.17 ms three-kernel; sums 5.86 vs 5.25; avgs 4.33 vs 3.90.
     // The chained kernel holds 8 sub-tiles in registers, which costs occupancy when the results are 8 or 16 bytes wide.
     constexpr bool use_chain = WR == W_MINS || WR == W_MAXS || WR == W_MAXP;
     if (!use_chain) {
-        A* agg3;
+        A *agg3, *chunk_tot;
         AQG_TRY(aqg_ws_get(ctx, ntiles, &agg3));
+        AQG_TRY(aqg_ws_get(ctx, (size_t)ntiles / CH + 2, &chunk_tot));
         hipLaunchKernelGGL((tile_reduce_kernel<T, ALG>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, agg3);
-        hipLaunchKernelGGL((agg_scan_kernel<ALG>), dim3(1), dim3(SB), 0, ctx->stream, agg3, ntiles);
+        launch_agg_scan<ALG>(ctx, agg3, ntiles, chunk_tot);
         aqg_kernel_timer_begin(ctx);
         hipLaunchKernelGGL((tile_scan_kernel<T, ALG, WR>), dim3(ntiles), dim3(SB), (size_t)TS * osz, ctx->stream, x, n, agg3, out);
         aqg_kernel_timer_end(ctx);
