@@ -1008,7 +1008,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (bitmap) AQG_HIP(ctx, hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, ctx->stream));
 
     // fast path eligibility: LDS mode, one 4-byte integer key, 1..3 four-byte value columns, plain additive accumulators
-    bool fast = use_lds && !plan.sj && !big_lds && k32 && n >= 8 && as.nacc >= (plan.need_count ? 0 : 1) && as.nacc <= 3 && !for_build &&
+    // (also the first pass of aqg_groupby_build: no accumulators, only the distinct keys)
+    bool fast = use_lds && !plan.sj && !big_lds && k32 && n >= 8 && (as.nacc >= 1 || plan.need_count || for_build) && as.nacc <= 3 &&
                 (ks.dt[0] == AQG_INT32 || ks.dt[0] == AQG_UINT32) && ((uintptr_t)ks.col[0] & 15) == 0;
     FastVals fv;
     memset(&fv, 0, sizeof fv);
@@ -1044,8 +1045,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
             switch (as.nacc) { case 0: rc = launch(&agg32_kernel<0, true>); break; case 1: rc = launch(&agg32_kernel<1, true>); break;
                                case 2: rc = launch(&agg32_kernel<2, true>); break; default: rc = launch(&agg32_kernel<3, true>); break; }
         } else {
-            switch (as.nacc) { case 1: rc = launch(&agg32_kernel<1, false>); break; case 2: rc = launch(&agg32_kernel<2, false>); break;
-                               default: rc = launch(&agg32_kernel<3, false>); break; }
+            switch (as.nacc) { case 0: rc = launch(&agg32_kernel<0, false>); break; case 1: rc = launch(&agg32_kernel<1, false>); break;
+                               case 2: rc = launch(&agg32_kernel<2, false>); break; default: rc = launch(&agg32_kernel<3, false>); break; }
         }
         AQG_TRY(rc);
     } else if (n && dense) {
