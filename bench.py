@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=float, default=1e9, help="rows per GPU")
     ap.add_argument("--cpu-sample", type=float, default=1e8, help="rows of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--workload", choices=["q1", "join"], default="q1",
+                    help="q1 (default, the graded metric): sum(v1) by id1.  join: BASELINE config 4, fact JOIN small(id4, w) ON id4, "
+                         "sum(v1 * w) by id1 through the fused aqg_join_groupby_sum, same shard merge")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,6 +92,13 @@ def main():
     dev = aquery2_amd.Device(gpu, stream=stream)
     id1 = dev.gen_column(ck.GEN_ID1, 42, rank * n, n, n_total, 100)
     v1 = dev.gen_column(ck.GEN_V1, 42, rank * n, n, n_total, 100)
+    join = args.workload == "join"
+    if join:
+        id4 = dev.gen_column(ck.GEN_ID4, 42, rank * n, n, n_total, 100)
+        rng = np.random.default_rng(4)                    # the dimension table small(id4, w): identical on every rank
+        dim_key_h = rng.permutation(np.arange(1, 101, dtype=np.int32))
+        dim_w_h = rng.integers(1, 50, 100).astype(np.int32)
+        dim_key, dim_w = dev.to_device(dim_key_h), dev.to_device(dim_w_h)
     dev.sync()
 
     state = {"gb": None, "merged": None}
@@ -96,7 +106,10 @@ def main():
     kernel_ms = []
 
     def step(record):
-        gb = dev.groupby_agg([id1], [ck.RED_SUM], [v1], hint=128, handle=state["gb"])
+        if join:
+            gb = dev.join_groupby_sum(dim_key, dim_w, id4, id1, v1, hint=128, handle=state["gb"])
+        else:
+            gb = dev.groupby_agg([id1], [ck.RED_SUM], [v1], hint=128, handle=state["gb"])
         state["gb"] = gb
         if record:
             kernel_ms.append(dev.last_kernel_ms())
@@ -138,8 +151,15 @@ def main():
 
     # sanity: the merged / local result is the exact sum of v1 (checked against a second HIP reduction)
     final = state["merged"] if world > 1 else state["gb"]
-    total = sum(ck.i128_to_int(final.result(0, ck.RED_SUM, ck.INT64 if world > 1 else ck.INT32)))
-    local_sum = int(dev.reduce(ck.RED_SUM, v1))
+    total = sum(ck.i128_to_int(final.result(0, ck.RED_SUM, ck.INT64 if (world > 1 or join) else ck.INT32)))
+    if join:
+        # independent check: sum(v1) by id4 (a plain group-by), dotted with w on the host
+        by4 = dev.groupby_agg([id4], [ck.RED_SUM], [v1], hint=128)
+        w_of = dict(zip(dim_key_h.tolist(), dim_w_h.tolist()))
+        local_sum = sum(int(s_) * w_of[int(k_)] for k_, s_ in zip(by4.keys(0, np.int32), ck.i128_to_int(by4.result(0, ck.RED_SUM, ck.INT32))))
+        by4.destroy()
+    else:
+        local_sum = int(dev.reduce(ck.RED_SUM, v1))
     if world > 1:
         t = torch.tensor([local_sum], dtype=torch.int64, device=xdev)
         dist.all_reduce(t)
@@ -150,21 +170,24 @@ def main():
     if rank == 0:
         ms_step = 1e3 * elapsed / args.steps
         k_ms = float(np.mean(kernel_ms))
-        achieved = Q1_BYTES_PER_ROW * n / (k_ms * 1e-3) / 1e9
+        bpr = 12 if join else Q1_BYTES_PER_ROW            # join: id4 + id1 + v1
+        achieved = bpr * n / (k_ms * 1e-3) / 1e9
         line = {
-            "metric": "rows/sec on h2o groupby 1e9-row", "value": n_total * args.steps / elapsed, "unit": "rows/s",
+            "metric": "rows/sec on h2o join + groupby 1e9-row" if join else "rows/sec on h2o groupby 1e9-row", "value": n_total * args.steps / elapsed, "unit": "rows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": f"h2o_groupby_q1_sum_v1_by_id1_{n:.0e}_rows_per_gpu", "rows_per_gpu": n, "K": 100,
+            "config": {"workload": (f"h2o_join_small_id4_w_then_sum_v1_times_w_by_id1_{n:.0e}_rows_per_gpu" if join else
+                                    f"h2o_groupby_q1_sum_v1_by_id1_{n:.0e}_rows_per_gpu"), "rows_per_gpu": n, "K": 100,
                        "seed": 42, "groups": int(final.ngroups), "parallelism": f"row-range shards x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # PMC-measured HBM bytes per launch at 1e9 rows (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
                          # profiles/r1_bench_q1_1e9_pmc.md): 8.0255 GB read + 0.0121 GB written; scaled to this run's rows
-                         "traffic": 8.0376e9 * n / 1e9,
-                         "kernel": "agg32_kernel<1,false>", "kernel_ms": k_ms, "algorithmic_bytes": Q1_BYTES_PER_ROW * n},
+                         # join: 12.001 GB read + 0.018 GB written (profiles/r1_groupby_join_1e9_pmc.md)
+                         "traffic": (12.019e9 if join else 8.0376e9) * n / 1e9,
+                         "kernel": "starjoin_kernel" if join else "agg32_kernel<1,false>", "kernel_ms": k_ms, "algorithmic_bytes": bpr * n},
         }
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_sample > 0 and not join:
             line["cpu_baseline"] = cpu_baseline(int(args.cpu_sample))
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -60,6 +60,17 @@ if which in ("all", "build"):
     v1 = col(ck.GEN_V1)
     timeit("grouped_reduce sum(v1[vecs])", 8, lambda: d.grouped_reduce(g, ck.RED_SUM, v1), reps=3)
     g.destroy()
+    if which == "build":
+        id3 = col(ck.GEN_ID3)
+        hb3 = {}
+        def build3():
+            if "b" in hb3: hb3["b"].destroy()
+            hb3["b"] = d.groupby_build([id3], hint=n // K + 1024); return hb3["b"]
+        g3 = timeit("build reversemap by id3 (1e7 groups)", 12, build3, reps=2)
+        timeit("grouped_reduce sum(v1[vecs]) 1e7 groups", 8, lambda: d.grouped_reduce(g3, ck.RED_SUM, v1), reps=2)
+        off3 = d.empty(g3.ngroups + 1, np.uint32); rows3 = d.empty(n, np.uint32)
+        timeit("ht_postproc 1e7 groups (3 radix passes)", 36, lambda: d._chk(d.lib.aqg_groupby_postproc(g3.h, C.c_void_p(off3.ptr), C.c_void_p(rows3.ptr)), "pp"), reps=2)
+        g3.destroy()
 if which in ("all", "scan"):
     price, v1 = col(ck.GEN_PRICE), col(ck.GEN_V1)
     outs = {}
