@@ -329,6 +329,15 @@ class Device:
         gb = handle if handle is not None else GroupBy(self, h)
         gb._keep = (dk, dv, fk, gk, fv)
         return gb
+    def groupby_pack(self, gb, agg_index, gmax, out_ptr):
+        """exchange payload of a shard's group table: (gmax + 1) int64 pairs at device address `out_ptr` (aqg_groupby_pack)"""
+        self._chk(self.lib.aqg_groupby_pack(gb.h, agg_index, C.c_uint32(gmax), C.c_void_p(out_ptr)), "aqg_groupby_pack")
+    def groupby_merge_packed(self, gathered_ptr, world, gmax, key_tag, op, handle=None):
+        """merge the gathered payloads of `world` shards (aqg_groupby_merge_packed)"""
+        h = handle.h if handle is not None else C.c_void_p()
+        self._chk(self.lib.aqg_groupby_merge_packed(self.ctx, C.c_void_p(gathered_ptr), C.c_uint32(world), C.c_uint32(gmax), key_tag, op, C.byref(h)),
+                  "aqg_groupby_merge_packed")
+        return handle if handle is not None else GroupBy(self, h)
     def grouped_reduce(self, gb, op, x):
         xd = self._dev(x)
         ot = self.lib.aqg_reduce_out_dtype(op, xd.tag)

@@ -816,6 +816,60 @@ __global__ void __launch_bounds__(256) assign_kernel(KeySpec ks, GTable gt, cons
     }
 }
 
+// ---- the exchange step of row-sharded group-bys ----------------------------------------------------------------
+// pack: {ngroups, 0; key, low 64 bits of the aggregate} as int64 pairs -- the payload of the one all_gather
+__global__ void __launch_bounds__(256) pack_kernel(const void* __restrict__ keys, int key_dt, const void* __restrict__ res, int res_dt, uint32_t G,
+                                                   long long* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= G; i += gridDim.x * blockDim.x) {
+        if (i == 0) { out[0] = G; out[1] = 0; continue; }
+        const uint32_t g = i - 1;
+        long long k;
+        switch (key_dt) {
+        case AQG_INT8: k = static_cast<const int8_t*>(keys)[g]; break;
+        case AQG_INT16: k = static_cast<const int16_t*>(keys)[g]; break;
+        case AQG_INT32: k = static_cast<const int32_t*>(keys)[g]; break;
+        case AQG_UINT8: case AQG_BOOL: k = static_cast<const uint8_t*>(keys)[g]; break;
+        case AQG_UINT16: k = static_cast<const uint16_t*>(keys)[g]; break;
+        case AQG_UINT32: k = static_cast<const uint32_t*>(keys)[g]; break;
+        default: k = static_cast<const long long*>(keys)[g]; break;
+        }
+        long long v;
+        if (res_dt == AQG_INT128 || res_dt == AQG_UINT128) v = (long long) static_cast<const aqg_i128*>(res)[g].lo;      // sums: low 64 bits
+        else switch (res_dt) {                                                                                            // min / max keep the value dtype
+        case AQG_INT8: v = static_cast<const int8_t*>(res)[g]; break;
+        case AQG_INT16: v = static_cast<const int16_t*>(res)[g]; break;
+        case AQG_INT32: v = static_cast<const int32_t*>(res)[g]; break;
+        case AQG_UINT8: case AQG_BOOL: v = static_cast<const uint8_t*>(res)[g]; break;
+        case AQG_UINT16: v = static_cast<const uint16_t*>(res)[g]; break;
+        case AQG_UINT32: v = static_cast<const uint32_t*>(res)[g]; break;
+        default: v = static_cast<const long long*>(res)[g]; break;                                                        // 8-byte values, counts (uint64)
+        }
+        out[2 * i] = k; out[2 * i + 1] = v;
+    }
+}
+// unpack the gathered payloads of `world` shards into one key column and one value column, shards in rank order
+__global__ void __launch_bounds__(256) unpack_kernel(const long long* __restrict__ gathered, uint32_t world, uint32_t gmax, int key_dt,
+                                                     void* __restrict__ keys, long long* __restrict__ vals) {
+    __shared__ uint32_t off[65];
+    if (threadIdx.x == 0) { uint32_t o = 0; for (uint32_t r = 0; r < world; ++r) { off[r] = o; o += (uint32_t)gathered[(size_t)r * (gmax + 1) * 2]; } off[world] = o; }
+    __syncthreads();
+    for (uint32_t r = blockIdx.x; r < world; r += gridDim.x) {
+        const long long* src = gathered + (size_t)r * (gmax + 1) * 2;
+        const uint32_t cnt = off[r + 1] - off[r];
+        for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const long long k = src[2 + 2 * i];
+            const uint32_t d = off[r] + i;
+            switch (aqg_dtype_size_dev(key_dt)) {
+            case 1: static_cast<uint8_t*>(keys)[d] = (uint8_t)k; break;
+            case 2: static_cast<uint16_t*>(keys)[d] = (uint16_t)k; break;
+            case 4: static_cast<uint32_t*>(keys)[d] = (uint32_t)k; break;
+            default: static_cast<long long*>(keys)[d] = k; break;
+            }
+            vals[d] = src[3 + 2 * i];
+        }
+    }
+}
+
 } // namespace
 
 // =================================================================================================
@@ -1188,6 +1242,8 @@ void aqg_groupby_destroy(aqg_groupby* g) {
     if (g->counts) hipFree(g->counts);
     if (g->reversemap) hipFree(g->reversemap);
     if (g->scratch) aqg_groupby_destroy(g->scratch);
+    if (g->xkeys) hipFree(g->xkeys);
+    if (g->xvals) hipFree(g->xvals);
     delete g;
 }
 uint32_t aqg_groupby_ngroups(const aqg_groupby* g) { return g ? g->ngroups : 0; }
@@ -1252,6 +1308,45 @@ int aqg_join_groupby_sum(aqg_ctx* ctx, int key_dtype, const void* dim_keys, int 
     int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, false, h, nullptr, nullptr);
     if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
     AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = h;
+    return AQG_OK;
+}
+
+int aqg_groupby_pack(aqg_groupby* g, int agg_index, uint32_t gmax, int64_t* out_dev) {
+    if (!g || !out_dev) return AQG_ERR_ARG;
+    aqg_ctx* ctx = g->ctx;
+    if (g->nkeys != 1) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_pack: one key column");
+    if (agg_index < 0 || agg_index >= g->nagg) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_pack: aggregate index");
+    if (g->ngroups > gmax) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_pack: more groups than gmax");
+    const int rdt = g->res_dt[agg_index];
+    if (rdt == AQG_FLOAT || rdt == AQG_DOUBLE) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_pack: integer aggregates only (floating partials: gather the result columns)");
+    hipLaunchKernelGGL(pack_kernel, dim3(aqg_grid(ctx, (uint64_t)g->ngroups + 1, 256, 1, 4)), dim3(256), 0, ctx->stream, (const void*)g->keys_out[0], g->key_dt[0],
+                       (const void*)g->results[agg_index], rdt, g->ngroups, reinterpret_cast<long long*>(out_dev));
+    return aqg_check_launch(ctx, "pack_kernel");
+}
+
+int aqg_groupby_merge_packed(aqg_ctx* ctx, const int64_t* gathered_dev, uint32_t world, uint32_t gmax, int key_dtype, int op, aqg_groupby** out) {
+    if (!ctx || !gathered_dev || !out || world == 0 || world > 64) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_merge_packed: bad argument (1..64 shards)");
+    if (!(op == AQG_RED_SUM || op == AQG_RED_MIN || op == AQG_RED_MAX || op == AQG_RED_COUNT)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_merge_packed: SUM / COUNT / MIN / MAX");
+    // the shards' group counts (one small copy), then the concatenation and a plain group-by over it
+    long long cnt[64];
+    for (uint32_t r = 0; r < world; ++r)
+        AQG_HIP(ctx, hipMemcpyAsync(&cnt[r], gathered_dev + (size_t)r * (gmax + 1) * 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    uint64_t total = 0;
+    for (uint32_t r = 0; r < world; ++r) { if (cnt[r] < 0 || (uint64_t)cnt[r] > gmax) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_merge_packed: corrupt shard header"); total += (uint64_t)cnt[r]; }
+    aqg_groupby* h = *out ? *out : new aqg_groupby();
+    h->ctx = ctx;
+    int rc = dev_realloc(ctx, &h->xkeys, &h->cap_xkeys, (total + 1) * 8);
+    if (rc == AQG_OK) rc = dev_realloc(ctx, &h->xvals, &h->cap_xvals, (total + 1) * 8);
+    if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
+    if (total) hipLaunchKernelGGL(unpack_kernel, dim3(world), dim3(256), 0, ctx->stream, reinterpret_cast<const long long*>(gathered_dev), world, gmax, key_dtype, h->xkeys,
+                                  static_cast<long long*>(h->xvals));
+    const void* kc[1] = {h->xkeys};
+    const void* vc[1] = {h->xvals};
+    const int mop = op == AQG_RED_COUNT ? AQG_RED_SUM : op, vdt = AQG_INT64;
+    rc = aqg_groupby_agg(ctx, 1, &key_dtype, kc, 1, &mop, &vdt, vc, (uint32_t)total, gmax, &h);
+    if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
     *out = h;
     return AQG_OK;
 }

@@ -23,5 +23,8 @@ struct aqg_groupby {
     size_t cap_groups = 0, cap_rows = 0, cap_results[MAXAGG] = {0};
     uint32_t hint_used = 0;
     aqg_groupby* scratch = nullptr;   // reusable handle for aqg_grouped_reduce
+    // aqg_groupby_merge_packed: the concatenated shard tables (keys / values), owned by the merged handle
+    void* xkeys = nullptr; void* xvals = nullptr;
+    size_t cap_xkeys = 0, cap_xvals = 0;
 };
 

@@ -40,3 +40,30 @@ def gather_group_tables(dist, cols, ngroups, gmax=None):
     sizes = allp[:, 0, 0].tolist()
     rows = torch.cat([allp[r, 1:1 + sizes[r]] for r in range(world)])
     return [rows[:, j].contiguous() for j in range(len(cols))]
+
+
+class GroupTableExchange:
+    """The lean form of the merge used by bench.py: the shard's table is packed by one kernel (aqg_groupby_pack), ONE
+    all_gather moves (gmax + 1) int64 pairs per rank, and aqg_groupby_merge_packed re-aggregates the concatenation --
+    three library / collective calls per step, buffers allocated once.  `xdev` = "cuda" (RCCL) or "cpu" (gloo rehearsal)."""
+
+    def __init__(self, dev, dist, gmax, key_tag, op, xdev="cuda"):
+        self.dev, self.dist, self.gmax, self.key_tag, self.op, self.xdev = dev, dist, gmax, key_tag, op, xdev
+        self.world = dist.get_world_size()
+        self.pack = torch.zeros((gmax + 1) * 2, dtype=torch.int64, device="cuda")
+        self.all = torch.zeros(self.world * (gmax + 1) * 2, dtype=torch.int64, device="cuda")
+        if xdev != "cuda":
+            self.all_x = torch.zeros_like(self.all, device=xdev)
+        self.merged = None
+
+    def __call__(self, gb, agg_index=0):
+        self.dev.groupby_pack(gb, agg_index, self.gmax, self.pack.data_ptr())
+        if self.xdev == "cuda":
+            self.dist.all_gather_into_tensor(self.all, self.pack)
+        else:
+            self.dev.sync()
+            self.dist.all_gather_into_tensor(self.all_x, self.pack.to(self.xdev))
+            self.all.copy_(self.all_x)
+            torch.cuda.synchronize()
+        self.merged = self.dev.groupby_merge_packed(self.all.data_ptr(), self.world, self.gmax, self.key_tag, self.op, self.merged)
+        return self.merged

@@ -101,6 +101,16 @@ def main():
         dim_key, dim_w = dev.to_device(dim_key_h), dev.to_device(dim_w_h)
     dev.sync()
 
+    # AQG_BENCH_SELFMERGE=1 (N=1 only): run the exchange step against a one-rank stand-in for torch.distributed, to time
+    # what the merge adds on top of the row pass without a second GPU.  Never set by the driver.
+    selfmerge = world == 1 and os.environ.get("AQG_BENCH_SELFMERGE") == "1"
+    if selfmerge:
+        class _OneRank:
+            @staticmethod
+            def get_world_size(): return 1
+            @staticmethod
+            def all_gather_into_tensor(out, inp): out.copy_(inp)
+        dist = _OneRank()
     state = {"gb": None, "merged": None}
     GMAX = 128                     # the group-by hint: upper bound of a shard's group count (h2o K=100)
     kernel_ms = []
@@ -113,22 +123,13 @@ def main():
         state["gb"] = gb
         if record:
             kernel_ms.append(dev.last_kernel_ms())
-        if world > 1:
-            # one exchange: gather every shard's {key, partial sum} (<= a few KB), then re-aggregate;
-            # shards are contiguous row ranges in rank order, so first occurrence in the concatenation
-            # is the global first occurrence
-            G = gb.ngroups
-            kbuf = state.setdefault("kbuf", dev.empty(GMAX, np.int32))
-            dev._chk(dev.lib.aqg_groupby_keys(gb.h, 0, ctypes.c_void_p(kbuf.ptr)), "aqg_groupby_keys")
-            keys_t = torch.as_tensor(kbuf, device="cuda")[:G].to(torch.int64)
-            sums = aquery2_amd.DevBuf(dev, dev.lib.aqg_groupby_agg_result(gb.h, 0), ck.I128, G, owned=False)
-            sums_lo = torch.as_tensor(sums, device="cuda").reshape(G, 2)[:, 0]   # partial sums fit 63 bits
-            mk, ms = shard.gather_group_tables(dist, [keys_t.to(xdev), sums_lo.to(xdev)], G, gmax=GMAX)
-            mk, ms = mk.to("cuda").to(torch.int32).contiguous(), ms.to("cuda").contiguous()
-            kd = aquery2_amd.DevBuf(dev, mk.data_ptr(), np.int32, mk.numel(), owned=False)
-            sd = aquery2_amd.DevBuf(dev, ms.data_ptr(), np.int64, ms.numel(), owned=False)
-            state["merged"] = dev.groupby_agg([kd], [ck.RED_SUM], [sd], hint=128, handle=state["merged"])
-            state["keep"] = (mk, ms, kbuf)
+        if world > 1 or selfmerge:
+            # one exchange: pack {key, partial sum} per group (one kernel), ONE all_gather of 129 int64 pairs per rank,
+            # re-aggregate the concatenation (aqg_groupby_merge_packed).  Shards are contiguous row ranges in rank order,
+            # so first occurrence in the concatenation is the global first occurrence.
+            if state.get("xchg") is None:
+                state["xchg"] = shard.GroupTableExchange(dev, dist, GMAX, ck.INT32, ck.RED_SUM, xdev)
+            state["merged"] = state["xchg"](gb, 0)
 
     def fence():
         if world > 1:

@@ -215,6 +215,20 @@ int aqg_join_pairs(aqg_ctx* ctx, int t, const void* build_keys, uint32_t nb,
 int aqg_join_lookup(aqg_ctx* ctx, int t, const void* build_keys, uint32_t nb,
                     const void* probe_keys, uint32_t np, uint32_t* build_row_of_probe);
 
+/* ---- the exchange step of row-sharded group-bys -------------------------------------------------
+ * Tables shard by row range, one process per GPU; every shard groups its own rows and the shards' group tables are merged
+ * by ONE all_gather (RCCL) of a fixed-size payload followed by a re-aggregation.  Because shards are contiguous row
+ * ranges gathered in rank order, first occurrence in the concatenation is the global first occurrence.
+ *   aqg_groupby_pack          writes the payload of this shard: (gmax + 1) int64 pairs -- {ngroups, 0} then per group
+ *                             {key, low 64 bits of aggregate `agg_index`} (one key column; integer SUM / COUNT / MIN / MAX)
+ *   aqg_groupby_merge_packed  takes the `world` gathered payloads (rank order, (gmax + 1) * 2 int64 each) and returns the
+ *                             merged group-by: keys of `key_dtype`, one aggregate combined with `op` (COUNT -> SUM of counts),
+ *                             result dtype as for an AQG_INT64 value column
+ * (the generated code of the reference has no distributed form; this replaces nothing there)                       */
+int aqg_groupby_pack(aqg_groupby* g, int agg_index, uint32_t gmax, int64_t* out_dev);
+int aqg_groupby_merge_packed(aqg_ctx* ctx, const int64_t* gathered_dev, uint32_t world, uint32_t gmax, int key_dtype, int op,
+                             aqg_groupby** out);
+
 /* Fused star join + grouped sum (BASELINE config 4: `fact JOIN small(key, w) ON fact.fk = small.key`, then
  * `sum(fact.val * small.w) BY fact.gkey`): one pass over fk, gkey and val (12 B/row) instead of lookup -> gather ->
  * multiply -> group-by (44 B/row).  The reference emits this as SQL for MonetDB (engine/ast.py:874-1085) followed by

@@ -194,6 +194,36 @@ def test_full_size_properties_q5_and_windows(gpu):
     assert (int(last["hi"]) << 64) + int(last["lo"]) == int(gpu.reduce(ck.RED_SUM, price))
 
 
+def test_shard_exchange_pack_and_merge(gpu, oracle):
+    """SURVEY 8e on one device: three row-range shards grouped separately, their tables packed (aqg_groupby_pack) into the
+    buffer an all_gather would fill, merged by aqg_groupby_merge_packed == the group-by of the whole table"""
+    import aquery2_amd
+    rng = np.random.default_rng(81)
+    n, world, gmax = 900_001, 3, 64
+    key = rng.integers(-20, 21, n).astype(np.int32)
+    key[: n // 3] = rng.integers(0, 5, n // 3)                 # the first shard sees only a few of the keys
+    val = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
+    gathered = gpu.empty(world * (gmax + 1) * 2, np.int64)
+    bounds = [0, n // 3, n // 3, n]                             # the second shard is EMPTY
+    for op in (ck.RED_SUM, ck.RED_MIN, ck.RED_MAX, ck.RED_COUNT):
+        for r in range(world):
+            lo, hi = bounds[r], bounds[r + 1]
+            gb = gpu.groupby_agg([key[lo:hi]], [op], [val[lo:hi]])
+            gpu.groupby_pack(gb, 0, gmax, gathered.ptr + r * (gmax + 1) * 2 * 8)
+            gb.destroy()
+        merged = gpu.groupby_merge_packed(gathered.ptr, world, gmax, ck.INT32, op)
+        o = oracle.groupby([key])
+        assert merged.ngroups == o["ngroups"]
+        assert np.array_equal(merged.keys(0, np.int32), key[o["first_rows"]])            # global first-occurrence order
+        want = oracle.grouped_reduce(op, val, o)
+        got = merged.result(0, ck.RED_SUM if op == ck.RED_COUNT else op, ck.INT64)
+        if op in (ck.RED_SUM, ck.RED_COUNT):
+            assert ck.i128_to_int(got) == (ck.i128_to_int(want) if op == ck.RED_SUM else [int(c) for c in want])
+        else:
+            assert np.array_equal(got.astype(np.int64), want.astype(np.int64))
+        merged.destroy()
+
+
 def test_maximum_row_count(gpu):
     """n = AQG_MAX_ROWS - 1 = 2^32 - 2^20 - 1 rows (sizes are uint32_t, server/vector_type.hpp:66; the last 2^20 counts are
     rejected, see include/aqg.h): every index computation near the 32-bit limit.

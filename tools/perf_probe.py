@@ -45,6 +45,15 @@ if which in ("all", "gb"):
     print("   Q5 groups", g.ngroups)
     timeit("Q7 max(v1),min(v2) by id3", 12, agg("q7", [id3], [ck.RED_MAX, ck.RED_MIN], [v1, v2], n // K + 1024), reps=2)
     for k in list(h): h[k].destroy()
+if which == "q10":
+    ids = [col(c) for c in (ck.GEN_ID1, ck.GEN_ID2, ck.GEN_ID3, ck.GEN_ID4, ck.GEN_ID5, ck.GEN_ID6)]
+    v3 = col(ck.GEN_V3)
+    hq = {}
+    def q10():
+        hq["h"] = d.groupby_agg(ids, [ck.RED_SUM, ck.RED_COUNT], [v3, v3], hint=n, handle=hq.get("h"))
+        return hq["h"]
+    g = timeit("Q10 sum(v3),count by id1..id6", 28, q10, reps=2)
+    print("   Q10 groups", g.ngroups, flush=True)
 if which in ("all", "build"):
     id1 = col(ck.GEN_ID1)
     hb = {}
