@@ -19,7 +19,9 @@ template <class T>
 __device__ inline void col_range(const void* col, uint32_t n, long long& mn, long long& mx) {
     const T* p = static_cast<const T*>(col);
     const uint32_t nchunk = n >> 2;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+    uint32_t c_lo, c_hi;
+    wg_span(nchunk, c_lo, c_hi);
+    for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
         pack<T, 4> v = *reinterpret_cast<const pack<T, 4>*>(p + (size_t)c * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { long long x = (long long)v.v[j]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
@@ -126,7 +128,9 @@ __global__ void __launch_bounds__(BLOCK) dense_agg_kernel(KeySpec ks, DenseSpec 
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) lacc[(size_t)a * PP + s] = acc_init(as.kind[a]);
         }
         __syncthreads();
-        for (uint32_t c = blockIdx.x * BLOCK + threadIdx.x; c < nchunk; c += gridDim.x * BLOCK) {
+        uint32_t c_lo, c_hi;
+        wg_span(nchunk, c_lo, c_hi);
+        for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += BLOCK) {
             const size_t base = (size_t)c * 4;
             uint32_t idx[4];
             dense_idx4(ks, ds, base, idx);

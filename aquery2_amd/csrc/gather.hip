@@ -16,7 +16,9 @@ template <class W> __global__ void __launch_bounds__(256) gather_kernel(const W*
     const uint32_t nchunk = m >> 2;
     const bool aligned = ((reinterpret_cast<uintptr_t>(idx) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
     if (aligned) {
-        for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+        uint32_t c_lo, c_hi;
+        wg_span(nchunk, c_lo, c_hi);
+        for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
             const pack<uint32_t, 4> i4 = *reinterpret_cast<const pack<uint32_t, 4>*>(idx + (size_t)c * 4);
             pack<W, 4> o;
 #pragma unroll

@@ -123,7 +123,9 @@ __global__ void __launch_bounds__(BLOCK) agg_kernel(KeySpec ks, AccSpec as, GTab
 
     const uint32_t nchunk = n >> 2;   // 4 consecutive rows per lane per step
     const bool vec_ok = K32 && ks.nkeys == 1;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+    uint32_t c_lo, c_hi;
+    wg_span(nchunk, c_lo, c_hi);
+    for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
         const size_t base = (size_t)c * 4;
         uint64_t key[4];
         if (vec_ok) {
@@ -298,7 +300,10 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
     };
 
     const uint32_t nchunk = n >> 3;            // 8 consecutive rows per lane per step
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+    // a workgroup takes one CONTIGUOUS span of rows (many more workgroups than fit the chip, dispatched as earlier ones retire)
+    uint32_t c_lo, c_hi;
+    wg_span(nchunk, c_lo, c_hi);
+    for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
         const size_t base = (size_t)c * 8;
         pack<uint32_t, 4> k0 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base);
         pack<uint32_t, 4> k1 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base + 4);
@@ -446,7 +451,9 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
     };
 
     const uint32_t nchunk = n >> 2;
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+    uint32_t c_lo, c_hi;
+    wg_span(nchunk, c_lo, c_hi);
+    for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
         const size_t base = (size_t)c * 4;
         const pack<uint32_t, 4> f4 = *reinterpret_cast<const pack<uint32_t, 4>*>(sj.fk + base);
         const pack<uint32_t, 4> g4 = *reinterpret_cast<const pack<uint32_t, 4>*>(gkeys + base);
@@ -790,7 +797,9 @@ __global__ void __launch_bounds__(256) assign_kernel(KeySpec ks, GTable gt, cons
         if constexpr (LDS_COUNTS) atomicAdd(&lc[g], 1u); else atomicAdd(&counts[g], 1u);
         return g;
     };
-    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+    uint32_t c_lo, c_hi;
+    wg_span(nchunk, c_lo, c_hi);
+    for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
         const size_t base = (size_t)c * 4;
         uint64_t key[4];
         if (vec_ok) {
@@ -1087,6 +1096,10 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         const size_t lds = (size_t)(lcap + 1) * (4 + 8 * (size_t)as.nacc + (plan.need_count ? 4 : 0)) + 64;
         unsigned bpc = lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : 2;
         unsigned grid = aqg_grid(ctx, n / 8 + 1, 256, 2, bpc);
+        {
+            static const int nb_env = getenv("AQG_AGG32_BLOCKS") ? atoi(getenv("AQG_AGG32_BLOCKS")) : 0;
+            if (nb_env > 0) { uint64_t need = ((uint64_t)n / 8 + 255) / 256; grid = (unsigned)((uint64_t)nb_env < need ? nb_env : (need ? need : 1)); }
+        }
         auto launch = [&](auto kern) -> int {
             AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             aqg_kernel_timer_begin(ctx);

@@ -91,7 +91,9 @@ __device__ inline void probe_rows(const T* __restrict__ col, uint32_t n, const J
     const uint32_t nchunk = n >> 2;
     const bool aligned = ((reinterpret_cast<uintptr_t>(col) & (sizeof(T) * 4 > 16 ? 15 : sizeof(T) * 4 - 1)) | (reinterpret_cast<uintptr_t>(out) & 15)) == 0;
     if (aligned) {
-        for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < nchunk; c += gridDim.x * blockDim.x) {
+        uint32_t c_lo, c_hi;
+        wg_span(nchunk, c_lo, c_hi);
+        for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
             const pack<T, 4> kv = *reinterpret_cast<const pack<T, 4>*>(col + (size_t)c * 4);
             uint64_t k[4], cur[4];
             uint32_t s[4];

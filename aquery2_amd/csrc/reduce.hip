@@ -99,16 +99,18 @@ __global__ void __launch_bounds__(256) stats_kernel(const T* __restrict__ x, uin
     if (head > n) head = n;
     const T* xb = x + head;
     uint32_t nvec = (n - head) / N;
-    uint32_t stride = gridDim.x * blockDim.x;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = blockDim.x;                 // a workgroup walks one contiguous span of the vectors (dev_common.hpp: wg_span)
+    uint32_t v_lo, v_hi;
+    wg_span(nvec, v_lo, v_hi);
+    uint32_t i = v_lo + threadIdx.x;
     // 4 independent 16-byte loads in flight per lane
-    for (; i + 3 * (uint64_t)stride < nvec; i += 4 * stride) {
+    for (; i + 3 * (uint64_t)stride < v_hi; i += 4 * stride) {
         vec16<T> a = load16(xb + (size_t)i * N), b = load16(xb + (size_t)(i + stride) * N);
         vec16<T> c = load16(xb + (size_t)(i + 2 * stride) * N), d = load16(xb + (size_t)(i + 3 * stride) * N);
 #pragma unroll
         for (int j = 0; j < N; ++j) { visit(a.v[j]); visit(b.v[j]); visit(c.v[j]); visit(d.v[j]); }
     }
-    for (; i < nvec; i += stride) {
+    for (; i < v_hi; i += stride) {
         vec16<T> a = load16(xb + (size_t)i * N);
 #pragma unroll
         for (int j = 0; j < N; ++j) visit(a.v[j]);

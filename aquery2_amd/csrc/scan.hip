@@ -410,8 +410,10 @@ __global__ void __launch_bounds__(SB) shift_kernel(const T* __restrict__ x, uint
     // lane of a wavefront reads it from memory.  The loop bound is wavefront-uniform so that every lane takes part in the shuffle.
     const uint32_t nv_wave = (nv + 63) & ~63u;
     constexpr int U = 1;                                          // vectors per lane per step (4 measured slower: 1.76 vs 1.66 ms per 1e9 rows)
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t c0 = blockIdx.x * blockDim.x + threadIdx.x; c0 < nv_wave && aligned; c0 += stride * U) {
+    const uint32_t stride = blockDim.x;
+    uint32_t v_lo, v_hi;
+    wg_span(nv_wave, v_lo, v_hi, 256);                            // spans of whole wavefronts
+    for (uint32_t c0 = v_lo + threadIdx.x; c0 < v_hi && aligned; c0 += stride * U) {
         pack<T, V> cur[U];
         uint32_t base[U];
         bool live[U];
