@@ -401,6 +401,19 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
         }
     }
     __syncthreads();
+    __shared__ uint32_t wmax;                                        // largest |w| of the dimension side
+    if (threadIdx.x == 0) wmax = 0;
+    __syncthreads();
+    {
+        uint32_t m = 0;
+        for (uint32_t r = threadIdx.x; r < sj.nb; r += blockDim.x) {
+            const uint32_t wb = sj.dim_vals[r];
+            const uint32_t a = sj.dim_signed ? (uint32_t)((int32_t)wb < 0 ? 0u - wb : wb) : wb;
+            m = a > m ? a : m;
+        }
+        m = wave_reduce(m, OpMax{});
+        if (lane_id() == 0) atomicMax(&wmax, m);
+    }
     for (uint32_t s = threadIdx.x; s < sj.dcap; s += blockDim.x) if (dval[s] != NOROW) dval[s] = sj.dim_vals[dval[s]];
     const bool has_sent = dsent != NOROW;
     const uint32_t sent_w = has_sent ? sj.dim_vals[dsent] : 0;
@@ -450,42 +463,55 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
         return false;
     };
 
-    const uint32_t nchunk = n >> 2;
+    constexpr int R = 8;                                             // rows per lane per step: two 16-byte loads per column
+    const uint32_t nchunk = n / R;
     uint32_t c_lo, c_hi;
     wg_span(nchunk, c_lo, c_hi);
+    // |product| < 2^32 * wmax; when this workgroup's rows cannot overflow 63 bits of that, ONE 64-bit LDS atomic per row carries
+    // the whole product (split into its halves at the merge); otherwise the halves are summed separately
+    const bool one_acc = (uint64_t)wmax * ((uint64_t)(c_hi - c_lo) * R + R) < (1ull << 31);
     for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
-        const size_t base = (size_t)c * 4;
-        const pack<uint32_t, 4> f4 = *reinterpret_cast<const pack<uint32_t, 4>*>(sj.fk + base);
-        const pack<uint32_t, 4> g4 = *reinterpret_cast<const pack<uint32_t, 4>*>(gkeys + base);
-        const pack<uint32_t, 4> v4 = *reinterpret_cast<const pack<uint32_t, 4>*>(sj.vals + base);
-        uint32_t ds[4], dk[4], gs[4];
-        uint64_t gw[4];
+        const size_t base = (size_t)c * R;
+        uint32_t f[R], g[R], v[R];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                                // eight LDS probes in flight
-            ds[j] = hash32(f4.v[j]) & dmask; dk[j] = dkey[ds[j]];
-            gs[j] = hash32(g4.v[j]) & lmask; gw[j] = lkey[gs[j]];
+        for (int h = 0; h < R / 4; ++h) {
+            const pack<uint32_t, 4> f4 = *reinterpret_cast<const pack<uint32_t, 4>*>(sj.fk + base + 4 * h);
+            const pack<uint32_t, 4> g4 = *reinterpret_cast<const pack<uint32_t, 4>*>(gkeys + base + 4 * h);
+            const pack<uint32_t, 4> v4 = *reinterpret_cast<const pack<uint32_t, 4>*>(sj.vals + base + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[4 * h + j] = f4.v[j]; g[4 * h + j] = g4.v[j]; v[4 * h + j] = v4.v[j]; }
+        }
+        uint32_t ds[R], dk[R], gs[R];
+        uint64_t gw[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {                                // 2 R LDS probes in flight
+            ds[j] = hash32(f[j]) & dmask; dk[j] = dkey[ds[j]];
+            gs[j] = hash32(g[j]) & lmask; gw[j] = lkey[gs[j]];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < R; ++j) {
             uint32_t w;
-            if (!dim_lookup(f4.v[j], dk[j], ds[j], w)) continue;     // no partner: the row is not in the join
-            const uint64_t p = product(v4.v[j], w);
-            const uint32_t row = (uint32_t)base + j, k = g4.v[j];
+            if (!dim_lookup(f[j], dk[j], ds[j], w)) continue;        // no partner: the row is not in the join
+            const uint64_t p = product(v[j], w);
+            const uint32_t row = (uint32_t)base + j, k = g[j];
             uint32_t s = gs[j];
             if ((uint32_t)gw[j] == k && k != EMPTY32) {
                 if (row < (uint32_t)(gw[j] >> 32)) atomicMin(reinterpret_cast<uint32_t*>(lkey) + 2 * s + 1, row);
             } else {
                 s = group_slot(k);
                 if (s == FAIL) { to_global(k, row, p); continue; }
-                uint32_t* f = reinterpret_cast<uint32_t*>(lkey) + 2 * s + 1;
-                if (row < *f) atomicMin(f, row);
+                uint32_t* fr = reinterpret_cast<uint32_t*>(lkey) + 2 * s + 1;
+                if (row < *fr) atomicMin(fr, row);
             }
-            atomicAdd(reinterpret_cast<unsigned long long*>(&lacc[s]), lo_half(p));
-            atomicAdd(reinterpret_cast<unsigned long long*>(&lacc[LT + s]), hi_half(p));
+            if (one_acc) atomicAdd(reinterpret_cast<unsigned long long*>(&lacc[s]), (unsigned long long)p);
+            else {
+                atomicAdd(reinterpret_cast<unsigned long long*>(&lacc[s]), lo_half(p));
+                atomicAdd(reinterpret_cast<unsigned long long*>(&lacc[LT + s]), hi_half(p));
+            }
         }
     }
-    if (blockIdx.x == 0) {                                           // tail rows (< 4)
-        const uint32_t row = (nchunk << 2) + threadIdx.x;
+    if (blockIdx.x == 0) {                                           // tail rows (< R)
+        const uint32_t row = nchunk * R + threadIdx.x;
         if (row < n) {
             const uint32_t k = sj.fk[row], s0 = hash32(k) & dmask;
             uint32_t w;
@@ -500,8 +526,13 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
         uint32_t g = gt_find_or_insert(gt, (uint64_t)(uint32_t)wd);
         if (g == FAIL) continue;
         atomicMin(gt.first_p(g), first);
-        atomicAdd(reinterpret_cast<unsigned long long*>(gt.acc_p(0, g)), (unsigned long long)lacc[s]);
-        atomicAdd(reinterpret_cast<unsigned long long*>(gt.acc_p(1, g)), (unsigned long long)lacc[LT + s]);
+        if (one_acc) {                                              // lacc[s] is the exact (signed or unsigned) 64-bit sum of this workgroup
+            atomicAdd(reinterpret_cast<unsigned long long*>(gt.acc_p(0, g)), lo_half(lacc[s]));
+            atomicAdd(reinterpret_cast<unsigned long long*>(gt.acc_p(1, g)), hi_half(lacc[s]));
+        } else {
+            atomicAdd(reinterpret_cast<unsigned long long*>(gt.acc_p(0, g)), (unsigned long long)lacc[s]);
+            atomicAdd(reinterpret_cast<unsigned long long*>(gt.acc_p(1, g)), (unsigned long long)lacc[LT + s]);
+        }
     }
 }
 
@@ -1089,7 +1120,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         unsigned bpc = lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : lds <= 80 * 1024 ? 2 : 1;
         AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&starjoin_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         aqg_kernel_timer_begin(ctx);
-        hipLaunchKernelGGL(starjoin_kernel, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, bpc)), dim3(256), lds, ctx->stream, static_cast<const uint32_t*>(ks.col[0]), *plan.sj, gt, n, lcap);
+        hipLaunchKernelGGL(starjoin_kernel, dim3(aqg_grid(ctx, n / 8 + 1, 256, 2, bpc)), dim3(256), lds, ctx->stream, static_cast<const uint32_t*>(ks.col[0]), *plan.sj, gt, n, lcap);
         aqg_kernel_timer_end(ctx);
         AQG_TRY(aqg_check_launch(ctx, "starjoin_kernel"));
     } else if (n && fast) {

@@ -118,7 +118,8 @@ def test_config4_fused_star_join_groupby_sum(gpu, oracle):
     """aqg_join_groupby_sum == the composed pipeline == the oracle, incl. unmatched fact rows (inner join), duplicate and
     sentinel dimension keys, negative values and the first-occurrence order among JOINED rows"""
     rng = np.random.default_rng(44)
-    for n, nb, lo in ((2_000_003, 100, 1), (50_001, 37, -5), (7, 3, 0), (3, 4096, 0)):
+    for n, nb, lo, wlim in ((2_000_003, 100, 1, 2**31 - 1), (2_000_003, 100, 1, 60), (50_001, 37, -5, 2**31 - 1), (50_001, 37, -5, 7), (7, 3, 0, 2**31 - 1),
+                            (3, 4096, 0, 3)):        # small |w|: the one-accumulator path; large: the split halves
         fk = rng.integers(lo, lo + nb + 20, n).astype(np.int32)                # some keys have no partner
         gkey = rng.integers(-40, 40, n).astype(np.int32)
         val = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
@@ -127,7 +128,7 @@ def test_config4_fused_star_join_groupby_sum(gpu, oracle):
             dim_key[5] = dim_key[30]                                             # duplicate: the lowest row wins
             dim_key[7] = np.iinfo(np.int32).min                                 # the LDS empty mark as a key
             fk[::11] = np.iinfo(np.int32).min
-        dim_w = rng.integers(-2**31, 2**31 - 1, nb).astype(np.int32)
+        dim_w = rng.integers(-wlim - 1, wlim, nb).astype(np.int32)
         gb = gpu.join_groupby_sum(dim_key, dim_w, fk, gkey, val)
         # oracle: lookup (lowest build row), drop unmatched rows, exact products, grouped sum in first-occurrence order
         first = {}
