@@ -128,44 +128,65 @@ __global__ void __launch_bounds__(BLOCK) dense_agg_kernel(KeySpec ks, DenseSpec 
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) lacc[(size_t)a * PP + s] = acc_init(as.kind[a]);
         }
         __syncthreads();
+        // H groups of four consecutive rows per lane and step, all loads issued before the first LDS access
+        constexpr int H = NACC <= 5 ? 2 : 1;                         // (more accumulators: the second group would spill)
+        const uint32_t nstep = nchunk / H;                          // whole steps; the odd chunks behind them take the same path one by one
         uint32_t c_lo, c_hi;
-        wg_span(nchunk, c_lo, c_hi);
-        for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += BLOCK) {
-            const size_t base = (size_t)c * 4;
-            uint32_t idx[4];
-            dense_idx4(ks, ds, base, idx);
-            uint64_t vals[NACC ? NACC : 1][4];
-            _Pragma("unroll") for (int a = 0; a < NACC; ++a) val_operand4(as.dt[a], as.col[a], base, as.kind[a], as.square[a], as.part[a], vals[a]);
-            uint32_t f[4];
+        wg_span(nstep, c_lo, c_hi);
+        auto rows = [&](const uint32_t (&idx)[4], const uint64_t (&vals)[NACC ? NACC : 1][4], size_t base) {
+            uint32_t f[4], id[4];
             bool in[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { idx[j] -= lo; in[j] = idx[j] < PP; f[j] = lfirst[in[j] ? idx[j] : 0]; }   // four LDS reads in flight
+            for (int j = 0; j < 4; ++j) { id[j] = idx[j] - lo; in[j] = id[j] < PP; f[j] = lfirst[in[j] ? id[j] : 0]; }   // four LDS reads in flight
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (in[j] && (uint32_t)base + j < f[j]) atomicMin(&lfirst[idx[j]], (uint32_t)base + j);
+            for (int j = 0; j < 4; ++j) if (in[j] && (uint32_t)base + j < f[j]) atomicMin(&lfirst[id[j]], (uint32_t)base + j);
             if (need_count) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (in[j]) atomicAdd(&lcount[idx[j]], 1u);
+                for (int j = 0; j < 4; ++j) if (in[j]) atomicAdd(&lcount[id[j]], 1u);
             }
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
                 uint64_t* la = lacc + (size_t)a * PP;
                 switch (as.kind[a]) {   // wave-uniform
                 case ACC_ADD_I:
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (in[j]) atomicAdd(reinterpret_cast<unsigned long long*>(&la[idx[j]]), (unsigned long long)vals[a][j]);
+                    for (int j = 0; j < 4; ++j) if (in[j]) atomicAdd(reinterpret_cast<unsigned long long*>(&la[id[j]]), (unsigned long long)vals[a][j]);
                     break;
                 case ACC_ADD_F:
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (in[j]) atomicAdd(reinterpret_cast<double*>(&la[idx[j]]), __builtin_bit_cast(double, vals[a][j]));
+                    for (int j = 0; j < 4; ++j) if (in[j]) atomicAdd(reinterpret_cast<double*>(&la[id[j]]), __builtin_bit_cast(double, vals[a][j]));
                     break;
                 case ACC_MIN:
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (in[j]) atomicMin(reinterpret_cast<unsigned long long*>(&la[idx[j]]), (unsigned long long)vals[a][j]);
+                    for (int j = 0; j < 4; ++j) if (in[j]) atomicMin(reinterpret_cast<unsigned long long*>(&la[id[j]]), (unsigned long long)vals[a][j]);
                     break;
                 default:
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (in[j]) atomicMax(reinterpret_cast<unsigned long long*>(&la[idx[j]]), (unsigned long long)vals[a][j]);
+                    for (int j = 0; j < 4; ++j) if (in[j]) atomicMax(reinterpret_cast<unsigned long long*>(&la[id[j]]), (unsigned long long)vals[a][j]);
                     break;
                 }
+            }
+        };
+        for (uint32_t st = c_lo + threadIdx.x; st < c_hi; st += BLOCK) {
+            uint32_t idx[H][4];
+            uint64_t vals[H][NACC ? NACC : 1][4];
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const size_t base = ((size_t)st * H + h) * 4;
+                dense_idx4(ks, ds, base, idx[h]);
+                _Pragma("unroll") for (int a = 0; a < NACC; ++a) val_operand4(as.dt[a], as.col[a], base, as.kind[a], as.square[a], as.part[a], vals[h][a]);
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h) rows(idx[h], vals[h], ((size_t)st * H + h) * 4);
+        }
+        if (blockIdx.x == 0) {                                       // chunks behind the last whole step (< H)
+            const uint32_t c = nstep * H + threadIdx.x;
+            if (c < nchunk) {
+                const size_t base = (size_t)c * 4;
+                uint32_t idx[4];
+                uint64_t vals[NACC ? NACC : 1][4];
+                dense_idx4(ks, ds, base, idx);
+                _Pragma("unroll") for (int a = 0; a < NACC; ++a) val_operand4(as.dt[a], as.col[a], base, as.kind[a], as.square[a], as.part[a], vals[a]);
+                rows(idx, vals, base);
             }
         }
         __syncthreads();
