@@ -1,4 +1,6 @@
-// partition.hip -- high-cardinality group-by without global atomics.
+// partition.hip -- high-cardinality group-by without global atomics: the plan of aqg_groupby_agg for more groups than LDS
+// holds (replaces AQHashTable's robin-hood build, reference server/hasher.h:146-199 + server/unordered_dense.h:1117-1147, and
+// the generated per-group loop engine/ast.py:722-789; h2o Q3 / Q5 / Q7).
 //
 // Scattered device-scope atomics top out near 3e10 per second on MI355X (they execute at the memory side; measured: h2o Q5,
 // 1e9 rows, 1e7 groups: 130-140 ms through the HBM table), so groups that do not fit a workgroup's LDS table are handled by
