@@ -25,7 +25,7 @@ def run(module, dataset, *funcs, cwd=None):
 def test_emitted_modules_compile():
     """CPU: the generated-shape translation units compile and link against the new library"""
     build()
-    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "distinct_orderby.so", "host_main"):
+    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "distinct_orderby.so", "funcs_udf.so", "host_main"):
         assert os.path.exists(os.path.join(EM, "build", m))
 
 
@@ -147,3 +147,34 @@ def test_distinct_order_by_materialize_colview():
         chk = (chk + 2**63) % 2**64 - 2**63          # long long wrap
     assert out[-2] == f"checksum {chk}"
     assert out[-1] == "done."
+
+
+@pytest.mark.gpu
+def test_user_functions_inside_the_group_loop():
+    """tests/funcs.a: UDF lambdas (covariance / sd / pairCorr) composed over per-group gathers"""
+    import math
+    import numpy as np
+    build()
+    out = run("funcs_udf.so", "test_csv", "dll_funcs").strip().splitlines()
+    a = [1, 2, 2, 1, 1, 4, 2, 2, 1, 3, 1, 3, 2, 3, 2, 2, 2, 3, 2, 1]
+    b = [1, 1, 4, 2, 2, 2, 1, 1, 2, 2, 2, 2, 1, 3, 2, 3, 4, 4, 3, 2]
+    c = [2, 2, 3, 2, 3, 1, 3, 1, 3, 4, 3, 1, 4, 4, 3, 4, 1, 1, 2, 3]
+    d = [2, 2, 4, 2, 4, 4, 3, 2, 4, 2, 3, 2, 2, 4, 1, 4, 2, 2, 2, 1]
+    order = []
+    for k in a:
+        if k not in order:
+            order.append(k)
+    want = []
+    for k in order:
+        rows = [i for i in range(len(a)) if a[i] == k][::-1]            # vecs[g]: descending row ids
+        x, y = np.array([c[i] for i in rows], float), np.array([b[i] for i in rows], float)
+        cov = lambda u, v: np.mean((u - u.mean()) * (v - v.mean()))
+        with np.errstate(all="ignore"):
+            pc = cov(x, y) / (np.sqrt(cov(x, x)) * np.sqrt(cov(y, y)))
+        want.append((pc, k, sum(b[j] for j in rows)))
+    body = [l.split(",") for l in out[2:-1] if "," in l]
+    assert out[-1] == "done." and len(body) == len(want)
+    for got, (v, k, sb) in zip(body, want):
+        g = float(got[0])
+        assert (math.isnan(g) and math.isnan(v)) or abs(g - v) < 1e-5, (got, v)
+        assert int(got[1]) == k and int(got[2]) == sb
