@@ -114,11 +114,24 @@ __global__ void __launch_bounds__(SB) part_hist_kernel(KeyIn kin, Segs sg, uint3
     if (!tile_range(sg, blockIdx.x, seg, tin, ntseg, rb, re)) return;
     if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
-    uint64_t key[SR];
-    load_keys(kin, rb, re, key);       // which rows a lane counts is irrelevant here: same loader as the scatter
+    // which rows a lane counts is irrelevant here; for single 4-byte keys lane-strided scalar loads measured 0.3 ms per
+    // 1e9 rows faster than the scatter's 16-byte groups (0.9 vs 1.2 ms), so that shape takes them
+    const bool one_u32 = kin.from_cols ? (kin.ks.nkeys == 1 && aqg_dtype_size_dev(kin.ks.dt[0]) == 4) : kin.ksz == 4;
+    if (one_u32) {
+        const uint32_t* kp = static_cast<const uint32_t*>(kin.from_cols ? kin.ks.col[0] : kin.rec);
+        uint32_t k32[SR];
 #pragma unroll
-    for (int r = 0; r < SR; ++r)
-        if (rb + tile_row(r) < re) atomicAdd(&h[(part_id(key[r], kin.pbits) >> shift) & (nb - 1)], 1u);
+        for (int r = 0; r < SR; ++r) { const uint32_t j = rb + r * SB + threadIdx.x; k32[r] = kp[j < re ? j : re - 1]; }
+#pragma unroll
+        for (int r = 0; r < SR; ++r)
+            if (rb + r * SB + threadIdx.x < re) atomicAdd(&h[(part_id((uint64_t)k32[r], kin.pbits) >> shift) & (nb - 1)], 1u);
+    } else {
+        uint64_t key[SR];
+        load_keys(kin, rb, re, key);
+#pragma unroll
+        for (int r = 0; r < SR; ++r)
+            if (rb + tile_row(r) < re) atomicAdd(&h[(part_id(key[r], kin.pbits) >> shift) & (nb - 1)], 1u);
+    }
     __syncthreads();
     if (threadIdx.x < nb) hist[(size_t)sg.tile_prefix[seg] * nb + (size_t)threadIdx.x * ntseg + tin] = h[threadIdx.x];
 }
