@@ -1049,16 +1049,18 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     const bool use_part = !part_off && !dense && !use_lds && !ks.wide && !for_build && n >= (1u << 20) && hint <= (1u << 25);
     uint32_t part_lcap = 0, pbits = 0;
     if (use_part) {
-        // LDS table of one partition: as many slots as fit 72 KB (two 512-thread workgroups per CU); the slot of a hash is
-        // a multiply-shift, so the capacity need not be a power of two.  Partitions are sized for a load factor <= LF/16:
-        // measured (1e9 rows, 1e7 groups) the LDS aggregation runs 2x faster at 0.3 than at 0.6 (probe sequences are
-        // walked by whole wavefronts), while every extra partition bit costs the scatter passes ~10 %.
-        static const int lf16 = getenv("AQG_PART_LF16") ? atoi(getenv("AQG_PART_LF16")) : 6;
-        static const int lds_kb = getenv("AQG_PART_LDSKB") ? atoi(getenv("AQG_PART_LDSKB")) : 72;
+        // LDS table of one partition: as many slots as fit the budget (the slot of a hash is a multiply-shift, so the
+        // capacity need not be a power of two).  Partitions are sized for a LOW load factor: probe sequences are walked by
+        // whole wavefronts, and measured at 1e9 rows / 1e7 groups the LDS aggregation takes 3.9 ms at load 0.20, 5.6 ms at
+        // 0.22-0.25, 6.7-7.2 ms at 0.30-0.33 and 18 ms at 0.6 (two accumulators), while one more partition bit costs the two
+        // scatter passes 1-2 ms.  AQG_PART_LF1000 / AQG_PART_LDSKB / AQG_PART_LCAP: measurement switches.
+        static const int lf1000 = getenv("AQG_PART_LF1000") ? atoi(getenv("AQG_PART_LF1000")) : 210;
+        static const int lds_kb = getenv("AQG_PART_LDSKB") ? atoi(getenv("AQG_PART_LDSKB")) : 60;
         const size_t sb = 16 + 8 * (size_t)as.nacc;
         part_lcap = (uint32_t)((size_t)lds_kb * 1024 / sb) - 1;
+        { static const int lcap_env = getenv("AQG_PART_LCAP") ? atoi(getenv("AQG_PART_LCAP")) : 0; if (lcap_env > 0) part_lcap = (uint32_t)lcap_env; }
         pbits = 10;                                  // at least 1024 partitions: every CU gets several
-        while (pbits < 16 && ((uint64_t)hint >> pbits) * 16 > (uint64_t)part_lcap * lf16) ++pbits;
+        while (pbits < 16 && ((uint64_t)hint >> pbits) * 1000 > (uint64_t)part_lcap * lf1000) ++pbits;
         gcap = (uint32_t)((uint64_t)hint + hint / 4 + 4096 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : (uint64_t)hint + hint / 4 + 4096);   // compact record table
     }
 

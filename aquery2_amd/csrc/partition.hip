@@ -261,7 +261,6 @@ __global__ void __launch_bounds__(1024) tile_prefix_kernel(const uint32_t* __res
 }
 
 // ---- aggregate each partition in LDS -------------------------------------------------------------------------------------
-constexpr int AB = 512;    // threads per workgroup
 constexpr int AR = 4;      // rows per thread and step, loaded together
 struct AggIn { const void* col[MAXACC]; int esz[MAXACC]; };   // partitioned value arrays (4- or 8-byte elements); null: the row id
 
@@ -281,7 +280,10 @@ __device__ inline uint64_t val_operand_bits(int dt, uint64_t bits, int kind, int
 }
 
 // one workgroup per partition (grid-stride): LDS open addressing {key64, first_row, count, acc...}; groups are appended to `out`
-template <int NACC>
+// AB threads per workgroup.  Measured at 1e9 rows / 1e7 groups (two accumulators): what this kernel's time follows is the
+// table's load factor (3.9 ms at 0.20 ... 7.2 ms at 0.33) and having at least 16 wavefronts per CU (8: 12.5 ms); 1024-thread
+// workgroups were no faster than 512 (the per-partition init / emit phases with their barriers grow with the workgroup).
+template <int NACC, int AB>
 __global__ void __launch_bounds__(AB) part_agg_kernel(const void* __restrict__ rkeys, int ksz, const uint32_t* __restrict__ rrows, AccSpec as, AggIn in,
                                                       const uint32_t* __restrict__ pstart, uint32_t nparts, uint32_t pbits, uint32_t lcap, int need_count,
                                                       GTable out, uint32_t out_cap) {
@@ -515,25 +517,28 @@ int aqg_partition_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as_i
         else { in.col[a] = nullptr; in.esz[a] = 4; }     // row-index operands: the carried row id
     }
     const size_t lds = ((size_t)lcap + 1) * (8 + 8 * (size_t)as.nacc + 4 + 4);
-    const unsigned per_cu = lds <= 48 * 1024 ? 3 : lds <= 76 * 1024 ? 2 : 1;
+    unsigned per_cu = (unsigned)((160 * 1024) / (lds + 1024));
+    if (per_cu < 1) per_cu = 1;
+    const unsigned block = 512;
+    if (per_cu * block > 2048) per_cu = 2048 / block;
     unsigned grid = nparts < (unsigned)ctx->num_cu * per_cu ? nparts : (unsigned)ctx->num_cu * per_cu;
     auto launch = [&](auto kern) -> int {
         AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         aqg_kernel_timer_begin(ctx);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(AB), lds, ctx->stream, (const void*)bufs[cur][0], ksz, (const uint32_t*)bufs[cur][1], as, in, (const uint32_t*)pstart, nparts,
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, ctx->stream, (const void*)bufs[cur][0], ksz, (const uint32_t*)bufs[cur][1], as, in, (const uint32_t*)pstart, nparts,
                            pbits, lcap, need_count, out, out_cap);
         aqg_kernel_timer_end(ctx);
         return aqg_check_launch(ctx, "part_agg_kernel");
     };
     switch (as.nacc) {
-    case 0: return launch(&part_agg_kernel<0>);
-    case 1: return launch(&part_agg_kernel<1>);
-    case 2: return launch(&part_agg_kernel<2>);
-    case 3: return launch(&part_agg_kernel<3>);
-    case 4: return launch(&part_agg_kernel<4>);
-    case 5: return launch(&part_agg_kernel<5>);
-    case 6: return launch(&part_agg_kernel<6>);
-    case 7: return launch(&part_agg_kernel<7>);
-    default: return launch(&part_agg_kernel<8>);
+    case 0: return launch(&part_agg_kernel<0, 512>);
+    case 1: return launch(&part_agg_kernel<1, 512>);
+    case 2: return launch(&part_agg_kernel<2, 512>);
+    case 3: return launch(&part_agg_kernel<3, 512>);
+    case 4: return launch(&part_agg_kernel<4, 512>);
+    case 5: return launch(&part_agg_kernel<5, 512>);
+    case 6: return launch(&part_agg_kernel<6, 512>);
+    case 7: return launch(&part_agg_kernel<7, 512>);
+    default: return launch(&part_agg_kernel<8, 512>);
     }
 }

@@ -12,5 +12,5 @@ for name, keys, ops, vals in (("Q5", [id6], [ck.RED_SUM] * 3, [v1, v2, v3]), ("Q
         d.sync(); d.timer_start()
         h = d.groupby_agg(keys, ops, vals, hint=n // K + 1024, handle=h)
         best = min(best, d.timer_stop_ms()); kb = min(kb, d.last_kernel_ms())
-    print(name, "LF16", os.environ.get("AQG_PART_LF16"), "KB", os.environ.get("AQG_PART_LDSKB"), "call ms %.2f  agg kernel ms %.2f" % (best, kb), "groups", h.ngroups, flush=True)
+    print(name, "LF1000", os.environ.get("AQG_PART_LF1000"), "KB", os.environ.get("AQG_PART_LDSKB"), "call ms %.2f  agg kernel ms %.2f" % (best, kb), "groups", h.ngroups, flush=True)
     h.destroy()
