@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
     uint32_t* lcount = lkey + LT;                                            // [LT] if COUNT
     uint32_t* ltouch = lcount + (COUNT ? LT : 0);                            // [1]  sentinel slot used?
     __shared__ uint32_t lused;
-    const uint32_t lmask = lcap - 1, llimit = lcap - (lcap >> 2);
+    const uint32_t lmask = lcap - 1, llimit = lcap - (lcap >> 2), lbits = 31 - __clz(lcap);
     for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) {
         lkey[s] = EMPTY32;
         _Pragma("unroll") for (int a = 0; a < NV; ++a) lacc[(size_t)a * LT + s] = 0;
@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
 
     auto slow_slot = [&](uint32_t k) -> uint32_t {      // insert path (first sight of a key in this workgroup)
         if (k == EMPTY32) { *ltouch = 1; return lcap; }
-        uint32_t s = hash32(k) & lmask;
+        uint32_t s = fib_slot(k, lbits);
         for (uint32_t p = 0; p <= lmask; ++p) {
             uint32_t cur = lkey[s];
             if (cur == k) return s;
@@ -316,9 +316,9 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) { k[j] = k0.v[j]; k[4 + j] = k1.v[j]; }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { slot[j] = hash32(k[j]) & lmask; cur[j] = lkey[slot[j]]; }     // eight probes in flight
+        for (int j = 0; j < 8; ++j) { slot[j] = fib_slot(k[j], lbits); cur[j] = lkey[slot[j]]; }     // eight probes in flight
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (cur[j] != k[j] || k[j] == EMPTY32) slot[j] = slow_slot(k[j]);
+        for (int j = 0; j < 8; ++j) if (cur[j] != k[j] || k[j] == EMPTY32) slot[j] = slow_slot(k[j]);   // (walking the missed rows' probe sequences together measured slower here)
         if constexpr (COUNT) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(&lcount[slot[j]], 1u);
@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
     uint32_t* dkey = reinterpret_cast<uint32_t*>(lacc + 2 * (size_t)LT);   // [dcap]
     uint32_t* dval = dkey + sj.dcap;                                 // [dcap] row while building, then w
     __shared__ uint32_t lused, dsent;                                // dsent: row / w of the dimension key equal to EMPTY32
-    const uint32_t lmask = lcap - 1, llimit = lcap - (lcap >> 2), dmask = sj.dcap - 1;
+    const uint32_t lmask = lcap - 1, llimit = lcap - (lcap >> 2), dmask = sj.dcap - 1, lbits = 31 - __clz(lcap), dbits = 31 - __clz(sj.dcap);
     for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) { lkey[s] = ((uint64_t)NOROW << 32) | EMPTY32; lacc[s] = 0; lacc[LT + s] = 0; }
     for (uint32_t s = threadIdx.x; s < sj.dcap; s += blockDim.x) { dkey[s] = EMPTY32; dval[s] = NOROW; }
     if (threadIdx.x == 0) { lused = 0; dsent = NOROW; }
@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
     for (uint32_t r = threadIdx.x; r < sj.nb; r += blockDim.x) {     // dimension table: key -> lowest row
         const uint32_t k = sj.dim_keys[r];
         if (k == EMPTY32) { atomicMin(&dsent, r); continue; }
-        uint32_t s = hash32(k) & dmask;
+        uint32_t s = fib_slot(k, dbits);
         while (true) {
             uint32_t cur = dkey[s];
             if (cur == EMPTY32) { uint32_t old = atomicCAS(&dkey[s], EMPTY32, k); cur = old == EMPTY32 ? k : old; }
@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
     auto group_slot = [&](uint32_t k) -> uint32_t {                  // insert path of the group table
         if (k == EMPTY32) return lcap;
         uint32_t* kw = reinterpret_cast<uint32_t*>(lkey);
-        uint32_t s = hash32(k) & lmask;
+        uint32_t s = fib_slot(k, lbits);
         for (uint32_t p = 0; p <= lmask; ++p) {
             uint32_t cur = kw[2 * s];
             if (cur == k) return s;
@@ -485,8 +485,8 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
         uint64_t gw[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) {                                // 2 R LDS probes in flight
-            ds[j] = hash32(f[j]) & dmask; dk[j] = dkey[ds[j]];
-            gs[j] = hash32(g[j]) & lmask; gw[j] = lkey[gs[j]];
+            ds[j] = fib_slot(f[j], dbits); dk[j] = dkey[ds[j]];
+            gs[j] = fib_slot(g[j], lbits); gw[j] = lkey[gs[j]];
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
     if (blockIdx.x == 0) {                                           // tail rows (< R)
         const uint32_t row = nchunk * R + threadIdx.x;
         if (row < n) {
-            const uint32_t k = sj.fk[row], s0 = hash32(k) & dmask;
+            const uint32_t k = sj.fk[row], s0 = fib_slot(k, dbits);
             uint32_t w;
             if (dim_lookup(k, dkey[s0], s0, w)) to_global(gkeys[row], row, product(sj.vals[row], w));
         }
