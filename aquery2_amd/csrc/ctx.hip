@@ -145,6 +145,12 @@ int aqg_d2h(aqg_ctx* ctx, void* dst, const void* src, size_t bytes) {
     AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return AQG_OK;
 }
+int aqg_d2d(aqg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || ((!dst || !src) && bytes)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_d2d: bad argument");
+    if (!bytes) return AQG_OK;
+    AQG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return AQG_OK;
+}
 int aqg_memset(aqg_ctx* ctx, void* dst, int byte, size_t bytes) {
     if (!ctx) return AQG_ERR_ARG;
     if (!bytes) return AQG_OK;

@@ -67,3 +67,78 @@ class GroupTableExchange:
             torch.cuda.synchronize()
         self.merged = self.dev.groupby_merge_packed(self.all.data_ptr(), self.world, self.gmax, self.key_tag, self.op, self.merged)
         return self.merged
+
+
+# ---- scans and windows over row-range shards ("windows need a fixed halo") ---------------------------------------
+# A shard needs the last w - 1 rows of the shard before it (sliding windows), its last row (deltas / prev / ratios), or one
+# value folded over everything before it (running min / max).  `exchange_tails` is the one collective; the functions below
+# are pure device code so that they can be tested on one GPU by feeding the halos by hand.
+
+def exchange_tails(dist, tail, head=None):
+    """all_gather every rank's `tail` (1-D tensor, the same length on every rank: its last h rows) and return the tail of the
+    previous rank (None on rank 0).  With `head` (its first rows) also returns the head of the next rank (None on the last)."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    out = torch.zeros(world * tail.numel(), dtype=tail.dtype, device=tail.device)
+    dist.all_gather_into_tensor(out, tail.contiguous())
+    prev_tail = out.view(world, -1)[rank - 1].clone() if rank > 0 else None
+    if head is None:
+        return prev_tail
+    outh = torch.zeros(world * head.numel(), dtype=head.dtype, device=head.device)
+    dist.all_gather_into_tensor(outh, head.contiguous())
+    next_head = outh.view(world, -1)[rank + 1].clone() if rank + 1 < world else None
+    return prev_tail, next_head
+
+
+def _concat(dev, parts, dtype):
+    """device buffer holding the concatenation of DevBufs / None entries"""
+    from .capi import DevBuf
+    import ctypes as C
+    import numpy as np
+    parts = [p for p in parts if p is not None and p.n]
+    n = sum(p.n for p in parts)
+    buf = dev.empty(max(n, 1), dtype)
+    off = 0
+    isz = np.dtype(dtype).itemsize
+    for p in parts:
+        dev._chk(dev.lib.aqg_d2d(dev.ctx, C.c_void_p(buf.ptr + off * isz), C.c_void_p(p.ptr), C.c_size_t(p.n * isz)), "aqg_d2d")
+        off += p.n
+    return DevBuf(dev, buf.ptr, dtype, n, owned=False), buf
+
+
+def window_scan_with_halo(dev, op, x_local, halo_prev, w):
+    """sumw / avgw / minw / maxw / ratiow of this shard's rows given the last (w - 1) rows (ratiow: w rows) of the shard
+    before it (`halo_prev`: DevBuf or None on the first shard).  Returns a DevBuf view of the n_local results (+ its owner)."""
+    from .capi import DevBuf, TAG2NP
+    import numpy as np
+    h = halo_prev.n if halo_prev is not None else 0
+    cat, owner = _concat(dev, [halo_prev, x_local], x_local.dtype)
+    res = dev.scan(op, cat, w, keep=True)
+    ot = np.dtype(TAG2NP[dev.lib.aqg_scan_out_dtype(op, x_local.tag)])
+    view = DevBuf(dev, res.ptr + h * ot.itemsize, ot, x_local.n, owned=False)
+    view._keep = (res, owner)
+    return view
+
+
+def shift_scan_with_neighbours(dev, op, x_local, prev_last, next_first):
+    """deltas / prev / aggnext with the neighbouring shards' boundary rows (1-element DevBufs or None at the table's ends)"""
+    from .capi import DevBuf
+    import numpy as np
+    h = 1 if prev_last is not None else 0
+    cat, owner = _concat(dev, [prev_last, x_local, next_first], x_local.dtype)
+    res = dev.scan(op, cat, 0, keep=True)
+    view = DevBuf(dev, res.ptr + h * np.dtype(x_local.dtype).itemsize, x_local.dtype, x_local.n, owned=False)
+    view._keep = (res, owner)
+    return view
+
+
+def running_minmax_with_carry(dev, op, x_local, carry):
+    """mins / maxs of this shard given the fold of every earlier row (`carry`: 1-element DevBuf or None): the carry is scanned
+    as a row in front of the shard's rows"""
+    from .capi import DevBuf
+    import numpy as np
+    h = 1 if carry is not None else 0
+    cat, owner = _concat(dev, [carry, x_local], x_local.dtype)
+    res = dev.scan(op, cat, 0, keep=True)
+    view = DevBuf(dev, res.ptr + h * np.dtype(x_local.dtype).itemsize, x_local.dtype, x_local.n, owned=False)
+    view._keep = (res, owner)
+    return view

@@ -86,6 +86,8 @@ int aqg_malloc(aqg_ctx* ctx, size_t bytes, void** dptr);
 int aqg_free(aqg_ctx* ctx, void* dptr);
 int aqg_h2d(aqg_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int aqg_d2h(aqg_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* device-to-device copy on the context's stream (vector_type::subvec_memcpy / the copy constructors, vector_type.hpp:83-135,228-240) */
+int aqg_d2d(aqg_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes);
 int aqg_memset(aqg_ctx* ctx, void* dst_dev, int byte, size_t bytes);
 
 /* Device mirror of a borrowed host column (the ColRef<T>(len, server->getCol(i))

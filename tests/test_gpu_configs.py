@@ -278,3 +278,44 @@ def test_maximum_row_count(gpu):
     fives = aquery2_amd.DevBuf(gpu, out.ptr, np.int32, kept.value, owned=False)
     assert int(gpu.reduce(ck.RED_MIN, fives)) == 5 and int(gpu.reduce(ck.RED_SUM, fives)) == 5 * kept.value
     assert abs(kept.value / n - 0.2) < 1e-3
+
+
+def test_scans_and_windows_over_row_range_shards(gpu, oracle):
+    """three row-range shards of one ordered series; every shard gets only the halo an exchange would bring
+    (last w-1 rows / boundary rows / the fold of everything before) and its results equal the whole-column scan"""
+    import aquery2_amd
+    from aquery2_amd import shard
+    n = 300_007
+    price = oracle.gen_column(ck.GEN_PRICE, 42, 0, n, n, K)
+    bounds = [0, 100_000, 100_050, n]                         # the middle shard is shorter than some of the windows' halos allow: w <= 51 below
+    dev_shards = [gpu.to_device(np.ascontiguousarray(price[bounds[r]:bounds[r + 1]])) for r in range(3)]
+    def tail(r, h):                                             # what exchange_tails would deliver to rank r + 1
+        lo = max(bounds[r + 1] - h, 0)
+        return gpu.to_device(np.ascontiguousarray(price[lo:bounds[r + 1]]))
+    for name, w in (("sumw", 7), ("avgw", 50), ("minw", 3), ("maxw", 51), ("ratiow", 1)):
+        op = ck.SCAN_NAMES[name]
+        h = w if name == "ratiow" else w - 1
+        want = oracle.scan(op, price, w)
+        for r in range(3):
+            halo = tail(r - 1, h) if r else None
+            got = shard.window_scan_with_halo(gpu, op, dev_shards[r], halo, w).to_host()
+            ref = want[bounds[r]:bounds[r + 1]]
+            if name == "avgw":
+                assert np.all(np.abs(got - ref) <= 1e-9 * np.abs(ref) * (np.arange(bounds[r], bounds[r + 1]) + 2)), (name, r)
+            else:
+                assert gu.same_bits(got, ref), (name, r)
+    for name in ("deltas", "prev", "aggnext"):
+        op = ck.SCAN_NAMES[name]
+        want = oracle.scan(op, price)
+        for r in range(3):
+            prev_last = gpu.to_device(price[bounds[r] - 1:bounds[r]].copy()) if r else None
+            next_first = gpu.to_device(price[bounds[r + 1]:bounds[r + 1] + 1].copy()) if r < 2 else None
+            got = shard.shift_scan_with_neighbours(gpu, op, dev_shards[r], prev_last, next_first).to_host()
+            assert gu.same_bits(got, want[bounds[r]:bounds[r + 1]]), (name, r)
+    for name, fold in (("mins", np.min), ("maxs", np.max)):
+        op = ck.SCAN_NAMES[name]
+        want = oracle.scan(op, price)
+        for r in range(3):
+            carry = gpu.to_device(np.array([fold(price[:bounds[r]])], dtype=price.dtype)) if r else None
+            got = shard.running_minmax_with_carry(gpu, op, dev_shards[r], carry).to_host()
+            assert gu.same_bits(got, want[bounds[r]:bounds[r + 1]]), (name, r)

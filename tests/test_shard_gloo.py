@@ -66,3 +66,40 @@ def test_shard_rows_cover_table():
         spans = [shard.shard_rows(n, w, r) for r in range(w)]
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+
+
+def _tails_worker(rank, world, port, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+    import torch.distributed as dist
+    from aquery2_amd import shard
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows = torch.arange(rank * 100, rank * 100 + 100, dtype=torch.int32)        # this shard's rows of an ordered column
+    prev_tail, next_head = shard.exchange_tails(dist, rows[-4:], rows[:1])
+    q.put((rank, None if prev_tail is None else prev_tail.tolist(), None if next_head is None else next_head.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halo_exchange_delivers_the_neighbours_rows():
+    """the one collective of sharded windows / shifts: every rank gets the last rows of the rank before it (and the first row of
+    the rank after it); the device side is covered on the GPU by test_scans_and_windows_over_row_range_shards"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_tails_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(3):
+        r, prev_tail, next_head = q.get(timeout=120)
+        got[r] = (prev_tail, next_head)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == (None, [100])
+    assert got[1] == ([96, 97, 98, 99], [200])
+    assert got[2] == ([196, 197, 198, 199], None)
