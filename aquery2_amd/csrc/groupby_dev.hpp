@@ -195,8 +195,12 @@ __host__ __device__ inline uint64_t acc_init(int kind) { return kind == ACC_MIN 
 // ---- global table ---------------------------------------------------------------------------
 // Slots only ever change EMPTY -> key, so a plain (possibly stale) load is safe: a stale EMPTY is
 // corrected by the device-scope compare-and-swap that follows.
+// Once some row has found the table full the call is going to be re-planned with a larger table: every later row gives up at
+// once instead of walking the whole (full) table first (1e6 distinct keys against a 2048-slot table: 300 ms -> 1 ms).
+__device__ inline bool gt_gave_up(const GTable& gt) { return __hip_atomic_load(&gt.flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; }
 __device__ inline uint32_t gt_find_or_insert(const GTable& gt, uint64_t key) {
     if (key == EMPTY64) return gt.cap;
+    if (gt_gave_up(gt)) return FAIL;
     uint32_t mask = gt.cap - 1, s = hash64(key) & mask;
     for (uint32_t p = 0; p < gt.cap; ++p) {
         uint64_t cur = (*gt.key_p(s));
@@ -232,6 +236,7 @@ __device__ inline bool rows_equal(const KeySpec& ks, size_t a, size_t b) {
     return true;
 }
 __device__ inline uint32_t gt_find_or_insert_wide(const GTable& gt, const KeySpec& ks, uint32_t row) {
+    if (gt_gave_up(gt)) return FAIL;
     uint32_t mask = gt.cap - 1, s = hash_wide(ks, row) & mask;
     for (uint32_t p = 0; p < gt.cap; ++p) {
         uint64_t cur = (*gt.key_p(s));
