@@ -213,7 +213,52 @@ __global__ void __launch_bounds__(BLOCK) dense_agg_kernel(KeySpec ks, DenseSpec 
     }
 }
 
+// second pass of aqg_groupby_build over a dense domain: reversemap[i] = dense id of row i's group, counts[g] += 1
+template <bool LDS_COUNTS>
+__global__ void __launch_bounds__(256) dense_assign_kernel(KeySpec ks, DenseSpec ds, const uint32_t* __restrict__ slot_gid, uint32_t n, uint32_t G,
+                                                           uint32_t* __restrict__ reversemap, uint32_t* __restrict__ counts) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint32_t* lc = reinterpret_cast<uint32_t*>(smem_raw);
+    if constexpr (LDS_COUNTS) { for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) lc[g] = 0; __syncthreads(); }
+    const uint32_t nchunk = n >> 2;
+    uint32_t c_lo, c_hi;
+    wg_span(nchunk, c_lo, c_hi);
+    for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
+        const size_t base = (size_t)c * 4;
+        uint32_t idx[4];
+        dense_idx4(ks, ds, base, idx);
+        pack<uint32_t, 4> o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.v[j] = slot_gid[idx[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { if constexpr (LDS_COUNTS) atomicAdd(&lc[o.v[j]], 1u); else atomicAdd(&counts[o.v[j]], 1u); }
+        *reinterpret_cast<pack<uint32_t, 4>*>(reversemap + base) = o;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const uint32_t row = (nchunk << 2) + threadIdx.x;
+        const uint32_t g = slot_gid[dense_idx1(ks, ds, row)];
+        reversemap[row] = g;
+        atomicAdd(&counts[g], 1u);
+    }
+    if constexpr (LDS_COUNTS) {
+        __syncthreads();
+        for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) { const uint32_t c = lc[g]; if (c) atomicAdd(&counts[g], c); }
+    }
+}
+
 } // namespace
+
+int aqg_dense_assign(aqg_ctx* ctx, const KeySpec& ks, const DenseSpec& ds, const uint32_t* slot_gid, uint32_t n, uint32_t G, uint32_t* reversemap, uint32_t* counts) {
+    const size_t lds = (size_t)G * 4 + 16;
+    if (lds <= 144 * 1024) {
+        const unsigned per_cu = (unsigned)((160 * 1024) / (lds + 1024)) > 8 ? 8 : (unsigned)((160 * 1024) / (lds + 1024));
+        AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_assign_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((dense_assign_kernel<true>), dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, per_cu ? per_cu : 1)), dim3(256), lds, ctx->stream, ks, ds, slot_gid, n, G, reversemap, counts);
+    } else {
+        hipLaunchKernelGGL((dense_assign_kernel<false>), dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 8)), dim3(256), 0, ctx->stream, ks, ds, slot_gid, n, G, reversemap, counts);
+    }
+    return aqg_check_launch(ctx, "dense_assign_kernel");
+}
 
 // Ranges of the key columns over n rows (synchronises).  Returns false when some column cannot take part (uint64 keys).
 int aqg_key_ranges(aqg_ctx* ctx, const KeySpec& ks, uint32_t n, long long* mins, long long* maxs, bool* ok) {

@@ -15,4 +15,5 @@ struct DenseSpec {
 int aqg_key_ranges(aqg_ctx* ctx, const KeySpec& ks, uint32_t n, long long* mins, long long* maxs, bool* ok);
 size_t aqg_dense_slot_bytes(const AccSpec& as, int need_count);
 bool aqg_dense_plan(const KeySpec& ks, const long long* mins, const long long* maxs, const AccSpec& as, int need_count, DenseSpec* ds);
+int aqg_dense_assign(aqg_ctx* ctx, const KeySpec& ks, const DenseSpec& ds, const uint32_t* slot_gid, uint32_t n, uint32_t G, uint32_t* reversemap, uint32_t* counts);
 int aqg_dense_aggregate(aqg_ctx* ctx, const KeySpec& ks, const DenseSpec& ds, const AccSpec& as, uint32_t n, int need_count, GTable gt);

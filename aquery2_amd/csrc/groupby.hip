@@ -998,8 +998,10 @@ int make_plan(aqg_ctx* ctx, int naggs, const int* ops, const int* dts, const voi
 }
 
 // One attempt at a given global capacity.  Returns AQG_ERR_OVERFLOW when the table filled up.
+struct DenseOut { bool used; DenseSpec spec; };      // tells aqg_groupby_build that the table is the direct-indexed one
+
 int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
-            GTable* gt_out, uint32_t** slot_gid_out, uint32_t** occ_out = nullptr) {
+            GTable* gt_out, uint32_t** slot_gid_out, uint32_t** occ_out = nullptr, DenseOut* dense_out = nullptr) {
     const AccSpec& as = plan.as;
     const bool k32 = ks.nkeys == 1 && ks.total_bytes == 4;
     uint32_t gcap = next_pow2((uint64_t)(hint < 512 ? 512 : hint) * 2);
@@ -1023,7 +1025,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     bool dense = false;
     DenseSpec dspec;
     static const bool dense_off = getenv("AQG_DISABLE_DENSE") != nullptr;    // A/B measurements only
-    if (!dense_off && !plan.sj && !use_lds && !for_build && n >= (1u << 20) &&
+    if (!dense_off && !plan.sj && !use_lds && (!for_build || dense_out) && n >= (1u << 20) &&
         (uint64_t)hint <= (uint64_t)(DENSE_LDS_BYTES / aqg_dense_slot_bytes(as, plan.need_count)) * DENSE_MAX_PASSES) {
         long long mins[MAXKEYS], maxs[MAXKEYS];
         bool ok = false;
@@ -1254,13 +1256,14 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(aqg_check_launch(ctx, "emit_kernel"));
     }
     if (gt_out) *gt_out = gt;
+    if (dense_out) { dense_out->used = dense; if (dense) dense_out->spec = dspec; }
     if (slot_gid_out) *slot_gid_out = slot_gid;
     if (occ_out) *occ_out = occ;
     return AQG_OK;
 }
 
 int run_with_retry(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
-                   GTable* gt_out, uint32_t** slot_gid_out, uint32_t** occ_out = nullptr);
+                   GTable* gt_out, uint32_t** slot_gid_out, uint32_t** occ_out = nullptr, DenseOut* dense_out = nullptr);
 
 // No hint and a large input: count the distinct tuples of the first 2^20 rows (a group-by without aggregates over a sample: well
 // under a millisecond) and size the plan from that, instead of discovering the cardinality by running -- and overflowing --
@@ -1290,12 +1293,12 @@ uint64_t estimate_groups(aqg_ctx* ctx, const KeySpec& ks, uint32_t n) {
 }
 
 int run_with_retry(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
-                   GTable* gt_out, uint32_t** slot_gid_out, uint32_t** occ_out) {
+                   GTable* gt_out, uint32_t** slot_gid_out, uint32_t** occ_out, DenseOut* dense_out) {
     uint64_t cur = hint ? hint : (h->hint_used ? h->hint_used : 1024);
     if (!hint && !h->hint_used && n >= (1u << 22) && !plan.sj) { const uint64_t e = estimate_groups(ctx, ks, n); if (e > cur) cur = e; }
     for (int attempt = 0; attempt < 12; ++attempt) {
         if (cur > n && n) cur = n;
-        int rc = run_agg(ctx, ks, plan, n, (uint32_t)cur, for_build, h, gt_out, slot_gid_out, occ_out);
+        int rc = run_agg(ctx, ks, plan, n, (uint32_t)cur, for_build, h, gt_out, slot_gid_out, occ_out, dense_out);
         if (rc != AQG_ERR_OVERFLOW) { if (rc == AQG_OK) h->hint_used = (uint32_t)cur; return rc; }
         if (n && cur >= n) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "group-by: table overflow at full capacity");
         cur *= 16;
@@ -1436,7 +1439,9 @@ int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void
     aqg_groupby* h = *out ? *out : new aqg_groupby();
     h->ctx = ctx; h->n = n;
     GTable gt; uint32_t* slot_gid = nullptr; uint32_t* occ_dev = nullptr;
-    int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, true, h, &gt, &slot_gid, &occ_dev);
+    DenseOut dn;
+    dn.used = false;
+    int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, true, h, &gt, &slot_gid, &occ_dev, &dn);
     if (rc == AQG_OK) {
         size_t c = h->reversemap ? h->cap_rows * 4 : 0;
         rc = dev_realloc(ctx, (void**)&h->reversemap, &c, ((size_t)n + 4) * 4);
@@ -1447,12 +1452,17 @@ int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void
     if (n) {
         hipMemsetAsync(h->counts, 0, (size_t)(G ? G : 1) * 4, ctx->stream);
         unsigned grid = aqg_grid(ctx, n / 4 + 1, 256, 2, 8);
-        if (G <= 2048 && !ks.wide) {
+        if (dn.used) {                      // direct-indexed table: the dense id of a row is slot_gid[idx(row)]
+            rc = aqg_dense_assign(ctx, ks, dn.spec, slot_gid, n, G, h->reversemap, h->counts);
+            if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
+        } else if (G <= 2048 && !ks.wide) {
             const uint32_t mcap = next_pow2((uint64_t)G * 2 + 2);
             size_t lds = (((size_t)G * 4 + 15) & ~(size_t)15) + (size_t)mcap * 12 + 16;
             hipLaunchKernelGGL((assign_kernel<true, true>), dim3(grid), dim3(256), lds, ctx->stream, ks, gt, slot_gid, occ_dev, n, G, mcap, h->reversemap, h->counts);
-        } else if (G <= 8192) {
+        } else if (G <= 36000) {            // group counts in an LDS histogram (up to 144 KB) instead of 1e9 global atomics
             size_t lds = (size_t)G * 4 + 16;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&assign_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (lds > 20 * 1024) { const unsigned per_cu = (unsigned)((160 * 1024) / (lds + 1024)); grid = aqg_grid(ctx, n / 4 + 1, 256, 2, per_cu ? per_cu : 1); }
             hipLaunchKernelGGL((assign_kernel<true, false>), dim3(grid), dim3(256), lds, ctx->stream, ks, gt, slot_gid, occ_dev, n, G, 0u, h->reversemap, h->counts);
         } else {
             hipLaunchKernelGGL((assign_kernel<false, false>), dim3(grid), dim3(256), 0, ctx->stream, ks, gt, slot_gid, occ_dev, n, G, 0u, h->reversemap, h->counts);

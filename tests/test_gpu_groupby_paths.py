@@ -114,3 +114,21 @@ def test_grouped_reduce_first_last_high_cardinality(gpu, oracle):
     for op in (ck.RED_FIRST, ck.RED_LAST, ck.RED_SUM, ck.RED_MAX):
         assert gu.same_bits(gpu.grouped_reduce(g, op, x), oracle.grouped_reduce(op, x, o)), op
     g.destroy()
+
+
+def test_build_over_dense_domain_and_large_count_histograms(gpu, oracle):
+    """aqg_groupby_build (reversemap + counts + postproc) where the first pass takes the dense plan (two narrow key columns), and where
+    the second pass keeps 20,000 group counts in an LDS histogram (sparse keys)"""
+    rng = np.random.default_rng(61)
+    for keys in ([rng.integers(0, 100, N).astype(np.int32), rng.integers(-50, 50, N).astype(np.int16)],
+                 [rng.integers(0, 20_000, N).astype(np.int32) * 104_729],
+                 [rng.integers(0, 40, N).astype(np.int64), rng.integers(0, 30, N).astype(np.uint8), rng.integers(0, 9, N).astype(np.int32)]):
+        o = oracle.groupby(keys)
+        g = gpu.groupby_build(keys)
+        assert g.ngroups == o["ngroups"]
+        assert np.array_equal(g.reversemap(), o["reversemap"])
+        assert np.array_equal(g.counts(), o["counts"])
+        assert np.array_equal(g.first_rows(), o["first_rows"])
+        x = rand(rng, np.int32, N, small=True)
+        assert gu.same_bits(gpu.grouped_reduce(g, ck.RED_SUM, x), oracle.grouped_reduce(ck.RED_SUM, x, o))
+        g.destroy()
