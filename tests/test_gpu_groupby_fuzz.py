@@ -1,0 +1,85 @@
+"""Seeded random sweep over the group-by plans: key shapes (1-3 columns, every integer dtype, dense and strided values), group counts
+from a handful to hundreds of thousands, row counts around the plan thresholds (2^20: partition / dense / big LDS; 2^22: the
+sample-based cardinality estimate when no hint is given), hints that are absent, exact, too small and too large, and random
+aggregate sets -- every result against the oracle's first-occurrence order, keys, first rows and aggregates."""
+import numpy as np
+import pytest
+
+import checker as ck
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+KEY_DTYPES = [np.int8, np.int16, np.int32, np.int64, np.uint8, np.uint16, np.uint32]
+VAL_DTYPES = [np.int8, np.int16, np.int32, np.int64, np.uint32, np.float32, np.float64]
+OPS = ["sum", "min", "max", "count", "avg"]
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import aquery2_amd
+    d = aquery2_amd.Device(0)
+    yield d
+    d.close()
+
+
+def make_case(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1_050_000, 1_500_017, 4_300_003]))
+    nk = int(rng.choice([1, 1, 2, 3]))
+    target = int(rng.choice([3, 50, 1000, 30_000, 300_000]))
+    per = max(2, int(round(target ** (1.0 / nk))))
+    keys = []
+    for _ in range(nk):
+        dt = KEY_DTYPES[rng.integers(len(KEY_DTYPES))]
+        info = np.iinfo(dt)
+        card = min(per, int(info.max) - int(info.min))
+        stride = int(rng.choice([1, 1, 1, 3, 16, 1024, 104_729]))
+        span = (int(info.max) - int(info.min)) // max(card, 1)
+        stride = max(1, min(stride, span))
+        lo = int(info.min) if rng.random() < 0.2 else (0 if info.min == 0 else int(rng.integers(-50, 50)))
+        lo = max(int(info.min), min(lo, int(info.max) - card * stride))
+        vals = (lo + rng.integers(0, card, n) * stride)
+        keys.append(vals.astype(dt))
+    naggs = int(rng.integers(1, 4))
+    aggs = []
+    for _ in range(naggs):
+        vdt = VAL_DTYPES[rng.integers(len(VAL_DTYPES))]
+        op = OPS[rng.integers(len(OPS))]
+        if np.dtype(vdt).kind == "f":
+            v = np.round(rng.uniform(-100, 100, n), 4).astype(vdt)
+        else:
+            info = np.iinfo(vdt)
+            v = rng.integers(max(info.min, -2**31), min(info.max, 2**31 - 1), n, endpoint=True).astype(vdt)
+        aggs.append((op, v))
+    hint_mode = rng.choice(["none", "exact", "small", "large"])
+    return n, keys, aggs, str(hint_mode)
+
+
+@pytest.mark.parametrize("seed", range(60))      # (200 seeds were run once while writing this: all green)
+def test_groupby_random_shapes(gpu, oracle, seed):
+    n, keys, aggs, hint_mode = make_case(1000 + seed)
+    o = oracle.groupby(keys)
+    G = o["ngroups"]
+    hint = {"none": 0, "exact": G, "small": max(1, G // 10), "large": min(n, G * 10 + 7)}[hint_mode]
+    ops = [ck.RED_NAMES[op] for op, _ in aggs]
+    try:
+        gb = gpu.groupby_agg(keys, ops, [v for _, v in aggs], hint=hint)
+    except Exception as e:                                   # the documented limit: 8 accumulators per call
+        assert "too many accumulators" in str(e), e
+        return
+    assert gb.ngroups == G, (seed, hint_mode)
+    assert np.array_equal(gb.first_rows(), o["first_rows"]), seed
+    for k, key in enumerate(keys):
+        assert np.array_equal(gb.keys(k, key.dtype), key[o["first_rows"]]), (seed, k)
+    for j, (op, v) in enumerate(aggs):
+        got, want = gb.result(j, ops[j], ck.tag_of(v)), oracle.grouped_reduce(ops[j], v, o)
+        if v.dtype.kind == "f" and op in ("sum", "avg"):
+            g64, w64 = got.astype(np.float64), want.astype(np.float64)
+            assert np.all(np.abs(g64 - w64) <= np.maximum(1.0, np.abs(w64)) * n * 2.0 ** -50), (seed, op)
+        else:
+            assert gu.same_bits(got, want), (seed, op, v.dtype)
+    gb.destroy()
+    if seed % 3 == 0:                                        # the build path on the same keys
+        g = gpu.groupby_build(keys, hint=hint)
+        assert g.ngroups == G and np.array_equal(g.reversemap(), o["reversemap"]) and np.array_equal(g.counts(), o["counts"])
+        g.destroy()
