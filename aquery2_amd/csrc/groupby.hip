@@ -592,9 +592,27 @@ __global__ void __launch_bounds__(256) gt_init_kernel(GTable gt, AccSpec as) {
 }
 
 // ---- dense ids in first-occurrence order --------------------------------------------------------
+// occupied slots -> occ[] (any order).  One returning atomic per workgroup and step, not per wavefront: with 1e8 occupied slots the
+// single counter word was the whole cost (47 ms; the word saturates near 9e7 atomics per second).
 __global__ void __launch_bounds__(256) collect_kernel(GTable gt, uint32_t* __restrict__ occ) {
-    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s <= gt.cap; s += gridDim.x * blockDim.x)
-        if ((*gt.first_p(s)) != NOROW) occ[atomicAdd(&gt.flags[1], 1u)] = s;
+    __shared__ uint32_t wcount[4];
+    __shared__ uint32_t base;
+    const uint64_t total = (uint64_t)gt.cap + 1;
+    for (uint64_t s0 = (uint64_t)blockIdx.x * blockDim.x; s0 < total; s0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t s = s0 + threadIdx.x;
+        const bool used = s < total && (*gt.first_p((uint32_t)s)) != NOROW;
+        const uint64_t bal = __ballot(used);
+        if (lane_id() == 0) wcount[wave_id()] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        if (threadIdx.x == 0) { const uint32_t c = wcount[0] + wcount[1] + wcount[2] + wcount[3]; base = c ? atomicAdd(&gt.flags[1], c) : 0; }
+        __syncthreads();
+        if (used) {
+            uint32_t off = base + (uint32_t)__popcll(bal & ((1ull << lane_id()) - 1ull));
+            for (int w = 0; w < wave_id(); ++w) off += wcount[w];
+            occ[off] = (uint32_t)s;
+        }
+        __syncthreads();
+    }
 }
 // G <= 4096: rank by counting inside one workgroup
 __global__ void __launch_bounds__(1024) rank_small_kernel(GTable gt, const uint32_t* __restrict__ occ, uint32_t* __restrict__ gid_of_occ,
