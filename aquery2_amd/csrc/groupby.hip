@@ -724,9 +724,16 @@ template <class T> __device__ inline void store_minmax(void* out, uint32_t g, ui
     static_cast<T*>(out)[g] = v;
 }
 
-__global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __restrict__ occ, const uint32_t* __restrict__ gid_of_occ, EmitSpec es) {
+// `order` (large G only): order[g] = the occ index of dense id g, so that the lanes walk the OUTPUT columns (and, for wide tuples,
+// the key columns at the groups' first rows) in ascending order instead of scattering eight columns at random
+__global__ void __launch_bounds__(256) emit_order_kernel(const uint32_t* __restrict__ gid_of_occ, uint32_t G, uint32_t* __restrict__ order) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) order[gid_of_occ[i]] = i;
+}
+__global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __restrict__ occ, const uint32_t* __restrict__ gid_of_occ, EmitSpec es,
+                                                   const uint32_t* __restrict__ order) {
     uint32_t G = gt.flags[1];
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) {
+    for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < G; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = order ? order[i0] : i0;
         uint32_t s = occ[i], g = gid_of_occ[i];
         uint64_t key = s == gt.cap ? EMPTY64 : (*gt.key_p(s));
         for (int k = 0; k < es.nkeys; ++k) {
@@ -1090,6 +1097,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     while (stride < 16 + 8 * (uint32_t)as.nacc) stride <<= 1;
     size_t need = slots * ((size_t)stride + 4 + 4 + 4) + 4096 + 256 * 16;
     if (!small_rank) need += (size_t)nwords * 8 + (size_t)ntiles * 4 + 4096;
+    const bool ordered_emit = !small_rank && hint >= (1u << 20);
+    if (ordered_emit) need += slots * 4 + 4096;
     if (use_part) need += aqg_partition_ws_bytes(n, ks.total_bytes <= 4 ? 4 : 8, as, pbits) + 65536;
     AQG_TRY(aqg_ws_reset(ctx));
     AQG_TRY(aqg_ws_ensure(ctx, need));
@@ -1270,7 +1279,12 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     }
     if (G) {
         unsigned eg = aqg_grid(ctx, G, 256, 1, 8);
-        hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt, occ, gid_of_occ, es);
+        uint32_t* order = nullptr;
+        if (ordered_emit && G >= (1u << 20)) {
+            AQG_TRY(aqg_ws_get(ctx, slots, &order));
+            hipLaunchKernelGGL(emit_order_kernel, dim3(eg), dim3(256), 0, ctx->stream, (const uint32_t*)gid_of_occ, G, order);
+        }
+        hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt, occ, gid_of_occ, es, (const uint32_t*)order);
         AQG_TRY(aqg_check_launch(ctx, "emit_kernel"));
     }
     if (gt_out) *gt_out = gt;
