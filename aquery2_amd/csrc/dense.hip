@@ -58,43 +58,53 @@ __global__ void range_init_kernel(long long* out, int nkeys) {
 }
 
 // ---- dense index of four consecutive rows ------------------------------------------------------------------------------------
-template <class T> __device__ inline void add_digit4(const void* col, size_t base, long long kmin, uint32_t mult, uint32_t (&idx)[4]) {
+// a digit outside [0, range) marks the row's index invalid (all ones): ranges taken from a sample may miss values
+template <class T> __device__ inline void add_digit4(const void* col, size_t base, long long kmin, uint32_t mult, uint32_t range, uint32_t (&idx)[4], uint32_t (&bad)[4]) {
     pack<T, 4> v = *reinterpret_cast<const pack<T, 4>*>(static_cast<const T*>(col) + base);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) idx[j] += (uint32_t)((long long)v.v[j] - kmin) * mult;
+    for (int j = 0; j < 4; ++j) {
+        const unsigned long long d = (unsigned long long)((long long)v.v[j] - kmin);
+        bad[j] |= d >= range;
+        idx[j] += (uint32_t)d * mult;
+    }
 }
-template <class T> __device__ inline uint32_t digit1(const void* col, size_t i, long long kmin, uint32_t mult) {
-    return (uint32_t)((long long)static_cast<const T*>(col)[i] - kmin) * mult;
+template <class T> __device__ inline uint32_t digit1(const void* col, size_t i, long long kmin, uint32_t mult, uint32_t range, uint32_t& bad) {
+    const unsigned long long d = (unsigned long long)((long long)static_cast<const T*>(col)[i] - kmin);
+    bad |= d >= range;
+    return (uint32_t)d * mult;
 }
 __device__ inline void dense_idx4(const KeySpec& ks, const DenseSpec& ds, size_t base, uint32_t (&idx)[4]) {
+    uint32_t bad[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 4; ++j) idx[j] = 0;
     for (int c = 0; c < ks.nkeys; ++c) {
         switch (ks.dt[c]) {
-        case AQG_INT8: add_digit4<int8_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
-        case AQG_INT16: add_digit4<int16_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
-        case AQG_INT32: add_digit4<int32_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
-        case AQG_INT64: add_digit4<int64_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
-        case AQG_UINT8: case AQG_BOOL: add_digit4<uint8_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
-        case AQG_UINT16: add_digit4<uint16_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
-        default: add_digit4<uint32_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], idx); break;
+        case AQG_INT8: add_digit4<int8_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], ds.range[c], idx, bad); break;
+        case AQG_INT16: add_digit4<int16_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], ds.range[c], idx, bad); break;
+        case AQG_INT32: add_digit4<int32_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], ds.range[c], idx, bad); break;
+        case AQG_INT64: add_digit4<int64_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], ds.range[c], idx, bad); break;
+        case AQG_UINT8: case AQG_BOOL: add_digit4<uint8_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], ds.range[c], idx, bad); break;
+        case AQG_UINT16: add_digit4<uint16_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], ds.range[c], idx, bad); break;
+        default: add_digit4<uint32_t>(ks.col[c], base, ds.kmin[c], ds.mult[c], ds.range[c], idx, bad); break;
         }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (bad[j]) idx[j] = 0xFFFFFFFFu;
 }
 __device__ inline uint32_t dense_idx1(const KeySpec& ks, const DenseSpec& ds, size_t i) {
-    uint32_t idx = 0;
+    uint32_t idx = 0, bad = 0;
     for (int c = 0; c < ks.nkeys; ++c) {
         switch (ks.dt[c]) {
-        case AQG_INT8: idx += digit1<int8_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
-        case AQG_INT16: idx += digit1<int16_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
-        case AQG_INT32: idx += digit1<int32_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
-        case AQG_INT64: idx += digit1<int64_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
-        case AQG_UINT8: case AQG_BOOL: idx += digit1<uint8_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
-        case AQG_UINT16: idx += digit1<uint16_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
-        default: idx += digit1<uint32_t>(ks.col[c], i, ds.kmin[c], ds.mult[c]); break;
+        case AQG_INT8: idx += digit1<int8_t>(ks.col[c], i, ds.kmin[c], ds.mult[c], ds.range[c], bad); break;
+        case AQG_INT16: idx += digit1<int16_t>(ks.col[c], i, ds.kmin[c], ds.mult[c], ds.range[c], bad); break;
+        case AQG_INT32: idx += digit1<int32_t>(ks.col[c], i, ds.kmin[c], ds.mult[c], ds.range[c], bad); break;
+        case AQG_INT64: idx += digit1<int64_t>(ks.col[c], i, ds.kmin[c], ds.mult[c], ds.range[c], bad); break;
+        case AQG_UINT8: case AQG_BOOL: idx += digit1<uint8_t>(ks.col[c], i, ds.kmin[c], ds.mult[c], ds.range[c], bad); break;
+        case AQG_UINT16: idx += digit1<uint16_t>(ks.col[c], i, ds.kmin[c], ds.mult[c], ds.range[c], bad); break;
+        default: idx += digit1<uint32_t>(ks.col[c], i, ds.kmin[c], ds.mult[c], ds.range[c], bad); break;
         }
     }
-    return idx;
+    return bad ? 0xFFFFFFFFu : idx;
 }
 // the packed key word the emit kernel expects in the table (wide tuples: any row of the group)
 __device__ inline uint64_t dense_key_word(const KeySpec& ks, const DenseSpec& ds, uint32_t idx, uint32_t some_row) {
@@ -137,7 +147,10 @@ __global__ void __launch_bounds__(BLOCK) dense_agg_kernel(KeySpec ks, DenseSpec 
             uint32_t f[4], id[4];
             bool in[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { id[j] = idx[j] - lo; in[j] = id[j] < PP; f[j] = lfirst[in[j] ? id[j] : 0]; }   // four LDS reads in flight
+            for (int j = 0; j < 4; ++j) {
+                if (idx[j] == 0xFFFFFFFFu) gt.flags[3] = 1;           // a value outside the sampled ranges: the host redoes the call with exact ranges
+                id[j] = idx[j] - lo; in[j] = idx[j] != 0xFFFFFFFFu && id[j] < PP; f[j] = lfirst[in[j] ? id[j] : 0];   // four LDS reads in flight
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (in[j] && (uint32_t)base + j < f[j]) atomicMin(&lfirst[id[j]], (uint32_t)base + j);
             if (need_count) {
@@ -205,6 +218,7 @@ __global__ void __launch_bounds__(BLOCK) dense_agg_kernel(KeySpec ks, DenseSpec 
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const uint32_t row = (nchunk << 2) + threadIdx.x;
         const uint32_t g = dense_idx1(ks, ds, row);
+        if (g == 0xFFFFFFFFu) { gt.flags[3] = 1; return; }
         *gt.key_p(g) = dense_key_word(ks, ds, g, row);
         atomicMin(gt.first_p(g), row);
         if (need_count) atomicAdd(gt.count_p(g), 1u);
@@ -289,6 +303,7 @@ bool aqg_dense_plan(const KeySpec& ks, const long long* mins, const long long* m
         const unsigned long long range = (unsigned long long)maxs[c] - (unsigned long long)mins[c] + 1ull;
         if (range == 0 || range > cap) return false;
         ds->kmin[c] = mins[c];
+        ds->range[c] = (uint32_t)range;
         ds->mult[c] = (uint32_t)D;
         D *= range;
         if (D > cap) return false;

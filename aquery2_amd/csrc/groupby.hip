@@ -1023,7 +1023,8 @@ int make_plan(aqg_ctx* ctx, int naggs, const int* ops, const int* dts, const voi
 }
 
 // One attempt at a given global capacity.  Returns AQG_ERR_OVERFLOW when the table filled up.
-struct DenseOut { bool used; DenseSpec spec; };      // tells aqg_groupby_build that the table is the direct-indexed one
+struct DenseOut { bool used; DenseSpec spec; };
+constexpr int AQG_ERR_RANGE_MISS = -1001;            // internal: sampled key ranges missed a value; run_with_retry repeats the attempt      // tells aqg_groupby_build that the table is the direct-indexed one
 
 int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
             GTable* gt_out, uint32_t** slot_gid_out, uint32_t** occ_out = nullptr, DenseOut* dense_out = nullptr) {
@@ -1056,8 +1057,12 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         bool ok = false;
         AQG_TRY(aqg_ws_reset(ctx));
         AQG_TRY(aqg_ws_ensure(ctx, 4096));
-        AQG_TRY(aqg_key_ranges(ctx, ks, n, mins, maxs, &ok));
+        // large inputs: ranges from the first 2^20 rows (a full pass over the key columns costs a third of Q2); the kernels check
+        // every row against them and flag a miss, which re-runs the call once with exact ranges (and remembers it in the handle)
+        const bool sampled = n >= (1u << 22) && !h->dense_exact;
+        AQG_TRY(aqg_key_ranges(ctx, ks, sampled ? (1u << 20) : n, mins, maxs, &ok));
         dense = ok && aqg_dense_plan(ks, mins, maxs, as, plan.need_count, &dspec);
+        dspec.sampled = sampled;
         if (dense) gcap = dspec.D;
     }
     if (!dense && !use_lds && !ks.wide && n >= (1u << 20)) {
@@ -1221,9 +1226,10 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     // ---- dense ids ---------------------------------------------------------------------------------
     unsigned cgrid = aqg_grid(ctx, slots, 256, 1, 8);
     if (!(n && use_part)) hipLaunchKernelGGL(collect_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, gt, occ);
-    uint32_t fl[2] = {0, 0};
-    AQG_HIP(ctx, hipMemcpyAsync(fl, gt.flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t fl[4] = {0, 0, 0, 0};                    // [0] overflow, [1] occupied slots, [3] a row outside the sampled key ranges
+    AQG_HIP(ctx, hipMemcpyAsync(fl, gt.flags, 16, hipMemcpyDeviceToHost, ctx->stream));
     AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (dense && fl[3]) { h->dense_exact = true; return AQG_ERR_RANGE_MISS; }
     if (fl[0]) return AQG_ERR_OVERFLOW;
     uint32_t G = fl[1];
     if (small_rank && G > 4096) return AQG_ERR_OVERFLOW;
@@ -1331,6 +1337,7 @@ int run_with_retry(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n
     for (int attempt = 0; attempt < 12; ++attempt) {
         if (cur > n && n) cur = n;
         int rc = run_agg(ctx, ks, plan, n, (uint32_t)cur, for_build, h, gt_out, slot_gid_out, occ_out, dense_out);
+        if (rc == AQG_ERR_RANGE_MISS) rc = run_agg(ctx, ks, plan, n, (uint32_t)cur, for_build, h, gt_out, slot_gid_out, occ_out, dense_out);   // exact ranges now
         if (rc != AQG_ERR_OVERFLOW) { if (rc == AQG_OK) h->hint_used = (uint32_t)cur; return rc; }
         if (n && cur >= n) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "group-by: table overflow at full capacity");
         cur *= 16;

@@ -22,6 +22,7 @@ struct aqg_groupby {
     int res_dt[MAXAGG] = {0};
     size_t cap_groups = 0, cap_rows = 0, cap_results[MAXAGG] = {0};
     uint32_t hint_used = 0;
+    bool dense_exact = false;         // a sampled key range missed values once: take exact ranges from now on
     aqg_groupby* scratch = nullptr;   // reusable handle for aqg_grouped_reduce
     // aqg_groupby_merge_packed: the concatenated shard tables (keys / values), owned by the merged handle
     void* xkeys = nullptr; void* xvals = nullptr;

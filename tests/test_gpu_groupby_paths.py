@@ -132,3 +132,27 @@ def test_build_over_dense_domain_and_large_count_histograms(gpu, oracle):
         x = rand(rng, np.int32, N, small=True)
         assert gu.same_bits(gpu.grouped_reduce(g, ck.RED_SUM, x), oracle.grouped_reduce(ck.RED_SUM, x, o))
         g.destroy()
+
+
+def test_dense_domain_sampled_ranges_miss_and_recover(gpu, oracle):
+    """>= 2^22 rows: the dense plan takes the key ranges from the first 2^20 rows; values that only appear later must trigger the
+    exact-range re-run (and give the same result as ever)"""
+    rng = np.random.default_rng(71)
+    n = 4_400_011
+    a = rng.integers(0, 60, n).astype(np.int32)
+    b = rng.integers(0, 70, n).astype(np.int16)
+    a[3_000_000:] += 25                                       # new maxima after the sampled prefix
+    b[4_399_000:] -= 9                                        # new minima at the very end
+    v = rand(rng, np.int32, n, small=True)
+    o = oracle.groupby([a, b])
+    gb = gpu.groupby_agg([a, b], [ck.RED_SUM, ck.RED_COUNT], [v, v], hint=8000)
+    assert gb.ngroups == o["ngroups"]
+    assert np.array_equal(gb.first_rows(), o["first_rows"])
+    assert np.array_equal(gb.keys(0, np.int32), a[o["first_rows"]]) and np.array_equal(gb.keys(1, np.int16), b[o["first_rows"]])
+    assert gu.same_bits(gb.result(0, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, v, o))
+    # the handle remembers: a second call on the same handle goes straight to exact ranges (same answer)
+    gb2 = gpu.groupby_agg([a, b], [ck.RED_SUM, ck.RED_COUNT], [v, v], hint=8000, handle=gb)
+    assert gb2.ngroups == o["ngroups"] and gu.same_bits(gb2.result(0, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, v, o))
+    g = gpu.groupby_build([a, b], hint=8000)
+    assert np.array_equal(g.reversemap(), o["reversemap"]) and np.array_equal(g.counts(), o["counts"])
+    g.destroy()
