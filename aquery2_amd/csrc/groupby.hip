@@ -242,42 +242,50 @@ __global__ void __launch_bounds__(BLOCK) agg_kernel(KeySpec ks, AccSpec as, GTab
   }   // passes
 }
 
-// ---- fast path: one 4-byte key column, 4-byte value columns, SUM/AVG/COUNT (h2o Q1, Q4) -------------------------------------
-// Same LDS open-addressing idea as agg_kernel, pared down to what this shape needs: the slot is the 4-byte key alone, eight
-// rows per lane per step with all probes issued before the first compare, and NO first-row bookkeeping in the loop -- first
-// rows are recovered afterwards by first_rows_kernel, which stops as soon as every group has one (a few tiles on h2o data).
-// vkind: 0 int32, 1 uint32, 2 float (accumulated in double).
-struct FastVals { const void* col[3]; int vkind[3]; };
+// ---- fast path: one or two 4-byte key columns, up to four accumulators over 4-byte value columns (h2o Q1, Q4, ...) ------------
+// Same LDS open-addressing idea as agg_kernel, pared down to what these shapes need: the slot is the packed key alone (4 or 8
+// bytes), eight rows per lane per step with all probes issued before the first compare, and NO first-row bookkeeping in the
+// loop -- first rows are recovered afterwards by first_rows_kernel, which stops as soon as every group has one (a few tiles on
+// h2o data).  vkind: 0 int32, 1 uint32, 2 float; kind: ACC_ADD_I / ACC_ADD_F / ACC_MIN / ACC_MAX; square: accumulate x*x.
+// (The generic agg_kernel ran max(v1),min(v2) by id1 at 27 % of the HBM roofline and var(v1) at 18 %; this kernel does SUM at 75 %.)
+struct FastVals { const void* col[4]; int vkind[4]; int kind[4]; int square[4]; };
 constexpr uint32_t OCCUPIED = 0xFFFFFFFEu;   // first_row mark: "group exists, first row not yet known"
 
-template <int NV, bool COUNT>
-__global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__ keys, FastVals fv, GTable gt, uint32_t n, uint32_t lcap) {
+template <int NV, bool COUNT, bool K64>
+__global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_hi, FastVals fv, GTable gt, uint32_t n, uint32_t lcap) {
+    using KT = std::conditional_t<K64, uint64_t, uint32_t>;
+    constexpr KT EMPTYK = K64 ? (KT)EMPTY64 : (KT)EMPTY32;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const uint32_t LT = lcap + 1;
     uint64_t* lacc = reinterpret_cast<uint64_t*>(smem_raw);                  // [NV][LT]
-    uint32_t* lkey = reinterpret_cast<uint32_t*>(lacc + (size_t)NV * LT);    // [LT], slot lcap = the key equal to EMPTY32
-    uint32_t* lcount = lkey + LT;                                            // [LT] if COUNT
+    KT* lkey = reinterpret_cast<KT*>(lacc + (size_t)NV * LT);                // [LT], slot lcap = the key equal to the empty mark
+    uint32_t* lcount = reinterpret_cast<uint32_t*>(lkey + LT);               // [LT] if COUNT
     uint32_t* ltouch = lcount + (COUNT ? LT : 0);                            // [1]  sentinel slot used?
     __shared__ uint32_t lused;
     const uint32_t lmask = lcap - 1, llimit = lcap - (lcap >> 2), lbits = 31 - __clz(lcap);
     for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) {
-        lkey[s] = EMPTY32;
-        _Pragma("unroll") for (int a = 0; a < NV; ++a) lacc[(size_t)a * LT + s] = 0;
+        lkey[s] = EMPTYK;
+        _Pragma("unroll") for (int a = 0; a < NV; ++a) lacc[(size_t)a * LT + s] = acc_init(fv.kind[a]);
         if constexpr (COUNT) lcount[s] = 0;
     }
     if (threadIdx.x == 0) { lused = 0; *ltouch = 0; }
     __syncthreads();
 
-    auto slow_slot = [&](uint32_t k) -> uint32_t {      // insert path (first sight of a key in this workgroup)
-        if (k == EMPTY32) { *ltouch = 1; return lcap; }
-        uint32_t s = fib_slot(k, lbits);
+    auto slot_of = [&](KT k) -> uint32_t {
+        if constexpr (K64) return lds_h1<false>((uint64_t)k) >> (32 - lbits); else return fib_slot((uint32_t)k, lbits);
+    };
+    auto slow_slot = [&](KT k) -> uint32_t {            // insert path (first sight of a key in this workgroup)
+        if (k == EMPTYK) { *ltouch = 1; return lcap; }
+        uint32_t s = slot_of(k);
         for (uint32_t p = 0; p <= lmask; ++p) {
-            uint32_t cur = lkey[s];
+            KT cur = lkey[s];
             if (cur == k) return s;
-            if (cur == EMPTY32) {
+            if (cur == EMPTYK) {
                 if (lused >= llimit) return FAIL;
-                uint32_t old = atomicCAS(&lkey[s], EMPTY32, k);
-                if (old == EMPTY32) { atomicAdd(&lused, 1u); return s; }
+                KT old;
+                if constexpr (K64) old = atomicCAS(reinterpret_cast<unsigned long long*>(&lkey[s]), (unsigned long long)EMPTYK, (unsigned long long)k);
+                else old = atomicCAS(&lkey[s], EMPTYK, k);
+                if (old == EMPTYK) { atomicAdd(&lused, 1u); return s; }
                 if (old == k) return s;
             }
             s = (s + 1) & lmask;
@@ -286,54 +294,97 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
     };
     auto operand = [&](int a, uint32_t bits) -> uint64_t {
         switch (fv.vkind[a]) {
-        case 0: return (uint64_t)(int64_t)(int32_t)bits;
-        case 1: return (uint64_t)bits;
-        default: return __builtin_bit_cast(uint64_t, (double)__uint_as_float(bits));
+        case 0: return val_operand_t((int32_t)bits, fv.kind[a], fv.square[a]);
+        case 1: return val_operand_t((uint32_t)bits, fv.kind[a], fv.square[a]);
+        default: return val_operand_t(__uint_as_float(bits), fv.kind[a], fv.square[a]);
         }
     };
-    auto to_table = [&](uint32_t k, const uint32_t* vbits) {   // rare: LDS table at its load limit, or tail rows
-        uint32_t g = gt_find_or_insert(gt, (uint64_t)k);
+    auto to_table = [&](KT k, const uint32_t* vbits) {   // rare: LDS table at its load limit, or tail rows
+        uint32_t g = gt_find_or_insert(gt, K64 ? (uint64_t)k : (uint64_t)(uint32_t)k);
         if (g == FAIL) return;
         atomicMin(gt.first_p(g), OCCUPIED);
         if constexpr (COUNT) atomicAdd(gt.count_p(g), 1u);
-        _Pragma("unroll") for (int a = 0; a < NV; ++a) acc_apply(gt.acc_p(a, g), fv.vkind[a] == 2 ? ACC_ADD_F : ACC_ADD_I, operand(a, vbits[a]));
+        _Pragma("unroll") for (int a = 0; a < NV; ++a) acc_apply(gt.acc_p(a, g), fv.kind[a], operand(a, vbits[a]));
     };
 
     const uint32_t nchunk = n >> 3;            // 8 consecutive rows per lane per step
-    // a workgroup takes one CONTIGUOUS span of rows (many more workgroups than fit the chip, dispatched as earlier ones retire)
     uint32_t c_lo, c_hi;
-    wg_span(nchunk, c_lo, c_hi);
+    wg_span(nchunk, c_lo, c_hi);               // one contiguous span of rows per workgroup
     for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
         const size_t base = (size_t)c * 8;
         pack<uint32_t, 4> k0 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base);
         pack<uint32_t, 4> k1 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base + 4);
+        pack<uint32_t, 4> h0, h1;
+        if constexpr (K64) {
+            h0 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys_hi + base);
+            h1 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys_hi + base + 4);
+        }
         pack<uint32_t, 4> v0[NV ? NV : 1], v1[NV ? NV : 1];
         _Pragma("unroll") for (int a = 0; a < NV; ++a) {
             v0[a] = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(fv.col[a]) + base);
             v1[a] = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(fv.col[a]) + base + 4);
         }
-        uint32_t k[8], slot[8], cur[8];
+        KT k[8], cur[8];
+        uint32_t slot[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { k[j] = k0.v[j]; k[4 + j] = k1.v[j]; }
+        for (int j = 0; j < 4; ++j) {
+            if constexpr (K64) { k[j] = (uint64_t)k0.v[j] | ((uint64_t)h0.v[j] << 32); k[4 + j] = (uint64_t)k1.v[j] | ((uint64_t)h1.v[j] << 32); }
+            else { k[j] = k0.v[j]; k[4 + j] = k1.v[j]; }
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { slot[j] = fib_slot(k[j], lbits); cur[j] = lkey[slot[j]]; }     // eight probes in flight
+        for (int j = 0; j < 8; ++j) { slot[j] = slot_of(k[j]); cur[j] = lkey[slot[j]]; }     // eight probes in flight
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (cur[j] != k[j] || k[j] == EMPTY32) slot[j] = slow_slot(k[j]);   // (walking the missed rows' probe sequences together measured slower here)
+        for (int j = 0; j < 8; ++j) if (cur[j] != k[j] || k[j] == EMPTYK) slot[j] = slow_slot(k[j]);   // (walking the missed rows' probe sequences together measured slower here)
         if constexpr (COUNT) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(&lcount[slot[j]], 1u);
         }
         _Pragma("unroll") for (int a = 0; a < NV; ++a) {
             uint64_t* la = lacc + (size_t)a * LT;
-            if (fv.vkind[a] == 2) {
+            // wave-uniform branches, one per accumulator per eight rows; plain sums keep their own straight-line form
+            if (fv.kind[a] == ACC_ADD_F && !fv.square[a]) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<double*>(&la[slot[j]]), (double)__uint_as_float(j < 4 ? v0[a].v[j] : v1[a].v[j - 4]));
-            } else if (fv.vkind[a] == 0) {
+            } else if (fv.kind[a] == ACC_ADD_I && !fv.square[a] && fv.vkind[a] == 0) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)(int64_t)(int32_t)(j < 4 ? v0[a].v[j] : v1[a].v[j - 4]));
-            } else {
+            } else if (fv.kind[a] == ACC_ADD_I && !fv.square[a]) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)(j < 4 ? v0[a].v[j] : v1[a].v[j - 4]));
+            } else {
+                uint64_t o[8];
+                switch (fv.vkind[a]) {      // the dtype switch outside the eight rows
+                case 0:
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = val_operand_t((int32_t)(j < 4 ? v0[a].v[j] : v1[a].v[j - 4]), fv.kind[a], fv.square[a]);
+                    break;
+                case 1:
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = val_operand_t((uint32_t)(j < 4 ? v0[a].v[j] : v1[a].v[j - 4]), fv.kind[a], fv.square[a]);
+                    break;
+                default:
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = val_operand_t(__uint_as_float(j < 4 ? v0[a].v[j] : v1[a].v[j - 4]), fv.kind[a], fv.square[a]);
+                    break;
+                }
+                switch (fv.kind[a]) {
+                case ACC_ADD_I:
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)o[j]);
+                    break;
+                case ACC_ADD_F:
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<double*>(&la[slot[j]]), __builtin_bit_cast(double, o[j]));
+                    break;
+                case ACC_MIN:
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicMin(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)o[j]);
+                    break;
+                default:
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicMax(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)o[j]);
+                    break;
+                }
             }
         }
 #pragma unroll
@@ -350,18 +401,20 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
         if (row < n) {
             uint32_t vb[NV ? NV : 1];
             _Pragma("unroll") for (int a = 0; a < NV; ++a) vb[a] = static_cast<const uint32_t*>(fv.col[a])[row];
-            to_table(keys[row], vb);
+            KT key;
+            if constexpr (K64) key = (uint64_t)keys[row] | ((uint64_t)keys_hi[row] << 32); else key = keys[row];
+            to_table(key, vb);
         }
     }
     __syncthreads();
     for (uint32_t s = threadIdx.x; s < LT; s += blockDim.x) {
-        const uint32_t key = lkey[s];
-        if (s < lcap ? key == EMPTY32 : *ltouch == 0) continue;
-        uint32_t g = gt_find_or_insert(gt, (uint64_t)(s < lcap ? key : EMPTY32));
+        const KT key = lkey[s];
+        if (s < lcap ? key == EMPTYK : *ltouch == 0) continue;
+        uint32_t g = gt_find_or_insert(gt, s < lcap ? (K64 ? (uint64_t)key : (uint64_t)(uint32_t)key) : (K64 ? EMPTY64 : (uint64_t)EMPTY32));
         if (g == FAIL) continue;
         atomicMin(gt.first_p(g), OCCUPIED);
         if constexpr (COUNT) atomicAdd(gt.count_p(g), lcount[s]);
-        _Pragma("unroll") for (int a = 0; a < NV; ++a) acc_apply(gt.acc_p(a, g), fv.vkind[a] == 2 ? ACC_ADD_F : ACC_ADD_I, lacc[(size_t)a * LT + s]);
+        _Pragma("unroll") for (int a = 0; a < NV; ++a) acc_apply(gt.acc_p(a, g), fv.kind[a], lacc[(size_t)a * LT + s]);
     }
 }
 
@@ -538,7 +591,7 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
 
 // first row of every group, after the fact: tiles are scanned in order by a small grid; once every group has a candidate,
 // a workgroup stops as soon as its next tile starts beyond the largest candidate (no later row can lower any of them).
-__global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restrict__ keys, uint32_t n, GTable gt, const uint32_t* __restrict__ occ) {
+__global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_hi, uint32_t n, GTable gt, const uint32_t* __restrict__ occ) {
     __shared__ uint32_t red[4];
     __shared__ uint32_t stop;
     const uint32_t G = gt.flags[1];
@@ -568,7 +621,7 @@ __global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restr
         for (int r = 0; r < 16; ++r) {
             uint32_t row = tbase + r * 256 + threadIdx.x;
             if (row < n) {
-                uint32_t s = gt_find(gt, (uint64_t)keys[row]);
+                uint32_t s = gt_find(gt, keys_hi ? ((uint64_t)keys[row] | ((uint64_t)keys_hi[row] << 32)) : (uint64_t)keys[row]);
                 if (s != FAIL && row < *gt.first_p(s)) {
                     uint32_t old = atomicMin(gt.first_p(s), row);
                     if (old >= OCCUPIED) atomicAdd(&gt.flags[2], 1u);
@@ -1035,7 +1088,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     // LDS mode, big:   one 1024-thread workgroup per CU with a table of up to 150 KB, and up to MAX_PASSES passes over the
     //                  rows, each aggregating the keys of one hash class (agg_kernel).  Beyond that rows go straight to HBM.
     constexpr uint32_t MAX_PASSES = 4;
-    constexpr size_t LDS_SMALL = 64 * 1024, LDS_BIG = 150 * 1024;
+    constexpr size_t LDS_SMALL = 76 * 1024, LDS_BIG = 150 * 1024;      // small: two workgroups per CU still fit
     bool use_lds = hint <= 3072 && !ks.wide;   // wide tuples compare against HBM-resident rows: HBM mode
     uint32_t lcap = use_lds ? next_pow2((uint64_t)(hint < 64 ? 64 : hint) * 4 / 3 + 1) : 0;
     if (use_lds && lcap < 256) lcap = 256;
@@ -1063,6 +1116,12 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(aqg_key_ranges(ctx, ks, sampled ? (1u << 20) : n, mins, maxs, &ok));
         dense = ok && aqg_dense_plan(ks, mins, maxs, as, plan.need_count, &dspec);
         dspec.sampled = sampled;
+        if (dense && dspec.D <= 1536) {          // (ranges from a sample are fine here: the hashed table takes any key)
+            // a tiny domain under a large hint: the small hashed table after all (1024 lanes on a hundred hot direct-indexed
+            // slots serialise on LDS atomics: 6.2 ms per 1e9 rows against 2.7 ms)
+            const uint32_t small_cap = next_pow2((uint64_t)(dspec.D < 64 ? 64 : dspec.D) * 4 / 3 + 1);
+            if ((size_t)(small_cap + 1) * lds_slot_bytes <= LDS_SMALL) { dense = false; use_lds = true; lcap = small_cap < 256 ? 256 : small_cap; hint = dspec.D; }
+        }
         if (dense) gcap = dspec.D;
     }
     if (!dense && !use_lds && !ks.wide && n >= (1u << 20)) {
@@ -1139,16 +1198,18 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
 
     // fast path eligibility: LDS mode, one 4-byte integer key, 1..3 four-byte value columns, plain additive accumulators
     // (also the first pass of aqg_groupby_build: no accumulators, only the distinct keys)
-    bool fast = use_lds && !plan.sj && !big_lds && k32 && n >= 8 && (as.nacc >= 1 || plan.need_count || for_build) && as.nacc <= 3 &&
-                (ks.dt[0] == AQG_INT32 || ks.dt[0] == AQG_UINT32) && ((uintptr_t)ks.col[0] & 15) == 0;
+    auto key32 = [&](int j) { return (ks.dt[j] == AQG_INT32 || ks.dt[j] == AQG_UINT32) && ((uintptr_t)ks.col[j] & 15) == 0; };
+    const bool fast_k64 = ks.nkeys == 2 && !ks.wide && ks.total_bytes == 8 && key32(0) && key32(1);
+    bool fast = use_lds && !plan.sj && !big_lds && ((k32 && key32(0)) || fast_k64) && n >= 8 && (as.nacc >= 1 || plan.need_count || for_build) && as.nacc <= 4;
     FastVals fv;
     memset(&fv, 0, sizeof fv);
     for (int a = 0; a < as.nacc && fast; ++a) {
-        const bool addk = as.kind[a] == ACC_ADD_I || as.kind[a] == ACC_ADD_F;
         const int dt = as.dt[a];
-        if (!addk || as.square[a] || as.part[a] || !(dt == AQG_INT32 || dt == AQG_UINT32 || dt == AQG_FLOAT) || ((uintptr_t)as.col[a] & 15)) fast = false;
+        if (as.part[a] || !(dt == AQG_INT32 || dt == AQG_UINT32 || dt == AQG_FLOAT) || ((uintptr_t)as.col[a] & 15)) fast = false;
         fv.col[a] = as.col[a];
         fv.vkind[a] = dt == AQG_INT32 ? 0 : dt == AQG_UINT32 ? 1 : 2;
+        fv.kind[a] = as.kind[a];
+        fv.square[a] = as.square[a];
     }
     // ---- pass over the rows ---------------------------------------------------------------------
     if (n && plan.sj) {
@@ -1160,25 +1221,31 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         aqg_kernel_timer_end(ctx);
         AQG_TRY(aqg_check_launch(ctx, "starjoin_kernel"));
     } else if (n && fast) {
-        const size_t lds = (size_t)(lcap + 1) * (4 + 8 * (size_t)as.nacc + (plan.need_count ? 4 : 0)) + 64;
+        const size_t lds = (size_t)(lcap + 1) * ((fast_k64 ? 8 : 4) + 8 * (size_t)as.nacc + (plan.need_count ? 4 : 0)) + 64;
         unsigned bpc = lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : 2;
         unsigned grid = aqg_grid(ctx, n / 8 + 1, 256, 2, bpc);
         // (more workgroups than fit the chip cost more in table merges than they gain: 8192 -> +3 %, 32768 -> +30 % on Q1)
+        const uint32_t* khi = fast_k64 ? static_cast<const uint32_t*>(ks.col[1]) : nullptr;
         auto launch = [&](auto kern) -> int {
             AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             aqg_kernel_timer_begin(ctx);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, static_cast<const uint32_t*>(ks.col[0]), fv, gt, n, lcap);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, static_cast<const uint32_t*>(ks.col[0]), khi, fv, gt, n, lcap);
             aqg_kernel_timer_end(ctx);
             return aqg_check_launch(ctx, "agg32_kernel");
         };
+        auto by_nv = [&](auto count_tag, auto k64_tag) -> int {
+            constexpr bool C = decltype(count_tag)::value, K = decltype(k64_tag)::value;
+            switch (as.nacc) {
+            case 0: return launch(&agg32_kernel<0, C, K>);
+            case 1: return launch(&agg32_kernel<1, C, K>);
+            case 2: return launch(&agg32_kernel<2, C, K>);
+            case 3: return launch(&agg32_kernel<3, C, K>);
+            default: return launch(&agg32_kernel<4, C, K>);
+            }
+        };
         int rc;
-        if (plan.need_count) {
-            switch (as.nacc) { case 0: rc = launch(&agg32_kernel<0, true>); break; case 1: rc = launch(&agg32_kernel<1, true>); break;
-                               case 2: rc = launch(&agg32_kernel<2, true>); break; default: rc = launch(&agg32_kernel<3, true>); break; }
-        } else {
-            switch (as.nacc) { case 0: rc = launch(&agg32_kernel<0, false>); break; case 1: rc = launch(&agg32_kernel<1, false>); break;
-                               case 2: rc = launch(&agg32_kernel<2, false>); break; default: rc = launch(&agg32_kernel<3, false>); break; }
-        }
+        if (plan.need_count) rc = fast_k64 ? by_nv(std::true_type{}, std::true_type{}) : by_nv(std::true_type{}, std::false_type{});
+        else rc = fast_k64 ? by_nv(std::false_type{}, std::true_type{}) : by_nv(std::false_type{}, std::false_type{});
         AQG_TRY(rc);
     } else if (n && dense) {
         AQG_TRY(aqg_dense_aggregate(ctx, ks, dspec, as, n, plan.need_count, gt));
@@ -1236,7 +1303,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (use_lds && G > lds_group_cap && G > hint) return AQG_ERR_OVERFLOW;   // correct but slow (overflow rows took the HBM path): re-plan
     if (G && n && fast) {
         unsigned fgrid = aqg_grid(ctx, n / 16 + 1, 256, 1, 1);
-        hipLaunchKernelGGL(first_rows_kernel, dim3(fgrid), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(ks.col[0]), n, gt, (const uint32_t*)occ);
+        hipLaunchKernelGGL(first_rows_kernel, dim3(fgrid), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(ks.col[0]),
+                           fast_k64 ? static_cast<const uint32_t*>(ks.col[1]) : (const uint32_t*)nullptr, n, gt, (const uint32_t*)occ);
         AQG_TRY(aqg_check_launch(ctx, "first_rows_kernel"));
     }
     if (G) {
