@@ -45,6 +45,22 @@ if which in ("all", "gb"):
     print("   Q5 groups", g.ngroups)
     timeit("Q7 max(v1),min(v2) by id3", 12, agg("q7", [id3], [ck.RED_MAX, ck.RED_MIN], [v1, v2], n // K + 1024), reps=2)
     for k in list(h): h[k].destroy()
+if which in ("all", "generic"):
+    # shapes beyond Q1 / Q4 that still take the fast LDS kernel: MIN / MAX / VAR kinds, two key columns, mixed aggregates
+    id1, id2, v1, v2, v3 = (col(c) for c in (ck.GEN_ID1, ck.GEN_ID2, ck.GEN_V1, ck.GEN_V2, ck.GEN_V3))
+    k7 = d.ewise(ck.OP_MOD, id2, np.int32(7), keep=True)
+    hg = {}
+    def aggg(key, keys, ops, vals):
+        def f():
+            hg[key] = d.groupby_agg(keys, ops, vals, hint=1024, handle=hg.get(key))
+        return f
+    timeit("max(v1),min(v2) by id1", 12, aggg("a", [id1], [ck.RED_MAX, ck.RED_MIN], [v1, v2]))
+    timeit("var(v1) by id1", 8, aggg("b", [id1], [ck.RED_VAR], [v1]))
+    timeit("min(v3) by id1", 8, aggg("c", [id1], [ck.RED_MIN], [v3]))
+    timeit("sum(v1) by id1,id2%7 (700 groups)", 12, aggg("d", [id1, k7], [ck.RED_SUM], [v1]))
+    timeit("sum(v1),max(v2),min(v3),avg(v1) by id1", 16, aggg("e", [id1], [ck.RED_SUM, ck.RED_MAX, ck.RED_MIN, ck.RED_AVG], [v1, v2, v3, v1]))
+    for k in list(hg): hg[k].destroy()
+    k7.free()
 if which == "q10":
     ids = [col(c) for c in (ck.GEN_ID1, ck.GEN_ID2, ck.GEN_ID3, ck.GEN_ID4, ck.GEN_ID5, ck.GEN_ID6)]
     v3 = col(ck.GEN_V3)
