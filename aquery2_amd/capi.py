@@ -165,6 +165,7 @@ class Device:
         if rc != 0:
             raise AqgError("aqg_ctx_create (no MI355X visible? the HIP path has no CPU fallback)", rc)
         self.ctx = ctx
+        self.stream = int(stream) if stream else 0    # 0: the library made its own stream
         self._handles = weakref.WeakSet()
 
     def close(self):

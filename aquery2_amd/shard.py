@@ -59,7 +59,14 @@ class GroupTableExchange:
     def __call__(self, gb, agg_index=0):
         self.dev.groupby_pack(gb, agg_index, self.gmax, self.pack.data_ptr())
         if self.xdev == "cuda":
+            # the collective orders itself with torch's current stream: free when the library runs on that stream,
+            # otherwise the two streams are joined on the host
+            shared = self.dev.stream and self.dev.stream == torch.cuda.current_stream().cuda_stream
+            if not shared:
+                self.dev.sync()
             self.dist.all_gather_into_tensor(self.all, self.pack)
+            if not shared:
+                torch.cuda.current_stream().synchronize()
         else:
             self.dev.sync()
             self.dist.all_gather_into_tensor(self.all_x, self.pack.to(self.xdev))

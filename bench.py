@@ -87,8 +87,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
     torch.cuda.set_device(gpu)
 
-    # the library runs on torch's current stream so that torch.cuda.synchronize / RCCL order with it
+    # The library and torch share ONE stream, so that RCCL's all_gather is ordered after the pack kernel and the merge
+    # after the all_gather without host syncs.  torch's default stream has handle 0, which the C-ABI reads as "create your
+    # own", so a side stream is made current for the whole run.
+    side = torch.cuda.Stream(device=gpu)
+    torch.cuda.set_stream(side)
     stream = torch.cuda.current_stream().cuda_stream
+    assert stream, "expected a non-default stream handle"
     dev = aquery2_amd.Device(gpu, stream=stream)
     id1 = dev.gen_column(ck.GEN_ID1, 42, rank * n, n, n_total, 100)
     v1 = dev.gen_column(ck.GEN_V1, 42, rank * n, n, n_total, 100)
