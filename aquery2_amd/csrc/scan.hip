@@ -256,58 +256,70 @@ __global__ void __launch_bounds__(SB) tile_scan_kernel(const T* __restrict__ x, 
     write_tile<T, ALG, WR>(run, v, cnt, base, blockIdx.x * TS, n, out, stage_raw);
 }
 
-// ---- single-pass scan: chained tiles with decoupled look-back ---------------------------------------------------------------------
-// Tile ids are handed out by an atomic counter, so every predecessor of a running tile has started (forward progress).  A tile
+// ---- single-pass scan: chained links with decoupled look-back ---------------------------------------------------------------------
+// Link ids are handed out by an atomic counter, so every predecessor of a running link has started (forward progress).  A link
 // publishes its aggregate, then walks back over its predecessors adding aggregates until it meets a published inclusive prefix,
-// then publishes its own inclusive prefix.  Payload words and status words are agent-scope atomics (write-through / L1-bypassing),
-// the status store is a release and the look-back ends in an acquire fence (MI355X guide, Guideline 16).  Spins are bounded: on
-// a timeout the kernel raises `err` and the host falls back to the three-kernel scan.
-template <class A> __device__ inline void publish_payload(uint64_t* slot, A v) {
-    if constexpr (std::is_same_v<A, aqg_i128>) {
-        __hip_atomic_store(slot, v.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(slot + 1, v.hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if constexpr (sizeof(A) == 8) {
-        __hip_atomic_store(slot, __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        uint64_t w = 0;
-        __builtin_memcpy(&w, &v, sizeof(A));
-        __hip_atomic_store(slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-template <class A> __device__ inline A read_payload(uint64_t* slot) {
-    if constexpr (std::is_same_v<A, aqg_i128>) {
-        aqg_i128 r;
-        r.lo = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.hi = __hip_atomic_load(slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return r;
-    } else if constexpr (sizeof(A) == 8) {
-        return __builtin_bit_cast(A, __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    } else {
-        uint64_t w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        A v;
-        __builtin_memcpy(&v, &w, sizeof(A));
-        return v;
-    }
-}
+// then publishes its own inclusive prefix.
+// Hand-off words: a link owns NW = sizeof(A) / 4 64-bit words, word k = {status : 32 | 32 bits of the value}.  Every word is one
+// relaxed agent-scope atomic store (write-through, no drain, no fence: a release would cost a vmcnt(0) round trip per publication
+// and a `buffer_wbl2` would write back this XCD's dirty output lines) and one L1-bypassing atomic load.  A reader accepts a link
+// when all its words carry the same non-zero status: each word is written once per status, so equal flags mean one publication.
+// Measured at 1e9 int32 rows (mins): separate status + payload words with a drain in between 1.95 ms, this protocol with the
+// aggregate published before the sub-tile scans 1.50 ms; the same kernel without any look-back 1.32 ms.
+// Spins are bounded: on a timeout the kernel raises `err` and the host falls back to the three-kernel scan.
 enum : uint32_t { ST_NONE = 0, ST_AGG = 1, ST_PREFIX = 2 };
-// Hand-off protocol (MI355X guide, Guideline 16, "sc1 stores drained by vmcnt(0), then the flag"): the payload words are
-// write-through agent-scope stores, the storing lane drains them, then stores the status word the same way.  No release fence:
-// a `buffer_wbl2` would write back every dirty output line of this XCD's L2 on each publication.
-__device__ inline void publish_status(uint32_t* st, uint32_t v) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(st, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+template <class A> constexpr int flagged_words() { return (int)((sizeof(A) + 3) / 4); }
+template <class A> __device__ inline void publish_flagged(uint64_t* slot, uint32_t st, A v) {
+    constexpr int NW = flagged_words<A>();
+    uint32_t w[NW] = {};
+    __builtin_memcpy(w, &v, sizeof(A));
+#pragma unroll
+    for (int k = 0; k < NW; ++k) __hip_atomic_store(slot + k, ((uint64_t)st << 32) | w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// waits until the link at `slot` has published something; returns its status (ST_NONE: gave up) and the value
+template <class A> __device__ inline uint32_t poll_flagged(uint64_t* slot, A& v) {
+    constexpr int NW = flagged_words<A>();
+    for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
+        uint64_t r[NW];
+#pragma unroll
+        for (int k = 0; k < NW; ++k) r[k] = __hip_atomic_load(slot + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t st = (uint32_t)(r[0] >> 32);
+        bool ok = st != ST_NONE;
+#pragma unroll
+        for (int k = 1; k < NW; ++k) ok = ok && (uint32_t)(r[k] >> 32) == st;
+        if (ok) {
+            uint32_t w[NW];
+#pragma unroll
+            for (int k = 0; k < NW; ++k) w[k] = (uint32_t)r[k];
+            __builtin_memcpy(&v, w, sizeof(A));
+            return st;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return ST_NONE;
+}
+
+// fold of one value per lane over the workgroup (every lane gets it); ALG::op must commute
+template <class ALG, class A> __device__ inline A block_fold(A v, A* lds_r /* >= SB / 64 */) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = ALG::op(v, shfl_xor_any(v, off));
+    if (lane_id() == 0) lds_r[wave_id()] = v;
+    __syncthreads();
+    A t = ALG::identity();
+#pragma unroll
+    for (int w = 0; w < SB / 64; ++w) t = ALG::op(t, lds_r[w]);
+    return t;
 }
 
 template <class T> constexpr int chain_m() { return sizeof(T) <= 4 ? 8 : 4; }   // 2048-element sub-tiles per chain link
 
-template <class T, class ALG, int WR>
-__global__ void __launch_bounds__(SB) chained_scan_kernel(const T* __restrict__ x, uint32_t n, uint32_t* __restrict__ ctrl /* [0] tile counter, [1] error */,
-                                                          uint32_t* __restrict__ status, uint64_t* __restrict__ agg, uint64_t* __restrict__ incl,
-                                                          void* __restrict__ out) {
+template <class T, class ALG, int WR, int M>
+__global__ void __launch_bounds__(SB) chained_scan_kernel(const T* __restrict__ x, uint32_t n, uint32_t* __restrict__ ctrl /* [0] link counter, [1] error */,
+                                                          uint64_t* __restrict__ slots, void* __restrict__ out) {
     using A = typename ALG::A;
-    constexpr int PW = std::is_same_v<A, aqg_i128> ? 2 : 1;     // payload words per tile
-    constexpr int M = chain_m<T>();                             // one chain link = M sub-tiles kept in registers
+    constexpr int NW = flagged_words<A>();
     __shared__ A lds_w[8];
+    __shared__ A lds_r[SB / 64];
     __shared__ uint32_t s_tile;
     __shared__ A s_prefix;
     extern __shared__ __align__(16) unsigned char stage_raw[];
@@ -315,56 +327,45 @@ __global__ void __launch_bounds__(SB) chained_scan_kernel(const T* __restrict__ 
     __syncthreads();
     const uint32_t tile = s_tile;
     const uint64_t link_base = (uint64_t)tile * M * TS;
-    T v[M][IT];
+    T v[M][IT];                                                 // one chain link = M sub-tiles kept in registers
     uint32_t cnt[M];
-    A excl[M];
-    A total = ALG::identity();
+    A a[M], excl[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const uint64_t b64 = link_base + (uint64_t)m * TS + threadIdx.x * IT;
         const uint32_t base = b64 < n ? (uint32_t)b64 : n;
         load_tile_items(x, n, base, v[m], cnt[m]);
     }
+    A mine = ALG::identity();
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-        A a = ALG::identity();
+        a[m] = ALG::identity();
 #pragma unroll
-        for (int j = 0; j < IT; ++j) if ((uint32_t)j < cnt[m]) a = ALG::op(a, ALG::lift(v[m][j]));
-        A sub_total;
-        A e = block_scan_excl<ALG>(a, lds_w, sub_total);
-        excl[m] = ALG::op(total, e);                            // prefix inside the link
-        total = ALG::op(total, sub_total);
+        for (int j = 0; j < IT; ++j) if ((uint32_t)j < cnt[m]) a[m] = ALG::op(a[m], ALG::lift(v[m][j]));
+        mine = ALG::op(mine, a[m]);
     }
-    if (wave_id() == 0) {          // wave 0 publishes and looks back, 64 predecessors per step
+    // the link's aggregate goes out before the sub-tile scans: by the time a successor looks back it is there
+    const A total = block_fold<ALG>(mine, lds_r);
+    if (threadIdx.x == 0) publish_flagged<A>(slots + (size_t)tile * NW, tile == 0 ? ST_PREFIX : ST_AGG, total);
+    A run = ALG::identity();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        A sub_total;
+        A e = block_scan_excl<ALG>(a[m], lds_w, sub_total);
+        excl[m] = ALG::op(run, e);                              // prefix inside the link
+        run = ALG::op(run, sub_total);
+    }
+    if (wave_id() == 0) {          // wave 0 looks back, 64 predecessors per step
         const int lane = lane_id();
         A prefix = ALG::identity();
-        if (tile == 0) {
-            if (lane == 0) {
-                publish_payload<A>(incl, total);
-                publish_status(&status[0], ST_PREFIX);
-            }
-        } else {
-            if (lane == 0) {
-                publish_payload<A>(agg + (size_t)tile * PW, total);
-                publish_status(&status[tile], ST_AGG);
-            }
+        if (tile > 0) {
             int64_t p = (int64_t)tile - 1;
-            bool failed = false;
             while (true) {
                 const int64_t idx = p - lane;                         // lane l inspects predecessor p - l
-                uint32_t st = ST_PREFIX;                              // before tile 0: an empty prefix
-                if (idx >= 0) {
-                    uint32_t spins = 0;
-                    while ((st = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == ST_NONE) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (++spins > (1u << 22)) { failed = true; break; }
-                    }
-                }
-                if (__ballot(failed)) { if (lane == 0) atomicExch(&ctrl[1], 1u); break; }
-                // no acquire fence: every hand-off word is read with an agent-scope (L1-bypassing) atomic load, issued only after
-                // this lane's poll has matched
+                uint32_t st = ST_PREFIX;                              // before link 0: an empty prefix
                 A val = ALG::identity();
-                if (idx >= 0) val = st == ST_PREFIX ? read_payload<A>(incl + (size_t)idx * PW) : read_payload<A>(agg + (size_t)idx * PW);
+                if (idx >= 0) st = poll_flagged<A>(slots + (size_t)idx * NW, val);
+                if (__ballot(st == ST_NONE)) { if (lane == 0) atomicExch(&ctrl[1], 1u); break; }
                 const uint64_t pm = __ballot(st == ST_PREFIX);
                 const int k = pm ? __ffsll((long long)pm) - 1 : 64;   // nearest predecessor that already has its inclusive prefix
                 A contrib = lane <= k ? val : ALG::identity();
@@ -374,10 +375,7 @@ __global__ void __launch_bounds__(SB) chained_scan_kernel(const T* __restrict__ 
                 if (pm) break;
                 p -= 64;
             }
-            if (lane == 0) {
-                publish_payload<A>(incl + (size_t)tile * PW, ALG::op(prefix, total));
-                publish_status(&status[tile], ST_PREFIX);
-            }
+            if (lane == 0) publish_flagged<A>(slots + (size_t)tile * NW, ST_PREFIX, ALG::op(prefix, total));
         }
         if (lane == 0) s_prefix = prefix;
     }
@@ -723,13 +721,15 @@ template <class T, class ALG, int WR>
 int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out) {
     using A = typename ALG::A;
     uint32_t ntiles = aqg_ceil_div(n, TS);
-    const uint32_t nlinks = (ntiles + chain_m<T>() - 1) / chain_m<T>();
+    constexpr int M = chain_m<T>();
+    const uint32_t nlinks = (ntiles + M - 1) / M;
     constexpr size_t osz = WR == W_SUMS ? (std::is_floating_point_v<T> ? 8 : 16) : WR == W_AVGS ? 8 : sizeof(T);
     constexpr int PW = std::is_same_v<A, aqg_i128> ? 2 : 1;
     AQG_TRY(aqg_ws_reset(ctx));
     AQG_TRY(aqg_ws_ensure(ctx, (size_t)ntiles * (4 + 16 * PW + sizeof(A)) + ((size_t)ntiles / CH + 2) * sizeof(A) + 16384));
-    // Measured at 1e9 int32 rows (whole call): mins 2.49 ms chained vs 3.17 ms three-kernel; sums 5.86 vs 5.25; avgs 4.33 vs 3.90.
-    // The chained kernel holds 8 sub-tiles in registers, which costs occupancy when the results are 8 or 16 bytes wide.
+    // Measured at 1e9 int32 rows (whole call): mins 1.53 ms chained vs 3.17 ms three-kernel; sums 4.34 vs 4.09; avgs 2.94 vs 2.75.
+    // A 4-byte aggregate is handed over in one flagged word; the 8-byte sum of an int32 column takes two words per link and
+    // the look-back then costs 1.0 ms at 1e9 rows (the same kernel without any look-back: sums 3.35 ms, avgs 2.30 ms).
     constexpr bool use_chain = WR == W_MINS || WR == W_MAXS || WR == W_MAXP;
     if (!use_chain) {
         A *agg3, *chunk_tot;
@@ -743,16 +743,16 @@ int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out) {
         return aqg_check_launch(ctx, "prefix scan");
     }
     // ---- single pass (chained tiles) --------------------------------------------------------------------------------
-    uint32_t *ctrl, *status;
-    uint64_t *aggw, *inclw;
+    uint32_t* ctrl;
+    uint64_t* slots;
+    constexpr int NW = flagged_words<A>();
     AQG_TRY(aqg_ws_get(ctx, 16, &ctrl));
-    AQG_TRY(aqg_ws_get(ctx, ntiles, &status));
-    AQG_TRY(aqg_ws_get(ctx, (size_t)ntiles * PW, &aggw));
-    AQG_TRY(aqg_ws_get(ctx, (size_t)ntiles * PW, &inclw));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)nlinks * NW, &slots));
     AQG_HIP(ctx, hipMemsetAsync(ctrl, 0, 64, ctx->stream));
-    AQG_HIP(ctx, hipMemsetAsync(status, 0, (size_t)ntiles * 4, ctx->stream));
+    AQG_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)nlinks * NW * 8, ctx->stream));
     aqg_kernel_timer_begin(ctx);
-    hipLaunchKernelGGL((chained_scan_kernel<T, ALG, WR>), dim3(nlinks), dim3(SB), (size_t)TS * osz, ctx->stream, x, n, ctrl, status, aggw, inclw, out);
+    if constexpr (use_chain)
+        hipLaunchKernelGGL((chained_scan_kernel<T, ALG, WR, M>), dim3(nlinks), dim3(SB), (size_t)TS * osz, ctx->stream, x, n, ctrl, slots, out);
     aqg_kernel_timer_end(ctx);
     AQG_TRY(aqg_check_launch(ctx, "chained_scan_kernel"));
     uint32_t h[2] = {0, 0};
