@@ -118,3 +118,20 @@ def test_groupby_and_join_sizes(gpu, oracle, off):
         look = gpu.join_lookup(view(gpu, bk, off), view(gpu, pk, off))
         pos = {int(k): i for i, k in enumerate(bk.tolist())}
         assert np.array_equal(look, np.array([pos.get(int(k), 0xFFFFFFFF) for k in pk.tolist()], dtype=np.uint32)), n
+
+
+@pytest.mark.parametrize("dt", [np.int32, np.int16, np.float32, np.int64, np.float64])
+def test_running_minmax_changes_across_many_links(gpu, oracle, dt):
+    """mins / maxs of a drifting series whose running extreme keeps changing to the last row: every chain link of the
+    single-pass scan needs the prefix handed over by its predecessors, over several 64-link look-back windows
+    (aggregations.h:350-381: mins seeds with max, maxs with min)"""
+    n = 6_000_011                       # 367 links of 16384 rows (4-byte types), 733 links of 8192 rows (8-byte types)
+    rng = np.random.default_rng(11)
+    span = 30000 if np.dtype(dt).itemsize == 2 else 1_000_000
+    drift = np.linspace(span, -span, n)
+    x = (drift + rng.integers(-span // 50, span // 50, n)).astype(dt)
+    for arr in (x, x[::-1].copy()):
+        d = gpu.to_device(arr)
+        assert gu.same_bits(gpu.scan(ck.SCAN_MINS, d), oracle.scan(ck.SCAN_MINS, arr))
+        assert gu.same_bits(gpu.scan(ck.SCAN_MAXS, d), oracle.scan(ck.SCAN_MAXS, arr))
+        d.free()
