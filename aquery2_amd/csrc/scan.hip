@@ -730,6 +730,8 @@ int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out) {
     // Measured at 1e9 int32 rows (whole call): mins 1.53 ms chained vs 3.17 ms three-kernel; sums 4.34 vs 4.09; avgs 2.94 vs 2.75.
     // A 4-byte aggregate is handed over in one flagged word; the 8-byte sum of an int32 column takes two words per link and
     // the look-back then costs 1.0 ms at 1e9 rows (the same kernel without any look-back: sums 3.35 ms, avgs 2.30 ms).
+    // Packing that sum into one 62-bit word changed nothing (4.43 ms): at two workgroups per CU (the 16-byte results take the
+    // registers) the look-back latency itself is exposed, not the number of words.
     constexpr bool use_chain = WR == W_MINS || WR == W_MAXS || WR == W_MAXP;
     if (!use_chain) {
         A *agg3, *chunk_tot;
