@@ -267,6 +267,21 @@ class Device:
                                     C.c_void_p(out.ptr)), "aqg_scan")
         return out if keep else out.to_host()
 
+    def scan_resume(self, op, x, carry, row_offset, keep=False, out=None):
+        """sums / avgs of one row-range shard: `carry` = sum of every earlier row (python int for integer columns, float for
+        floating ones), `row_offset` = number of earlier rows (aqg_scan_resume)"""
+        xd = self._dev(x)
+        ot = self.lib.aqg_scan_out_dtype(op, xd.tag)
+        out = out if out is not None else self.empty(xd.n, TAG2NP[ot])
+        if np.issubdtype(xd.dtype, np.floating):
+            raw = np.array([float(carry), 0.0], dtype=np.float64).tobytes()
+        else:
+            raw = (int(carry) & ((1 << 128) - 1)).to_bytes(16, "little")
+        buf = C.create_string_buffer(raw, 16)
+        self._chk(self.lib.aqg_scan_resume(self.ctx, op, xd.tag, C.c_void_p(xd.ptr), C.c_uint32(xd.n), buf, C.c_uint64(int(row_offset)),
+                                           C.c_void_p(out.ptr)), "aqg_scan_resume")
+        return out if keep else out.to_host()
+
     # -- gather / filter
     def gather(self, x, idx):
         xd, idd = self._dev(x), self._dev(np.ascontiguousarray(idx, dtype=np.uint32) if not isinstance(idx, DevBuf) else idx)

@@ -205,17 +205,26 @@ template <class ALG> void launch_agg_scan(aqg_ctx* ctx, typename ALG::A* tile_ag
 // K3: scan inside the tile with the carry-in; WRITER(out, i, inclusive_value)
 enum : int { W_SUMS = 0, W_AVGS = 1, W_MINS = 2, W_MAXS = 3, W_MAXP = 4 /* running max without the reference's seed (maxw, w >= n) */ };
 
+// a scan that resumes a column sharded by row range (aqg_scan_resume): the sum of every earlier row in the result's LongType
+// and the number of earlier rows.  Kept apart from the tile accumulator, which is 64 bits wide for <= 4-byte integer columns
+// while the carry of a table of more than 2^32 rows is not.
+struct ScanSeed {
+    aqg_i128 i;        // integer columns
+    double d;          // floating columns (-0.0 when there is nothing to add: the only value that leaves every double unchanged)
+    uint64_t row0;     // rows before this shard (avgs divide by row0 + i + 1)
+};
+
 // writes one tile's results: `run` = fold of everything before this lane's first element
 template <class T, class ALG, int WR>
 __device__ inline void write_tile(typename ALG::A run, const T (&v)[IT], uint32_t cnt, uint32_t base, uint32_t tile_base, uint32_t n, void* __restrict__ out,
-                                  unsigned char* stage_raw) {
+                                  unsigned char* stage_raw, const ScanSeed& seed = ScanSeed{{0, 0}, -0.0, 0}) {
     if constexpr (WR == W_SUMS) {
         using O = std::conditional_t<std::is_floating_point_v<T>, double, aqg_i128>;
         O o[IT];
 #pragma unroll
         for (int j = 0; j < IT; ++j) {
             if ((uint32_t)j < cnt) run = ALG::op(run, ALG::lift(v[j]));
-            if constexpr (std::is_floating_point_v<T>) o[j] = run; else o[j] = sum_alg<T>::to_i128(run);
+            if constexpr (std::is_floating_point_v<T>) o[j] = seed.d + run; else o[j] = i128_add(seed.i, sum_alg<T>::to_i128(run));
         }
         store_tile_striped(static_cast<O*>(out), tile_base, o, n, reinterpret_cast<O*>(stage_raw));
     } else if constexpr (WR == W_AVGS) {
@@ -223,7 +232,13 @@ __device__ inline void write_tile(typename ALG::A run, const T (&v)[IT], uint32_
 #pragma unroll
         for (int j = 0; j < IT; ++j) {
             if ((uint32_t)j < cnt) run = ALG::op(run, ALG::lift(v[j]));
-            o[j] = sum_alg<T>::to_double(run) / (double)(base + j + 1);            // (s += arr[i]) / (double)(i + 1)
+            double sum;                                                            // (s += arr[i]) / (double)(i + 1)
+            if constexpr (std::is_floating_point_v<T>) sum = seed.d + run;
+            else {
+                const aqg_i128 t = i128_add(seed.i, sum_alg<T>::to_i128(run));
+                if constexpr (std::is_unsigned_v<T>) sum = u128_to_double(t.hi, t.lo); else sum = i128_to_double(t);
+            }
+            o[j] = sum / (double)(seed.row0 + base + j + 1);
         }
         store_tile_striped(static_cast<double*>(out), tile_base, o, n, reinterpret_cast<double*>(stage_raw));
     } else {
@@ -241,7 +256,7 @@ __device__ inline void write_tile(typename ALG::A run, const T (&v)[IT], uint32_
 
 template <class T, class ALG, int WR>
 __global__ void __launch_bounds__(SB) tile_scan_kernel(const T* __restrict__ x, uint32_t n, const typename ALG::A* __restrict__ tile_prefix,
-                                                       void* __restrict__ out) {
+                                                       void* __restrict__ out, ScanSeed seed) {
     using A = typename ALG::A;
     __shared__ A lds_w[8];
     extern __shared__ __align__(16) unsigned char stage_raw[];
@@ -253,7 +268,7 @@ __global__ void __launch_bounds__(SB) tile_scan_kernel(const T* __restrict__ x, 
     for (int j = 0; j < IT; ++j) if ((uint32_t)j < cnt) a = ALG::op(a, ALG::lift(v[j]));
     A total;
     A run = ALG::op(tile_prefix[blockIdx.x], block_scan_excl<ALG>(a, lds_w, total));
-    write_tile<T, ALG, WR>(run, v, cnt, base, blockIdx.x * TS, n, out, stage_raw);
+    write_tile<T, ALG, WR>(run, v, cnt, base, blockIdx.x * TS, n, out, stage_raw, seed);
 }
 
 // ---- single-pass scan: chained links with decoupled look-back ---------------------------------------------------------------------
@@ -718,7 +733,7 @@ template <class T> struct sq_alg {   // tile aggregate of x*x in double
 };
 
 template <class T, class ALG, int WR>
-int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out) {
+int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out, const ScanSeed& seed = ScanSeed{{0, 0}, -0.0, 0}) {
     using A = typename ALG::A;
     uint32_t ntiles = aqg_ceil_div(n, TS);
     constexpr int M = chain_m<T>();
@@ -740,7 +755,7 @@ int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out) {
         hipLaunchKernelGGL((tile_reduce_kernel<T, ALG>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, agg3);
         launch_agg_scan<ALG>(ctx, agg3, ntiles, chunk_tot);
         aqg_kernel_timer_begin(ctx);
-        hipLaunchKernelGGL((tile_scan_kernel<T, ALG, WR>), dim3(ntiles), dim3(SB), (size_t)TS * osz, ctx->stream, x, n, agg3, out);
+        hipLaunchKernelGGL((tile_scan_kernel<T, ALG, WR>), dim3(ntiles), dim3(SB), (size_t)TS * osz, ctx->stream, x, n, agg3, out, seed);
         aqg_kernel_timer_end(ctx);
         return aqg_check_launch(ctx, "prefix scan");
     }
@@ -766,7 +781,7 @@ int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out) {
     AQG_TRY(aqg_ws_get(ctx, ntiles, &agg));
     hipLaunchKernelGGL((tile_reduce_kernel<T, ALG>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, agg);
     hipLaunchKernelGGL((agg_scan_kernel<ALG>), dim3(1), dim3(SB), 0, ctx->stream, agg, ntiles);
-    hipLaunchKernelGGL((tile_scan_kernel<T, ALG, WR>), dim3(ntiles), dim3(SB), (size_t)TS * osz, ctx->stream, x, n, agg, out);
+    hipLaunchKernelGGL((tile_scan_kernel<T, ALG, WR>), dim3(ntiles), dim3(SB), (size_t)TS * osz, ctx->stream, x, n, agg, out, seed);
     return aqg_check_launch(ctx, "prefix scan");
 }
 
@@ -783,6 +798,25 @@ int aqg_scan_out_dtype(int op, int t) {
     case AQG_SCAN_RATIOW: return aqg_fp_type(t);
     }
     return AQG_ERROR;
+}
+
+int aqg_scan_resume(aqg_ctx* ctx, int op, int t, const void* xv, uint32_t n, const void* carry_host16, uint64_t row_offset, void* out) {
+    if (!ctx || (!xv && n) || (!out && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_scan_resume: bad argument");
+    if (op != AQG_SCAN_SUMS && op != AQG_SCAN_AVGS) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_scan_resume: sums and avgs only (mins / maxs resume from a leading row)");
+    AQG_CHECK_ROWS(ctx, n, "aqg_scan_resume");
+    if (n == 0) return AQG_OK;
+    if (!dt_is_num(t)) return aqg_fail(ctx, AQG_ERR_DTYPE, "scan: the column dtype is not numeric (128-bit results are not inputs)");
+    ScanSeed seed{{0, 0}, -0.0, row_offset};
+    if (carry_host16) {
+        if (t == AQG_FLOAT || t == AQG_DOUBLE) memcpy(&seed.d, carry_host16, 8);
+        else memcpy(&seed.i, carry_host16, 16);
+    }
+    return aqg_dispatch_num(t, [&](auto tt) -> int {
+        using T = typename decltype(tt)::type;
+        const T* x = static_cast<const T*>(xv);
+        if (op == AQG_SCAN_SUMS) return run_prefix<T, sum_alg<T>, W_SUMS>(ctx, x, n, out, seed);
+        return run_prefix<T, sum_alg<T>, W_AVGS>(ctx, x, n, out, seed);
+    });
 }
 
 int aqg_scan(aqg_ctx* ctx, int op, int t, const void* xv, uint32_t n, uint32_t w, void* out) {

@@ -149,3 +149,35 @@ def running_minmax_with_carry(dev, op, x_local, carry):
     view = DevBuf(dev, res.ptr + h * np.dtype(x_local.dtype).itemsize, x_local.dtype, x_local.n, owned=False)
     view._keep = (res, owner)
     return view
+
+
+def exchange_totals(dist, total, device="cpu"):
+    """all_gather every rank's column total and row count; returns (sum of the totals of the ranks before this one, rows before
+    this rank).  `total`: python int of up to 128 bits (integer columns; travels as two int64 halves) or float."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    total, rows = total
+    if isinstance(total, float):
+        mine = torch.tensor([total, float(rows)], dtype=torch.float64, device=device)
+        out = torch.zeros(world * 2, dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(out, mine)
+        o = out.view(world, 2).tolist()
+        carry = 0.0
+        for r in range(rank):
+            carry += o[r][0]
+        return (carry if rank else -0.0), int(sum(o[r][1] for r in range(rank)))
+    u = int(total) & ((1 << 128) - 1)
+    halves = [(u >> s) & 0xFFFFFFFF for s in (0, 32, 64, 96)]          # four 32-bit limbs: every one fits an int64 as is
+    mine = torch.tensor(halves + [int(rows)], dtype=torch.int64, device=device)
+    out = torch.zeros(world * 5, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    o = out.view(world, 5).tolist()
+    carry = 0
+    for r in range(rank):
+        v = o[r][0] | (o[r][1] << 32) | (o[r][2] << 64) | (o[r][3] << 96)
+        carry += v - (1 << 128) if v >> 127 else v                        # back to a signed 128-bit value
+    return carry, int(sum(o[r][4] for r in range(rank)))
+
+
+def running_sums_with_carry(dev, op, x_local, carry, rows_before):
+    """sums / avgs of this shard given the sum and the number of every earlier row (from exchange_totals)"""
+    return dev.scan_resume(op, x_local, carry, rows_before, keep=True)

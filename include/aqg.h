@@ -150,6 +150,12 @@ typedef enum aqg_scanop {
 } aqg_scanop;
 int aqg_scan(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, uint32_t w, void* out);
 int aqg_scan_out_dtype(int op, int t);
+/* sums / avgs of one row-range shard of a column: rows [row_offset, row_offset + n) of the whole column.
+ * `carry_host16` = the sum of every earlier row in the result's LongType (server/types.h:152-160): 16 bytes holding an
+ * __int128 / unsigned __int128 for integer columns, a double in the first 8 bytes for floating ones; NULL = nothing before.
+ * Element i is carry + x[0..i] (sums, aggregations.h:89-103) or that over (row_offset + i + 1) (avgs, :105-125), i.e. the
+ * rows the whole-column scan would have produced.  Integer results are bit-identical to the unsharded scan.  */
+int aqg_scan_resume(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, const void* carry_host16, uint64_t row_offset, void* out);
 
 /* ---- gather / mask filter ---------------------------------------------------
  * ColRef::operator[](vector_type<uint32_t>&)  server/table.h:184-189

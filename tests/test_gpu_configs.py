@@ -319,3 +319,22 @@ def test_scans_and_windows_over_row_range_shards(gpu, oracle):
             carry = gpu.to_device(np.array([fold(price[:bounds[r]])], dtype=price.dtype)) if r else None
             got = shard.running_minmax_with_carry(gpu, op, dev_shards[r], carry).to_host()
             assert gu.same_bits(got, want[bounds[r]:bounds[r + 1]]), (name, r)
+    # running sums / avgs: the carry is the exact sum of every earlier row (128 bits for integer columns) and avgs also need
+    # the number of earlier rows; integer results are bit-identical to the whole-column scan
+    for dt in (np.int32, np.int64, np.uint32, np.float64):
+        col = price.astype(dt) if dt != np.int64 else price.astype(np.int64) * 3_000_000_007 - 5_000_000_000_000
+        for name in ("sums", "avgs"):
+            op = ck.SCAN_NAMES[name]
+            want = oracle.scan(op, col)
+            for r in range(3):
+                part = np.ascontiguousarray(col[bounds[r]:bounds[r + 1]])
+                before = col[:bounds[r]]
+                carry = float(np.sum(before)) if dt == np.float64 else sum(int(v) for v in before.tolist())
+                if r == 0:
+                    carry = -0.0 if dt == np.float64 else 0
+                got = shard.running_sums_with_carry(gpu, op, gpu.to_device(part), carry, bounds[r]).to_host()
+                ref = want[bounds[r]:bounds[r + 1]]
+                if dt == np.float64:
+                    assert np.all(np.abs(got - ref) <= 1e-12 * np.maximum(np.abs(ref), 1.0)), (name, r)
+                else:
+                    assert gu.same_bits(got, ref), (dt, name, r)

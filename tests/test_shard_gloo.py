@@ -79,7 +79,13 @@ def _tails_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rows = torch.arange(rank * 100, rank * 100 + 100, dtype=torch.int32)        # this shard's rows of an ordered column
     prev_tail, next_head = shard.exchange_tails(dist, rows[-4:], rows[:1])
-    q.put((rank, None if prev_tail is None else prev_tail.tolist(), None if next_head is None else next_head.tolist()))
+    # the collective of sharded running sums: totals of up to 128 bits (negative ones too) and the row counts before a rank
+    totals = [-(1 << 100) - 7, (1 << 70) + 3, 12345]
+    carry, before = shard.exchange_totals(dist, (totals[rank], 100 + rank))
+    fcarry, fbefore = shard.exchange_totals(dist, (0.5 + rank, 100 + rank))
+    sums_ok = (carry == sum(totals[:rank]) and before == sum(100 + r for r in range(rank))
+               and fcarry == sum(0.5 + r for r in range(rank)) and fbefore == before)
+    q.put((rank, None if prev_tail is None else prev_tail.tolist(), None if next_head is None else next_head.tolist(), sums_ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -95,7 +101,8 @@ def test_halo_exchange_delivers_the_neighbours_rows():
         p.start()
     got = {}
     for _ in range(3):
-        r, prev_tail, next_head = q.get(timeout=120)
+        r, prev_tail, next_head, sums_ok = q.get(timeout=120)
+        assert sums_ok, r
         got[r] = (prev_tail, next_head)
     for p in procs:
         p.join(timeout=60)
