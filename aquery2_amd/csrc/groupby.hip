@@ -246,12 +246,14 @@ __global__ void __launch_bounds__(BLOCK) agg_kernel(KeySpec ks, AccSpec as, GTab
 // Same LDS open-addressing idea as agg_kernel, pared down to what these shapes need: the slot is the packed key alone (4 or 8
 // bytes), eight rows per lane per step with all probes issued before the first compare, and NO first-row bookkeeping in the
 // loop -- first rows are recovered afterwards by first_rows_kernel, which stops as soon as every group has one (a few tiles on
-// h2o data).  vkind: 0 int32, 1 uint32, 2 float; kind: ACC_ADD_I / ACC_ADD_F / ACC_MIN / ACC_MAX; square: accumulate x*x.
+// h2o data).  vkind: 0 int32, 1 uint32, 2 float (VW = 4) or 3 int64, 4 uint64, 5 double (VW = 8: every value column is 8 bytes wide;
+// an int64 sum is two accumulators over the same column, `part` 1 / 2 = its low / high half);
+// kind: ACC_ADD_I / ACC_ADD_F / ACC_MIN / ACC_MAX; square: accumulate x*x.
 // (The generic agg_kernel ran max(v1),min(v2) by id1 at 27 % of the HBM roofline and var(v1) at 18 %; this kernel does SUM at 75 %.)
-struct FastVals { const void* col[4]; int vkind[4]; int kind[4]; int square[4]; };
+struct FastVals { const void* col[4]; int vkind[4]; int kind[4]; int square[4]; int part[4]; };
 constexpr uint32_t OCCUPIED = 0xFFFFFFFEu;   // first_row mark: "group exists, first row not yet known"
 
-template <int NV, bool COUNT, bool K64>
+template <int NV, bool COUNT, bool K64, int VW = 4>
 __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_hi, FastVals fv, GTable gt, uint32_t n, uint32_t lcap) {
     using KT = std::conditional_t<K64, uint64_t, uint32_t>;
     constexpr KT EMPTYK = K64 ? (KT)EMPTY64 : (KT)EMPTY32;
@@ -292,14 +294,23 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
         }
         return FAIL;
     };
-    auto operand = [&](int a, uint32_t bits) -> uint64_t {
-        switch (fv.vkind[a]) {
-        case 0: return val_operand_t((int32_t)bits, fv.kind[a], fv.square[a]);
-        case 1: return val_operand_t((uint32_t)bits, fv.kind[a], fv.square[a]);
-        default: return val_operand_t(__uint_as_float(bits), fv.kind[a], fv.square[a]);
+    using VB = std::conditional_t<VW == 8, uint64_t, uint32_t>;       // raw bits of one value
+    auto operand = [&](int a, VB bits) -> uint64_t {
+        if constexpr (VW == 8) {
+            switch (fv.vkind[a]) {
+            case 3: return val_operand_t((int64_t)bits, fv.kind[a], fv.square[a], fv.part[a]);
+            case 4: return val_operand_t((uint64_t)bits, fv.kind[a], fv.square[a], fv.part[a]);
+            default: return val_operand_t(__builtin_bit_cast(double, (uint64_t)bits), fv.kind[a], fv.square[a]);
+            }
+        } else {
+            switch (fv.vkind[a]) {
+            case 0: return val_operand_t((int32_t)bits, fv.kind[a], fv.square[a]);
+            case 1: return val_operand_t((uint32_t)bits, fv.kind[a], fv.square[a]);
+            default: return val_operand_t(__uint_as_float((uint32_t)bits), fv.kind[a], fv.square[a]);
+            }
         }
     };
-    auto to_table = [&](KT k, const uint32_t* vbits) {   // rare: LDS table at its load limit, or tail rows
+    auto to_table = [&](KT k, const VB* vbits) {   // rare: LDS table at its load limit, or tail rows
         uint32_t g = gt_find_or_insert(gt, K64 ? (uint64_t)k : (uint64_t)(uint32_t)k);
         if (g == FAIL) return;
         atomicMin(gt.first_p(g), OCCUPIED);
@@ -320,10 +331,20 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
             h1 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys_hi + base + 4);
         }
         pack<uint32_t, 4> v0[NV ? NV : 1], v1[NV ? NV : 1];
+        pack<uint64_t, 2> w[VW == 8 && NV ? NV : 1][4];
         _Pragma("unroll") for (int a = 0; a < NV; ++a) {
-            v0[a] = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(fv.col[a]) + base);
-            v1[a] = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(fv.col[a]) + base + 4);
+            if constexpr (VW == 8) {
+                if (a > 0 && fv.col[a] == fv.col[a - 1]) {   // both halves of an int64 sum (or sum and sum of squares) read one column
+                    _Pragma("unroll") for (int q = 0; q < 4; ++q) w[a][q] = w[a - 1][q];
+                } else {
+                    _Pragma("unroll") for (int q = 0; q < 4; ++q) w[a][q] = *reinterpret_cast<const pack<uint64_t, 2>*>(static_cast<const uint64_t*>(fv.col[a]) + base + 2 * q);
+                }
+            } else {
+                v0[a] = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(fv.col[a]) + base);
+                v1[a] = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(fv.col[a]) + base + 4);
+            }
         }
+        auto raw = [&](int a, int j) -> VB { if constexpr (VW == 8) return w[a][j >> 1].v[j & 1]; else return j < 4 ? v0[a].v[j] : v1[a].v[j - 4]; };
         KT k[8], cur[8];
         uint32_t slot[8];
 #pragma unroll
@@ -341,6 +362,35 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
         }
         _Pragma("unroll") for (int a = 0; a < NV; ++a) {
             uint64_t* la = lacc + (size_t)a * LT;
+            if constexpr (VW == 8) {
+                if (fv.kind[a] == ACC_ADD_F && !fv.square[a]) {        // sum / avg of a double column
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<double*>(&la[slot[j]]), __builtin_bit_cast(double, (uint64_t)raw(a, j)));
+                } else {
+                    uint64_t o[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = operand(a, raw(a, j));
+                    switch (fv.kind[a]) {
+                    case ACC_ADD_I:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)o[j]);
+                        break;
+                    case ACC_ADD_F:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<double*>(&la[slot[j]]), __builtin_bit_cast(double, o[j]));
+                        break;
+                    case ACC_MIN:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicMin(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)o[j]);
+                        break;
+                    default:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicMax(reinterpret_cast<unsigned long long*>(&la[slot[j]]), (unsigned long long)o[j]);
+                        break;
+                    }
+                }
+                continue;
+            }
             // wave-uniform branches, one per accumulator per eight rows; plain sums keep their own straight-line form
             if (fv.kind[a] == ACC_ADD_F && !fv.square[a]) {
 #pragma unroll
@@ -390,8 +440,8 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             if (slot[j] == FAIL) {
-                uint32_t vb[NV ? NV : 1];
-                _Pragma("unroll") for (int a = 0; a < NV; ++a) vb[a] = j < 4 ? v0[a].v[j] : v1[a].v[j - 4];
+                VB vb[NV ? NV : 1];
+                _Pragma("unroll") for (int a = 0; a < NV; ++a) vb[a] = raw(a, j);
                 to_table(k[j], vb);
             }
         }
@@ -399,8 +449,8 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
     if (blockIdx.x == 0) {                     // tail rows (< 8)
         uint32_t row = (nchunk << 3) + threadIdx.x;
         if (row < n) {
-            uint32_t vb[NV ? NV : 1];
-            _Pragma("unroll") for (int a = 0; a < NV; ++a) vb[a] = static_cast<const uint32_t*>(fv.col[a])[row];
+            VB vb[NV ? NV : 1];
+            _Pragma("unroll") for (int a = 0; a < NV; ++a) vb[a] = static_cast<const VB*>(fv.col[a])[row];
             KT key;
             if constexpr (K64) key = (uint64_t)keys[row] | ((uint64_t)keys_hi[row] << 32); else key = keys[row];
             to_table(key, vb);
@@ -1203,13 +1253,19 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     bool fast = use_lds && !plan.sj && !big_lds && ((k32 && key32(0)) || fast_k64) && n >= 8 && (as.nacc >= 1 || plan.need_count || for_build) && as.nacc <= 4;
     FastVals fv;
     memset(&fv, 0, sizeof fv);
+    // value columns: all 4 bytes wide, or all 8 bytes wide (an int64 sum takes two accumulators)
+    auto wide_dt = [](int dt) { return dt == AQG_INT64 || dt == AQG_UINT64 || dt == AQG_DOUBLE; };
+    const bool fast_v8 = as.nacc >= 1 && as.nacc <= 4 && wide_dt(as.dt[0]) && getenv("AQG_DISABLE_FAST64") == nullptr;
     for (int a = 0; a < as.nacc && fast; ++a) {
         const int dt = as.dt[a];
-        if (as.part[a] || !(dt == AQG_INT32 || dt == AQG_UINT32 || dt == AQG_FLOAT) || ((uintptr_t)as.col[a] & 15)) fast = false;
+        if ((uintptr_t)as.col[a] & 15) fast = false;
+        if (fast_v8) { if (!wide_dt(dt)) fast = false; }
+        else if (as.part[a] || !(dt == AQG_INT32 || dt == AQG_UINT32 || dt == AQG_FLOAT)) fast = false;
         fv.col[a] = as.col[a];
-        fv.vkind[a] = dt == AQG_INT32 ? 0 : dt == AQG_UINT32 ? 1 : 2;
+        fv.vkind[a] = dt == AQG_INT32 ? 0 : dt == AQG_UINT32 ? 1 : dt == AQG_FLOAT ? 2 : dt == AQG_INT64 ? 3 : dt == AQG_UINT64 ? 4 : 5;
         fv.kind[a] = as.kind[a];
         fv.square[a] = as.square[a];
+        fv.part[a] = as.part[a];
     }
     // ---- pass over the rows ---------------------------------------------------------------------
     if (n && plan.sj) {
@@ -1235,6 +1291,12 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         };
         auto by_nv = [&](auto count_tag, auto k64_tag) -> int {
             constexpr bool C = decltype(count_tag)::value, K = decltype(k64_tag)::value;
+            if (fast_v8) switch (as.nacc) {
+            case 1: return launch(&agg32_kernel<1, C, K, 8>);
+            case 2: return launch(&agg32_kernel<2, C, K, 8>);
+            case 3: return launch(&agg32_kernel<3, C, K, 8>);
+            default: return launch(&agg32_kernel<4, C, K, 8>);
+            }
             switch (as.nacc) {
             case 0: return launch(&agg32_kernel<0, C, K>);
             case 1: return launch(&agg32_kernel<1, C, K>);

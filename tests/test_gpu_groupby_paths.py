@@ -156,3 +156,34 @@ def test_dense_domain_sampled_ranges_miss_and_recover(gpu, oracle):
     g = gpu.groupby_build([a, b], hint=8000)
     assert np.array_equal(g.reversemap(), o["reversemap"]) and np.array_equal(g.counts(), o["counts"])
     g.destroy()
+
+
+@pytest.mark.parametrize("n", [77, 1_000_003])
+def test_fast_kernel_8_byte_value_columns(gpu, oracle, n):
+    """one or two 4-byte keys with 1..4 accumulators over 8-byte columns (agg32_kernel<.., VW = 8>): doubles, int64 sums that
+    need all 128 bits of the reference's __int128 (two 64-bit half sums), order-preserving MIN / MAX of negative int64"""
+    rng = np.random.default_rng(5 + n)
+    f64 = np.round(rng.uniform(-1e6, 1e6, n), 3)
+    i64 = rng.integers(-(1 << 62), 1 << 62, n, dtype=np.int64)
+    u64 = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    shapes = [(["sum"], [f64]), (["avg"], [f64]), (["min", "max"], [f64, f64]), (["var"], [f64]), (["sum"], [i64]), (["sum"], [u64]),
+              (["min", "max"], [i64, u64]), (["sum", "avg"], [i64, f64]), (["sum", "count", "max"], [f64, f64, i64]), (["avg", "avg", "sum"], [f64, -f64, u64])]
+    for keys in ([rng.integers(-40, 40, n).astype(np.int32)], [rng.integers(0, 9, n).astype(np.int32), rng.integers(0, 7, n).astype(np.uint32) * np.uint32(600_000_000)]):
+        ogb = oracle.groupby(keys)
+        for names, vals in shapes:
+            ops = [ck.RED_NAMES[nm] for nm in names]
+            gb = gpu.groupby_agg(keys, ops, vals, hint=128)
+            assert gb.ngroups == ogb["ngroups"]
+            assert np.array_equal(gb.first_rows(), ogb["first_rows"])
+            for k, key in enumerate(keys):
+                assert np.array_equal(gb.keys(k, key.dtype), key[ogb["first_rows"]])
+            for j, (nm, v) in enumerate(zip(names, vals)):
+                got = gb.result(j, ops[j], ck.tag_of(v))
+                want = oracle.grouped_reduce(ops[j], v, ogb)
+                if v.dtype.kind == "f" and nm in ("sum", "avg", "var"):
+                    w, g = want.astype(np.float64), got.astype(np.float64)
+                    scale = np.maximum(1.0, np.abs(w)) if nm != "var" else np.maximum(1.0, np.abs(w)) * 1e3
+                    assert np.all(np.abs(g - w) <= scale * len(v) * 2.0 ** -50), (nm, names)
+                else:
+                    assert gu.same_bits(got, want), (nm, v.dtype, names)
+            gb.destroy()

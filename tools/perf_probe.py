@@ -60,8 +60,20 @@ if which in ("all", "generic"):
     timeit("min(v3) by id1", 8, aggg("c", [id1], [ck.RED_MIN], [v3]))
     timeit("sum(v1) by id1,id2%7 (700 groups)", 12, aggg("d", [id1, k7], [ck.RED_SUM], [v1]))
     timeit("sum(v1),max(v2),min(v3),avg(v1) by id1", 16, aggg("e", [id1], [ck.RED_SUM, ck.RED_MAX, ck.RED_MIN, ck.RED_AVG], [v1, v2, v3, v1]))
+    # 8-byte value columns (doubles, int64): the same kernel with 8-byte value loads
+    v3d = d.ewise(ck.OP_MUL, v3, np.float64(1.0), ot=ck.DOUBLE, keep=True)
+    v1l = d.ewise(ck.OP_MUL, v1, np.int64(3_000_000_007), ot=ck.INT64, keep=True)
+    assert v3d.dtype == np.float64 and v1l.dtype == np.int64
+    timeit("sum(v3 double) by id1", 12, aggg("f", [id1], [ck.RED_SUM], [v3d]))
+    timeit("avg(v3 double) by id1", 12, aggg("g", [id1], [ck.RED_AVG], [v3d]))
+    timeit("min(v3 double) by id1", 12, aggg("h", [id1], [ck.RED_MIN], [v3d]))
+    timeit("sum(v1 int64) by id1", 12, aggg("i", [id1], [ck.RED_SUM], [v1l]))
+    timeit("sum(v3 double) by id1,id2%7", 16, aggg("j", [id1, k7], [ck.RED_SUM], [v3d]))
+    v2d = d.ewise(ck.OP_MUL, v2, np.float64(1.0), ot=ck.DOUBLE, keep=True)
+    timeit("avg(v3d),avg(v2d),sum(v1 int64) by id1", 28, aggg("k", [id1], [ck.RED_AVG, ck.RED_AVG, ck.RED_SUM], [v3d, v2d, v1l]))
+    v2d.free()
     for k in list(hg): hg[k].destroy()
-    k7.free()
+    k7.free(); v3d.free(); v1l.free()
 if which == "q10":
     ids = [col(c) for c in (ck.GEN_ID1, ck.GEN_ID2, ck.GEN_ID3, ck.GEN_ID4, ck.GEN_ID5, ck.GEN_ID6)]
     v3 = col(ck.GEN_V3)
