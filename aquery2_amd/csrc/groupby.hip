@@ -323,12 +323,19 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
     wg_span(nchunk, c_lo, c_hi);               // one contiguous span of rows per workgroup
     for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
         const size_t base = (size_t)c * 8;
-        pack<uint32_t, 4> k0 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base);
-        pack<uint32_t, 4> k1 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base + 4);
-        pack<uint32_t, 4> h0, h1;
-        if constexpr (K64) {
-            h0 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys_hi + base);
-            h1 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys_hi + base + 4);
+        // K64 with keys_hi == nullptr: `keys` is ONE 8-byte column (its bits are the packed key); otherwise two 4-byte columns
+        const bool key8 = K64 && keys_hi == nullptr;
+        pack<uint32_t, 4> k0, k1, h0, h1;
+        pack<uint64_t, 2> kw[K64 ? 4 : 1];
+        if (key8) {
+            _Pragma("unroll") for (int q = 0; q < (K64 ? 4 : 1); ++q) kw[q] = *reinterpret_cast<const pack<uint64_t, 2>*>(reinterpret_cast<const uint64_t*>(keys) + base + 2 * q);
+        } else {
+            k0 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base);
+            k1 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base + 4);
+            if constexpr (K64) {
+                h0 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys_hi + base);
+                h1 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys_hi + base + 4);
+            }
         }
         pack<uint32_t, 4> v0[NV ? NV : 1], v1[NV ? NV : 1];
         pack<uint64_t, 2> w[VW == 8 && NV ? NV : 1][4];
@@ -349,8 +356,10 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
         uint32_t slot[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if constexpr (K64) { k[j] = (uint64_t)k0.v[j] | ((uint64_t)h0.v[j] << 32); k[4 + j] = (uint64_t)k1.v[j] | ((uint64_t)h1.v[j] << 32); }
-            else { k[j] = k0.v[j]; k[4 + j] = k1.v[j]; }
+            if constexpr (K64) {
+                if (key8) { k[j] = kw[j >> 1].v[j & 1]; k[4 + j] = kw[2 + (j >> 1)].v[j & 1]; }
+                else { k[j] = (uint64_t)k0.v[j] | ((uint64_t)h0.v[j] << 32); k[4 + j] = (uint64_t)k1.v[j] | ((uint64_t)h1.v[j] << 32); }
+            } else { k[j] = k0.v[j]; k[4 + j] = k1.v[j]; }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) { slot[j] = slot_of(k[j]); cur[j] = lkey[slot[j]]; }     // eight probes in flight
@@ -452,7 +461,7 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
             VB vb[NV ? NV : 1];
             _Pragma("unroll") for (int a = 0; a < NV; ++a) vb[a] = static_cast<const VB*>(fv.col[a])[row];
             KT key;
-            if constexpr (K64) key = (uint64_t)keys[row] | ((uint64_t)keys_hi[row] << 32); else key = keys[row];
+            if constexpr (K64) key = keys_hi ? ((uint64_t)keys[row] | ((uint64_t)keys_hi[row] << 32)) : reinterpret_cast<const uint64_t*>(keys)[row]; else key = keys[row];
             to_table(key, vb);
         }
     }
@@ -641,7 +650,7 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
 
 // first row of every group, after the fact: tiles are scanned in order by a small grid; once every group has a candidate,
 // a workgroup stops as soon as its next tile starts beyond the largest candidate (no later row can lower any of them).
-__global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_hi, uint32_t n, GTable gt, const uint32_t* __restrict__ occ) {
+__global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_hi, int key8, uint32_t n, GTable gt, const uint32_t* __restrict__ occ) {
     __shared__ uint32_t red[4];
     __shared__ uint32_t stop;
     const uint32_t G = gt.flags[1];
@@ -671,7 +680,7 @@ __global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restr
         for (int r = 0; r < 16; ++r) {
             uint32_t row = tbase + r * 256 + threadIdx.x;
             if (row < n) {
-                uint32_t s = gt_find(gt, keys_hi ? ((uint64_t)keys[row] | ((uint64_t)keys_hi[row] << 32)) : (uint64_t)keys[row]);
+                uint32_t s = gt_find(gt, key8 ? reinterpret_cast<const uint64_t*>(keys)[row] : keys_hi ? ((uint64_t)keys[row] | ((uint64_t)keys_hi[row] << 32)) : (uint64_t)keys[row]);
                 if (s != FAIL && row < *gt.first_p(s)) {
                     uint32_t old = atomicMin(gt.first_p(s), row);
                     if (old >= OCCUPIED) atomicAdd(&gt.flags[2], 1u);
@@ -1249,7 +1258,9 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     // fast path eligibility: LDS mode, one 4-byte integer key, 1..3 four-byte value columns, plain additive accumulators
     // (also the first pass of aqg_groupby_build: no accumulators, only the distinct keys)
     auto key32 = [&](int j) { return (ks.dt[j] == AQG_INT32 || ks.dt[j] == AQG_UINT32) && ((uintptr_t)ks.col[j] & 15) == 0; };
-    const bool fast_k64 = ks.nkeys == 2 && !ks.wide && ks.total_bytes == 8 && key32(0) && key32(1);
+    // two 4-byte key columns, or one 8-byte key column whose bits are the packed key
+    const bool fast_key8 = ks.nkeys == 1 && !ks.wide && (ks.dt[0] == AQG_INT64 || ks.dt[0] == AQG_UINT64) && ((uintptr_t)ks.col[0] & 15) == 0 && getenv("AQG_DISABLE_FAST64") == nullptr;
+    const bool fast_k64 = (ks.nkeys == 2 && !ks.wide && ks.total_bytes == 8 && key32(0) && key32(1)) || fast_key8;
     bool fast = use_lds && !plan.sj && !big_lds && ((k32 && key32(0)) || fast_k64) && n >= 8 && (as.nacc >= 1 || plan.need_count || for_build) && as.nacc <= 4;
     FastVals fv;
     memset(&fv, 0, sizeof fv);
@@ -1281,7 +1292,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         unsigned bpc = lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : 2;
         unsigned grid = aqg_grid(ctx, n / 8 + 1, 256, 2, bpc);
         // (more workgroups than fit the chip cost more in table merges than they gain: 8192 -> +3 %, 32768 -> +30 % on Q1)
-        const uint32_t* khi = fast_k64 ? static_cast<const uint32_t*>(ks.col[1]) : nullptr;
+        const uint32_t* khi = fast_k64 && !fast_key8 ? static_cast<const uint32_t*>(ks.col[1]) : nullptr;
         auto launch = [&](auto kern) -> int {
             AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             aqg_kernel_timer_begin(ctx);
@@ -1366,7 +1377,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (G && n && fast) {
         unsigned fgrid = aqg_grid(ctx, n / 16 + 1, 256, 1, 1);
         hipLaunchKernelGGL(first_rows_kernel, dim3(fgrid), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(ks.col[0]),
-                           fast_k64 ? static_cast<const uint32_t*>(ks.col[1]) : (const uint32_t*)nullptr, n, gt, (const uint32_t*)occ);
+                           fast_k64 && !fast_key8 ? static_cast<const uint32_t*>(ks.col[1]) : (const uint32_t*)nullptr, fast_key8 ? 1 : 0, n, gt, (const uint32_t*)occ);
         AQG_TRY(aqg_check_launch(ctx, "first_rows_kernel"));
     }
     if (G) {

@@ -160,7 +160,7 @@ def test_dense_domain_sampled_ranges_miss_and_recover(gpu, oracle):
 
 @pytest.mark.parametrize("n", [77, 1_000_003])
 def test_fast_kernel_8_byte_value_columns(gpu, oracle, n):
-    """one or two 4-byte keys with 1..4 accumulators over 8-byte columns (agg32_kernel<.., VW = 8>): doubles, int64 sums that
+    """one or two 4-byte keys (or one 8-byte key) with 1..4 accumulators over 8-byte columns (agg32_kernel<.., VW = 8>): doubles, int64 sums that
     need all 128 bits of the reference's __int128 (two 64-bit half sums), order-preserving MIN / MAX of negative int64"""
     rng = np.random.default_rng(5 + n)
     f64 = np.round(rng.uniform(-1e6, 1e6, n), 3)
@@ -168,9 +168,16 @@ def test_fast_kernel_8_byte_value_columns(gpu, oracle, n):
     u64 = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
     shapes = [(["sum"], [f64]), (["avg"], [f64]), (["min", "max"], [f64, f64]), (["var"], [f64]), (["sum"], [i64]), (["sum"], [u64]),
               (["min", "max"], [i64, u64]), (["sum", "avg"], [i64, f64]), (["sum", "count", "max"], [f64, f64, i64]), (["avg", "avg", "sum"], [f64, -f64, u64])]
-    for keys in ([rng.integers(-40, 40, n).astype(np.int32)], [rng.integers(0, 9, n).astype(np.int32), rng.integers(0, 7, n).astype(np.uint32) * np.uint32(600_000_000)]):
+    # one 8-byte key column takes the same kernel (its bits are the packed key): -1 is the table's empty mark, INT64_MIN and huge
+    # unsigned values exercise the hash of the high half
+    k64 = rng.integers(-3, 60, n).astype(np.int64) * 3_000_000_019
+    k64[k64 == -3 * 3_000_000_019] = -1
+    k64[k64 == -2 * 3_000_000_019] = np.iinfo(np.int64).min
+    ku64 = rng.integers(0, 50, n).astype(np.uint64) * np.uint64(368_934_881_474_191_032) + np.uint64(7)
+    for keys in ([rng.integers(-40, 40, n).astype(np.int32)], [rng.integers(0, 9, n).astype(np.int32), rng.integers(0, 7, n).astype(np.uint32) * np.uint32(600_000_000)],
+                 [k64], [ku64]):
         ogb = oracle.groupby(keys)
-        for names, vals in shapes:
+        for names, vals in shapes + [(["sum", "count"], [rand(rng, np.int32, n, small=True)] * 2)]:
             ops = [ck.RED_NAMES[nm] for nm in names]
             gb = gpu.groupby_agg(keys, ops, vals, hint=128)
             assert gb.ngroups == ogb["ngroups"]
