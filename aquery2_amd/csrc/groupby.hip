@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(BLOCK) agg_kernel(KeySpec ks, AccSpec as, GTab
 // Same LDS open-addressing idea as agg_kernel, pared down to what these shapes need: the slot is the packed key alone (4 or 8
 // bytes), eight rows per lane per step with all probes issued before the first compare, and NO first-row bookkeeping in the
 // loop -- first rows are recovered afterwards by first_rows_kernel, which stops as soon as every group has one (a few tiles on
-// h2o data).  vkind: 0 int32, 1 uint32, 2 float (VW = 4) or 3 int64, 4 uint64, 5 double (VW = 8: every value column is 8 bytes wide;
+// h2o data).  vkind: 0 int32, 1 uint32, 2 float (VW = 4) or 3 int64, 4 uint64, 5 double (VW = 8: some value column is 8 bytes wide;
 // an int64 sum is two accumulators over the same column, `part` 1 / 2 = its low / high half);
 // kind: ACC_ADD_I / ACC_ADD_F / ACC_MIN / ACC_MAX; square: accumulate x*x.
 // (The generic agg_kernel ran max(v1),min(v2) by id1 at 27 % of the HBM roofline and var(v1) at 18 %; this kernel does SUM at 75 %.)
@@ -298,6 +298,9 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
     auto operand = [&](int a, VB bits) -> uint64_t {
         if constexpr (VW == 8) {
             switch (fv.vkind[a]) {
+            case 0: return val_operand_t((int32_t)(uint32_t)bits, fv.kind[a], fv.square[a]);
+            case 1: return val_operand_t((uint32_t)bits, fv.kind[a], fv.square[a]);
+            case 2: return val_operand_t(__uint_as_float((uint32_t)bits), fv.kind[a], fv.square[a]);
             case 3: return val_operand_t((int64_t)bits, fv.kind[a], fv.square[a], fv.part[a]);
             case 4: return val_operand_t((uint64_t)bits, fv.kind[a], fv.square[a], fv.part[a]);
             default: return val_operand_t(__builtin_bit_cast(double, (uint64_t)bits), fv.kind[a], fv.square[a]);
@@ -323,19 +326,18 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
     wg_span(nchunk, c_lo, c_hi);               // one contiguous span of rows per workgroup
     for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
         const size_t base = (size_t)c * 8;
-        // K64 with keys_hi == nullptr: `keys` is ONE 8-byte column (its bits are the packed key); otherwise two 4-byte columns
+        // K64 with keys_hi == nullptr: `keys` is ONE 8-byte column (its bits are the packed key); otherwise two 4-byte columns.
+        // Either way four 16-byte loads into the same registers; only the way a key is put together differs.
         const bool key8 = K64 && keys_hi == nullptr;
-        pack<uint32_t, 4> k0, k1, h0, h1;
-        pack<uint64_t, 2> kw[K64 ? 4 : 1];
-        if (key8) {
-            _Pragma("unroll") for (int q = 0; q < (K64 ? 4 : 1); ++q) kw[q] = *reinterpret_cast<const pack<uint64_t, 2>*>(reinterpret_cast<const uint64_t*>(keys) + base + 2 * q);
-        } else {
-            k0 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base);
-            k1 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base + 4);
-            if constexpr (K64) {
-                h0 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys_hi + base);
-                h1 = *reinterpret_cast<const pack<uint32_t, 4>*>(keys_hi + base + 4);
+        pack<uint32_t, 4> kq[K64 ? 4 : 2];
+        if constexpr (K64) {
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {
+                const uint32_t* src = key8 ? keys + 2 * base + 4 * q : (q < 2 ? keys + base + 4 * q : keys_hi + base + 4 * (q - 2));
+                kq[q] = *reinterpret_cast<const pack<uint32_t, 4>*>(src);
             }
+        } else {
+            kq[0] = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base);
+            kq[1] = *reinterpret_cast<const pack<uint32_t, 4>*>(keys + base + 4);
         }
         pack<uint32_t, 4> v0[NV ? NV : 1], v1[NV ? NV : 1];
         pack<uint64_t, 2> w[VW == 8 && NV ? NV : 1][4];
@@ -343,23 +345,31 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
             if constexpr (VW == 8) {
                 if (a > 0 && fv.col[a] == fv.col[a - 1]) {   // both halves of an int64 sum (or sum and sum of squares) read one column
                     _Pragma("unroll") for (int q = 0; q < 4; ++q) w[a][q] = w[a - 1][q];
-                } else {
+                } else if (fv.vkind[a] >= 3) {
                     _Pragma("unroll") for (int q = 0; q < 4; ++q) w[a][q] = *reinterpret_cast<const pack<uint64_t, 2>*>(static_cast<const uint64_t*>(fv.col[a]) + base + 2 * q);
+                } else {                                     // a 4-byte column beside 8-byte ones: eight rows in the first two register pairs
+                    _Pragma("unroll") for (int q = 0; q < 2; ++q) w[a][q] = *reinterpret_cast<const pack<uint64_t, 2>*>(static_cast<const uint32_t*>(fv.col[a]) + base + 4 * q);
                 }
             } else {
                 v0[a] = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(fv.col[a]) + base);
                 v1[a] = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(fv.col[a]) + base + 4);
             }
         }
-        auto raw = [&](int a, int j) -> VB { if constexpr (VW == 8) return w[a][j >> 1].v[j & 1]; else return j < 4 ? v0[a].v[j] : v1[a].v[j - 4]; };
+        auto raw = [&](int a, int j) -> VB {
+            if constexpr (VW == 8) {
+                if (fv.vkind[a] >= 3) return w[a][j >> 1].v[j & 1];
+                return (w[a][j >> 2].v[(j >> 1) & 1] >> (32 * (j & 1))) & 0xFFFFFFFFull;
+            } else return j < 4 ? v0[a].v[j] : v1[a].v[j - 4];
+        };
         KT k[8], cur[8];
         uint32_t slot[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
             if constexpr (K64) {
-                if (key8) { k[j] = kw[j >> 1].v[j & 1]; k[4 + j] = kw[2 + (j >> 1)].v[j & 1]; }
-                else { k[j] = (uint64_t)k0.v[j] | ((uint64_t)h0.v[j] << 32); k[4 + j] = (uint64_t)k1.v[j] | ((uint64_t)h1.v[j] << 32); }
-            } else { k[j] = k0.v[j]; k[4 + j] = k1.v[j]; }
+                const uint32_t lo = key8 ? kq[j >> 1].v[2 * (j & 1)] : kq[j >> 2].v[j & 3];
+                const uint32_t hi = key8 ? kq[j >> 1].v[2 * (j & 1) + 1] : kq[2 + (j >> 2)].v[j & 3];
+                k[j] = (uint64_t)lo | ((uint64_t)hi << 32);
+            } else k[j] = kq[j >> 2].v[j & 3];
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) { slot[j] = slot_of(k[j]); cur[j] = lkey[slot[j]]; }     // eight probes in flight
@@ -372,13 +382,39 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
         _Pragma("unroll") for (int a = 0; a < NV; ++a) {
             uint64_t* la = lacc + (size_t)a * LT;
             if constexpr (VW == 8) {
-                if (fv.kind[a] == ACC_ADD_F && !fv.square[a]) {        // sum / avg of a double column
+                if (fv.kind[a] == ACC_ADD_F && !fv.square[a] && fv.vkind[a] == 5) {        // sum / avg of a double column
 #pragma unroll
                     for (int j = 0; j < 8; ++j) if (slot[j] != FAIL) atomicAdd(reinterpret_cast<double*>(&la[slot[j]]), __builtin_bit_cast(double, (uint64_t)raw(a, j)));
                 } else {
                     uint64_t o[8];
+                    auto raw64 = [&](int j) -> uint64_t { return w[a][j >> 1].v[j & 1]; };
+                    auto raw32 = [&](int j) -> uint32_t { return (uint32_t)(w[a][j >> 2].v[(j >> 1) & 1] >> (32 * (j & 1))); };
+                    switch (fv.vkind[a]) {      // the dtype switch outside the eight rows
+                    case 0:
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = operand(a, raw(a, j));
+                        for (int j = 0; j < 8; ++j) o[j] = val_operand_t((int32_t)raw32(j), fv.kind[a], fv.square[a]);
+                        break;
+                    case 1:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = val_operand_t(raw32(j), fv.kind[a], fv.square[a]);
+                        break;
+                    case 2:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = val_operand_t(__uint_as_float(raw32(j)), fv.kind[a], fv.square[a]);
+                        break;
+                    case 3:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = val_operand_t((int64_t)raw64(j), fv.kind[a], fv.square[a], fv.part[a]);
+                        break;
+                    case 4:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = val_operand_t(raw64(j), fv.kind[a], fv.square[a], fv.part[a]);
+                        break;
+                    default:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = val_operand_t(__builtin_bit_cast(double, raw64(j)), fv.kind[a], fv.square[a]);
+                        break;
+                    }
                     switch (fv.kind[a]) {
                     case ACC_ADD_I:
 #pragma unroll
@@ -459,7 +495,9 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
         uint32_t row = (nchunk << 3) + threadIdx.x;
         if (row < n) {
             VB vb[NV ? NV : 1];
-            _Pragma("unroll") for (int a = 0; a < NV; ++a) vb[a] = static_cast<const VB*>(fv.col[a])[row];
+            _Pragma("unroll") for (int a = 0; a < NV; ++a) {
+                if (VW == 8 && fv.vkind[a] < 3) vb[a] = static_cast<const uint32_t*>(fv.col[a])[row]; else vb[a] = static_cast<const VB*>(fv.col[a])[row];
+            }
             KT key;
             if constexpr (K64) key = keys_hi ? ((uint64_t)keys[row] | ((uint64_t)keys_hi[row] << 32)) : reinterpret_cast<const uint64_t*>(keys)[row]; else key = keys[row];
             to_table(key, vb);
@@ -1264,14 +1302,17 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     bool fast = use_lds && !plan.sj && !big_lds && ((k32 && key32(0)) || fast_k64) && n >= 8 && (as.nacc >= 1 || plan.need_count || for_build) && as.nacc <= 4;
     FastVals fv;
     memset(&fv, 0, sizeof fv);
-    // value columns: all 4 bytes wide, or all 8 bytes wide (an int64 sum takes two accumulators)
+    // value columns: 4 bytes wide, or 4 and 8 bytes wide (an int64 sum takes two accumulators)
     auto wide_dt = [](int dt) { return dt == AQG_INT64 || dt == AQG_UINT64 || dt == AQG_DOUBLE; };
-    const bool fast_v8 = as.nacc >= 1 && as.nacc <= 4 && wide_dt(as.dt[0]) && getenv("AQG_DISABLE_FAST64") == nullptr;
+    auto narrow_dt = [](int dt) { return dt == AQG_INT32 || dt == AQG_UINT32 || dt == AQG_FLOAT; };
+    bool fast_v8 = false;                       // some value column is 8 bytes wide: the VW = 8 instantiation (it takes 4-byte ones, too)
+    for (int a = 0; a < as.nacc; ++a) fast_v8 = fast_v8 || wide_dt(as.dt[a]);
+    fast_v8 = fast_v8 && getenv("AQG_DISABLE_FAST64") == nullptr;
     for (int a = 0; a < as.nacc && fast; ++a) {
         const int dt = as.dt[a];
         if ((uintptr_t)as.col[a] & 15) fast = false;
-        if (fast_v8) { if (!wide_dt(dt)) fast = false; }
-        else if (as.part[a] || !(dt == AQG_INT32 || dt == AQG_UINT32 || dt == AQG_FLOAT)) fast = false;
+        if (fast_v8) { if (!wide_dt(dt) && !narrow_dt(dt)) fast = false; }
+        else if (as.part[a] || !narrow_dt(dt)) fast = false;
         fv.col[a] = as.col[a];
         fv.vkind[a] = dt == AQG_INT32 ? 0 : dt == AQG_UINT32 ? 1 : dt == AQG_FLOAT ? 2 : dt == AQG_INT64 ? 3 : dt == AQG_UINT64 ? 4 : 5;
         fv.kind[a] = as.kind[a];

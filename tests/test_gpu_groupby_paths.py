@@ -166,8 +166,13 @@ def test_fast_kernel_8_byte_value_columns(gpu, oracle, n):
     f64 = np.round(rng.uniform(-1e6, 1e6, n), 3)
     i64 = rng.integers(-(1 << 62), 1 << 62, n, dtype=np.int64)
     u64 = rng.integers(0, 1 << 63, n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)
+    i32 = rand(rng, np.int32, n, small=True)
+    u32 = rng.integers(0, 1 << 32, n, dtype=np.uint32)
+    f32 = np.round(rng.uniform(0, 100, n), 6).astype(np.float32)
     shapes = [(["sum"], [f64]), (["avg"], [f64]), (["min", "max"], [f64, f64]), (["var"], [f64]), (["sum"], [i64]), (["sum"], [u64]),
-              (["min", "max"], [i64, u64]), (["sum", "avg"], [i64, f64]), (["sum", "count", "max"], [f64, f64, i64]), (["avg", "avg", "sum"], [f64, -f64, u64])]
+              (["min", "max"], [i64, u64]), (["sum", "avg"], [i64, f64]), (["sum", "count", "max"], [f64, f64, i64]), (["avg", "avg", "sum"], [f64, -f64, u64]),
+              # 4-byte columns beside 8-byte ones
+              (["sum", "avg"], [i32, f64]), (["sum", "sum", "max"], [f32, i64, u32]), (["min", "var"], [u32, f64]), (["avg", "max", "min", "sum"], [i32, f64, f32, f64])]
     # one 8-byte key column takes the same kernel (its bits are the packed key): -1 is the table's empty mark, INT64_MIN and huge
     # unsigned values exercise the hash of the high half
     k64 = rng.integers(-3, 60, n).astype(np.int64) * 3_000_000_019
