@@ -770,7 +770,15 @@ int aqg_scan(aqg_ctx* ctx, int op, int t, const void* xv, uint32_t n, uint32_t w
         using T = typename decltype(tt)::type;
         const T* x = static_cast<const T*>(xv);
         const uint32_t ntiles = aqg_ceil_div(n, TS);
-        unsigned sgrid = aqg_grid(ctx, n, SB, 4, 16);
+        // shifts: an exact grid, ONE 16-byte vector per lane and workgroup (1e9 rows: deltas 1.59 -> 1.25 ms against a capped
+        // grid-stride launch; 4 / 8 / 16 / 32 / 64 vectors per lane: 1.37 / 1.45 / 1.44 / 1.51 / 1.48 ms)
+        auto shift_grid = [&](size_t out_size, unsigned per = 1) -> unsigned {
+            const size_t v = 16 / (sizeof(T) > out_size ? sizeof(T) : out_size);        // elements per vector, as in shift_kernel
+            const uint64_t nv = ((uint64_t)n / v + 63) & ~63ull;
+            const uint64_t g = (nv + (uint64_t)SB * per - 1) / ((uint64_t)SB * per);
+            return (unsigned)(g < 1 ? 1 : g);
+        };
+        const unsigned sgrid = shift_grid(sizeof(T));
         switch (op) {
         case AQG_SCAN_SUMS: return run_prefix<T, sum_alg<T>, W_SUMS>(ctx, x, n, out);
         case AQG_SCAN_AVGS: return run_prefix<T, sum_alg<T>, W_AVGS>(ctx, x, n, out);
@@ -784,7 +792,7 @@ int aqg_scan(aqg_ctx* ctx, int op, int t, const void* xv, uint32_t n, uint32_t w
             uint32_t len = n, ww = w;
             if (n <= ww) len = 1;
             ww = ww > len ? len : ww;
-            hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_RATIOW>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, ww, out);
+            hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_RATIOW>), dim3(shift_grid(sizeof(T) == 4 ? 4 : 8, 4)), dim3(SB), 0, ctx->stream, x, n, ww, out);   // (one vector per lane: 1.59 ms, four: 1.43 ms)
             return aqg_check_launch(ctx, "ratiow");
         }
         case AQG_SCAN_SUMW: case AQG_SCAN_AVGW: case AQG_SCAN_VARW: case AQG_SCAN_STDDEVW: {
