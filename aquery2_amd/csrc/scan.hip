@@ -784,15 +784,17 @@ int aqg_scan(aqg_ctx* ctx, int op, int t, const void* xv, uint32_t n, uint32_t w
         case AQG_SCAN_AVGS: return run_prefix<T, sum_alg<T>, W_AVGS>(ctx, x, n, out);
         case AQG_SCAN_MINS: return run_prefix<T, min_alg<T>, W_MINS>(ctx, x, n, out);
         case AQG_SCAN_MAXS: return run_prefix<T, max_alg<T>, W_MAXS>(ctx, x, n, out);
-        case AQG_SCAN_DELTAS: hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_DELTAS>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, w, out); return aqg_check_launch(ctx, "deltas");
-        case AQG_SCAN_PREV: hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_PREV>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, w, out); return aqg_check_launch(ctx, "prev");
-        case AQG_SCAN_NEXT: hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_NEXT>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, w, out); return aqg_check_launch(ctx, "aggnext");
+        case AQG_SCAN_DELTAS: aqg_kernel_timer_begin(ctx); hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_DELTAS>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, w, out); aqg_kernel_timer_end(ctx); return aqg_check_launch(ctx, "deltas");
+        case AQG_SCAN_PREV: aqg_kernel_timer_begin(ctx); hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_PREV>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, w, out); aqg_kernel_timer_end(ctx); return aqg_check_launch(ctx, "prev");
+        case AQG_SCAN_NEXT: aqg_kernel_timer_begin(ctx); hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_NEXT>), dim3(sgrid), dim3(SB), 0, ctx->stream, x, n, w, out); aqg_kernel_timer_end(ctx); return aqg_check_launch(ctx, "aggnext");
         case AQG_SCAN_RATIOW: {
             // aggregations.h:172-175: a window not smaller than the column degrades to w = 1
             uint32_t len = n, ww = w;
             if (n <= ww) len = 1;
             ww = ww > len ? len : ww;
+            aqg_kernel_timer_begin(ctx);
             hipLaunchKernelGGL((shift_kernel<T, AQG_SCAN_RATIOW>), dim3(shift_grid(sizeof(T) == 4 ? 4 : 8, 4)), dim3(SB), 0, ctx->stream, x, n, ww, out);   // (one vector per lane: 1.59 ms, four: 1.43 ms)
+            aqg_kernel_timer_end(ctx);
             return aqg_check_launch(ctx, "ratiow");
         }
         case AQG_SCAN_SUMW: case AQG_SCAN_AVGW: case AQG_SCAN_VARW: case AQG_SCAN_STDDEVW: {

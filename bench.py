@@ -191,7 +191,7 @@ def main():
                          # profiles/r1_bench_q1_1e9_pmc.md): 8.0255 GB read + 0.0121 GB written; scaled to this run's rows
                          # join: 12.001 GB read + 0.018 GB written (profiles/r1_groupby_join_1e9_pmc.md)
                          "traffic": (12.019e9 if join else 8.0376e9) * n / 1e9,
-                         "kernel": "starjoin_kernel" if join else "agg32_kernel<1,false>", "kernel_ms": k_ms, "algorithmic_bytes": bpr * n},
+                         "kernel": "starjoin_kernel" if join else "agg32_kernel<1,false,false,4>", "kernel_ms": k_ms, "algorithmic_bytes": bpr * n},
         }
         if world == 1 and args.cpu_sample > 0 and not join:
             line["cpu_baseline"] = cpu_baseline(int(args.cpu_sample))
