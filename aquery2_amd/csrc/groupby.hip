@@ -419,12 +419,13 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
 
 // first row of every group, after the fact: tiles are scanned in order by a small grid; once every group has a candidate,
 // a workgroup stops as soon as its next tile starts beyond the largest candidate (no later row can lower any of them).
-__global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_hi, int key8, uint32_t n, GTable gt, const uint32_t* __restrict__ occ) {
+__global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_hi, int key8, uint32_t t0 /* first tile */, uint32_t n /* rows end */, GTable gt, const uint32_t* __restrict__ occ) {
     __shared__ uint32_t red[4];
     __shared__ uint32_t stop;
     const uint32_t G = gt.flags[1];
-    constexpr uint32_t TILE = 256 * 16;
-    for (uint32_t t = blockIdx.x; (uint64_t)t * TILE < n; t += gridDim.x) {
+    constexpr int FR = 4;                      // rows per lane and tile: the first round covers gridDim x 1024 rows (16 rows: 28 us on h2o Q1)
+    constexpr uint32_t TILE = 256 * FR;
+    for (uint32_t t = t0 + blockIdx.x; (uint64_t)t * TILE < n; t += gridDim.x) {
         const uint32_t tbase = t * TILE;
         if (threadIdx.x == 0) stop = 0;
         __syncthreads();
@@ -446,7 +447,7 @@ __global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restr
             __syncthreads();
         }
         if (stop) break;
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; r < FR; ++r) {
             uint32_t row = tbase + r * 256 + threadIdx.x;
             if (row < n) {
                 uint32_t s = gt_find(gt, key8 ? reinterpret_cast<const uint64_t*>(keys)[row] : keys_hi ? ((uint64_t)keys[row] | ((uint64_t)keys_hi[row] << 32)) : (uint64_t)keys[row]);
@@ -611,8 +612,9 @@ __global__ void __launch_bounds__(256) emit_order_kernel(const uint32_t* __restr
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) order[gid_of_occ[i]] = i;
 }
 __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __restrict__ occ, const uint32_t* __restrict__ gid_of_occ, EmitSpec es,
-                                                   const uint32_t* __restrict__ order) {
+                                                   const uint32_t* __restrict__ order, uint32_t gmax /* 0: no bound; else give up beyond it (ranks were not computed) */) {
     uint32_t G = gt.flags[1];
+    if (gmax && G > gmax) return;
     for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < G; i0 += gridDim.x * blockDim.x) {
         const uint32_t i = order ? order[i0] : i0;
         uint32_t s = occ[i], g = gid_of_occ[i];
@@ -1114,20 +1116,39 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     unsigned cgrid = aqg_grid(ctx, slots, 256, 1, 8);
     if (!(n && use_part)) hipLaunchKernelGGL(collect_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, gt, occ);
     uint32_t fl[4] = {0, 0, 0, 0};                    // [0] overflow, [1] occupied slots, [3] a row outside the sampled key ranges
-    AQG_HIP(ctx, hipMemcpyAsync(fl, gt.flags, 16, hipMemcpyDeviceToHost, ctx->stream));
-    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (dense && fl[3]) { h->dense_exact = true; return AQG_ERR_RANGE_MISS; }
-    if (fl[0]) return AQG_ERR_OVERFLOW;
-    uint32_t G = fl[1];
-    if (small_rank && G > 4096) return AQG_ERR_OVERFLOW;
-    if (use_lds && G > lds_group_cap && G > hint) return AQG_ERR_OVERFLOW;   // correct but slow (overflow rows took the HBM path): re-plan
-    if (G && n && fast) {
-        unsigned fgrid = aqg_grid(ctx, n / 16 + 1, 256, 1, 1);
-        hipLaunchKernelGGL(first_rows_kernel, dim3(fgrid), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(ks.col[0]),
-                           fast_k64 && !fast_key8 ? static_cast<const uint32_t*>(ks.col[1]) : (const uint32_t*)nullptr, fast_key8 ? 1 : 0, n, gt, (const uint32_t*)occ);
+    uint32_t G = 0;
+    auto read_flags = [&]() -> int {
+        AQG_HIP(ctx, hipMemcpyAsync(fl, gt.flags, 16, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (dense && fl[3]) { h->dense_exact = true; return AQG_ERR_RANGE_MISS; }
+        if (fl[0]) return AQG_ERR_OVERFLOW;
+        G = fl[1];
+        if (small_rank && G > 4096) return AQG_ERR_OVERFLOW;
+        if (use_lds && G > lds_group_cap && G > hint) return AQG_ERR_OVERFLOW;   // correct but slow (overflow rows took the HBM path): re-plan
+        return AQG_OK;
+    };
+    // The fast kernel with a small table (h2o Q1 / Q4): every kernel of the tail reads the group count from the device flags and
+    // the outputs are sized by the table, so the host waits ONCE, at the end, instead of once here and once after emit (the
+    // round trip in the middle cost 26 us of a 1.45 ms step).  An overflow is then noticed after the tail has run on it: the
+    // kernels are bounded by the table and by `gmax`, the results are discarded and the call re-plans as before.
+    const bool defer = n && fast && small_rank && !dense && !use_part;
+    const uint32_t gupper = (uint32_t)(slots + 1 < 4096 ? slots + 1 : 4096);
+    if (!defer) AQG_TRY(read_flags());
+    if ((defer || G) && n && fast) {
+        // two launches: 32 workgroups over the first 32768 rows (where every group of an h2o-like column already shows up), then
+        // the whole chip over the rest, whose workgroups leave at once when nothing is missing.  One launch of 256 workgroups
+        // starts with 65536 lanes pushing atomicMin at ~100 addresses: 28-31 us on h2o Q1.
+        const uint32_t* k0 = static_cast<const uint32_t*>(ks.col[0]);
+        const uint32_t* k1 = fast_k64 && !fast_key8 ? static_cast<const uint32_t*>(ks.col[1]) : (const uint32_t*)nullptr;
+        const uint32_t head_tiles = 32, head_rows = head_tiles * 1024;
+        hipLaunchKernelGGL(first_rows_kernel, dim3(head_tiles), dim3(256), 0, ctx->stream, k0, k1, fast_key8 ? 1 : 0, 0u, n < head_rows ? n : head_rows, gt, (const uint32_t*)occ);
+        if (n > head_rows) {
+            unsigned fgrid = aqg_grid(ctx, (n - head_rows) / 4 + 1, 256, 1, 1);
+            hipLaunchKernelGGL(first_rows_kernel, dim3(fgrid), dim3(256), 0, ctx->stream, k0, k1, fast_key8 ? 1 : 0, head_tiles, n, gt, (const uint32_t*)occ);
+        }
         AQG_TRY(aqg_check_launch(ctx, "first_rows_kernel"));
     }
-    if (G) {
+    if (defer || G) {
         if (small_rank) {
             hipLaunchKernelGGL(rank_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, gt, occ, gid_of_occ, slot_gid);
         } else {
@@ -1139,9 +1160,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         }
     }
     // ---- outputs --------------------------------------------------------------------------------------
-    h->ngroups = G;
     h->nkeys = ks.nkeys;
-    size_t gcapn = G ? G : 1;
+    size_t gcapn = defer ? gupper : (G ? G : 1);
     EmitSpec es;
     memset(&es, 0, sizeof es);
     es.nkeys = ks.nkeys;
@@ -1171,16 +1191,18 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(dev_realloc(ctx, &h->results[j], &h->cap_results[j], gcapn * 16));
         es.agg[j].out = h->results[j];
     }
-    if (G) {
-        unsigned eg = aqg_grid(ctx, G, 256, 1, 8);
+    if (defer || G) {
+        unsigned eg = aqg_grid(ctx, defer ? gupper : G, 256, 1, 8);
         uint32_t* order = nullptr;
         if (ordered_emit && G >= (1u << 20)) {
             AQG_TRY(aqg_ws_get(ctx, slots, &order));
             hipLaunchKernelGGL(emit_order_kernel, dim3(eg), dim3(256), 0, ctx->stream, (const uint32_t*)gid_of_occ, G, order);
         }
-        hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt, occ, gid_of_occ, es, (const uint32_t*)order);
+        hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt, occ, gid_of_occ, es, (const uint32_t*)order, defer ? 4096u : 0u);
         AQG_TRY(aqg_check_launch(ctx, "emit_kernel"));
     }
+    if (defer) AQG_TRY(read_flags());
+    h->ngroups = G;
     if (gt_out) *gt_out = gt;
     if (dense_out) { dense_out->used = dense; if (dense) dense_out->spec = dspec; }
     if (slot_gid_out) *slot_gid_out = slot_gid;
