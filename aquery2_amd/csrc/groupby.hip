@@ -1127,11 +1127,11 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         if (use_lds && G > lds_group_cap && G > hint) return AQG_ERR_OVERFLOW;   // correct but slow (overflow rows took the HBM path): re-plan
         return AQG_OK;
     };
-    // The fast kernel with a small table (h2o Q1 / Q4): every kernel of the tail reads the group count from the device flags and
+    // The fast kernel or the fused star join with a small table (h2o Q1 / Q4, config 4): every kernel of the tail reads the group count from the device flags and
     // the outputs are sized by the table, so the host waits ONCE, at the end, instead of once here and once after emit (the
     // round trip in the middle cost 26 us of a 1.45 ms step).  An overflow is then noticed after the tail has run on it: the
     // kernels are bounded by the table and by `gmax`, the results are discarded and the call re-plans as before.
-    const bool defer = n && fast && small_rank && !dense && !use_part;
+    const bool defer = n && (fast || plan.sj) && small_rank && !dense && !use_part;
     const uint32_t gupper = (uint32_t)(slots + 1 < 4096 ? slots + 1 : 4096);
     if (!defer) AQG_TRY(read_flags());
     if ((defer || G) && n && fast) {
