@@ -27,6 +27,7 @@ struct aqg_ctx {
     hipEvent_t evk0 = nullptr, evk1 = nullptr;   // bracket the dominant kernel of the last call
     bool evk_valid = false;
     std::unordered_map<const void*, aqg_pin> pins;
+    std::unordered_map<const void*, int> max_lds;   // largest dynamic LDS size already granted per kernel (aqg_allow_lds)
     // pinned host staging for small results
     void* host_stage = nullptr;
     size_t host_stage_cap = 0;
@@ -87,6 +88,15 @@ static inline int aqg_check_launch(aqg_ctx* ctx, const char* what) {
 
 // grid sizing for memory-bound grid-stride kernels: enough blocks to fill 256 CUs,
 // capped (guide: Guideline 11)
+// hipFuncAttributeMaxDynamicSharedMemorySize once per kernel and size, not on every launch (a few microseconds of host time each)
+static inline int aqg_allow_lds(aqg_ctx* ctx, const void* kernel, size_t lds) {
+    auto it = ctx->max_lds.find(kernel);
+    if (it != ctx->max_lds.end() && (size_t)it->second >= lds) return AQG_OK;
+    AQG_HIP(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ctx->max_lds[kernel] = (int)lds;
+    return AQG_OK;
+}
+
 static inline unsigned aqg_grid(const aqg_ctx* ctx, uint64_t work_items, unsigned block, unsigned items_per_thread,
                                 unsigned blocks_per_cu = 8) {
     uint64_t per_block = (uint64_t)block * items_per_thread;

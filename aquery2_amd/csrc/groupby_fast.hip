@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
 int aqg_fast_aggregate(aqg_ctx* ctx, const uint32_t* keys, const uint32_t* keys_hi, bool k64, bool v8, int nacc, bool need_count,
                        const FastVals& fv, GTable gt, uint32_t n, uint32_t lcap, size_t lds, unsigned grid) {
     auto launch = [&](auto kern) -> int {
-        AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
         aqg_kernel_timer_begin(ctx);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, keys, keys_hi, fv, gt, n, lcap);
         aqg_kernel_timer_end(ctx);
