@@ -797,10 +797,21 @@ __global__ void __launch_bounds__(256) pack_kernel(const void* __restrict__ keys
 }
 // unpack the gathered payloads of `world` shards into one key column and one value column, shards in rank order
 __global__ void __launch_bounds__(256) unpack_kernel(const long long* __restrict__ gathered, uint32_t world, uint32_t gmax, int key_dt,
-                                                     void* __restrict__ keys, long long* __restrict__ vals) {
+                                                     void* __restrict__ keys, long long* __restrict__ vals, uint32_t* __restrict__ total_out /* [0] rows, [1] bad header */) {
     __shared__ uint32_t off[65];
-    if (threadIdx.x == 0) { uint32_t o = 0; for (uint32_t r = 0; r < world; ++r) { off[r] = o; o += (uint32_t)gathered[(size_t)r * (gmax + 1) * 2]; } off[world] = o; }
+    if (threadIdx.x == 0) {
+        uint32_t o = 0, bad = 0;
+        for (uint32_t r = 0; r < world; ++r) {
+            const long long c = gathered[(size_t)r * (gmax + 1) * 2];
+            if (c < 0 || c > (long long)gmax) bad = 1;
+            off[r] = o;
+            o += bad ? 0u : (uint32_t)c;
+        }
+        off[world] = o;
+        if (blockIdx.x == 0) { total_out[0] = o; total_out[1] = bad; }
+    }
     __syncthreads();
+    if (off[world] > world * gmax) return;
     for (uint32_t r = blockIdx.x; r < world; r += gridDim.x) {
         const long long* src = gathered + (size_t)r * (gmax + 1) * 2;
         const uint32_t cnt = off[r + 1] - off[r];
@@ -816,6 +827,90 @@ __global__ void __launch_bounds__(256) unpack_kernel(const long long* __restrict
             vals[d] = src[3 + 2 * i];
         }
     }
+}
+
+
+// The whole merge of a few shard tables in ONE workgroup (world x gmax <= 2048 rows: h2o Q1 on 8 GPUs is 8 x 100): concatenate in
+// rank order, group in an LDS table, rank the groups by first occurrence, write keys / aggregates / first rows.  One launch and one
+// 8-byte copy instead of the generic group-by's ten launches (the merge cost 0.13 ms of a 1.55 ms step).
+// SUM adds sign-extended int64 partials into 128 bits with two atomics (the carry out of the low word is exact under any order).
+constexpr uint32_t MERGE_ROWS = 2048, MERGE_CAP = 4096;
+constexpr unsigned long long MERGE_EMPTY = 0x8000000000000001ull;
+__global__ void __launch_bounds__(1024) merge_small_kernel(const long long* __restrict__ gathered, uint32_t world, uint32_t gmax, int key_dt, int op,
+                                                           void* __restrict__ keys_out, void* __restrict__ res_out, uint32_t* __restrict__ first_out,
+                                                           uint32_t* __restrict__ info /* [0] groups, [1] bad header, [2] rows */) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    unsigned long long* tkey = reinterpret_cast<unsigned long long*>(smem_raw);            // [MERGE_CAP + 1] (last: the key equal to the empty mark)
+    unsigned long long* tlo = tkey + MERGE_CAP + 1;                                        // [MERGE_CAP + 1]
+    unsigned long long* thi = tlo + MERGE_CAP + 1;                                         // [MERGE_CAP + 1]
+    uint32_t* tfirst = reinterpret_cast<uint32_t*>(thi + MERGE_CAP + 1);                   // [MERGE_CAP + 1]
+    uint32_t* occ = tfirst + MERGE_CAP + 1;                                                // [MERGE_ROWS] occupied slots
+    __shared__ uint32_t off[65];
+    __shared__ uint32_t s_bad, s_g;
+    if (threadIdx.x == 0) {
+        uint32_t o = 0, bad = 0;
+        for (uint32_t r = 0; r < world; ++r) {
+            const long long c = gathered[(size_t)r * (gmax + 1) * 2];
+            if (c < 0 || c > (long long)gmax) bad = 1;
+            off[r] = o;
+            o += bad ? 0u : (uint32_t)c;
+        }
+        off[world] = o;
+        s_bad = bad; s_g = 0;
+    }
+    const unsigned long long init = op == AQG_RED_MIN ? 0x7FFFFFFFFFFFFFFFull : op == AQG_RED_MAX ? 0x8000000000000000ull : 0ull;
+    for (uint32_t t = threadIdx.x; t <= MERGE_CAP; t += blockDim.x) { tkey[t] = MERGE_EMPTY; tlo[t] = init; thi[t] = 0; tfirst[t] = 0xFFFFFFFFu; }
+    __syncthreads();
+    const uint32_t total = off[world];
+    for (uint32_t i = threadIdx.x; i < total && !s_bad; i += blockDim.x) {
+        uint32_t r = 0;
+        while (i >= off[r + 1]) ++r;                                   // world <= 64
+        const long long* src = gathered + (size_t)r * (gmax + 1) * 2 + 2 + 2 * (size_t)(i - off[r]);
+        const unsigned long long key = (unsigned long long)src[0];
+        const long long val = src[1];
+        uint32_t slot = MERGE_CAP;                                     // the key that equals the empty mark lives in the extra slot
+        if (key != MERGE_EMPTY) {
+            slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 52);    // top 12 bits: MERGE_CAP slots
+            while (true) {
+                const unsigned long long cur = tkey[slot];
+                if (cur == key) break;
+                if (cur == MERGE_EMPTY) {
+                    const unsigned long long old = atomicCAS(&tkey[slot], MERGE_EMPTY, key);
+                    if (old == MERGE_EMPTY || old == key) break;
+                }
+                slot = (slot + 1) & (MERGE_CAP - 1);                   // at most MERGE_ROWS keys in MERGE_CAP slots: always ends
+            }
+        }
+        atomicMin(&tfirst[slot], i);
+        if (op == AQG_RED_MIN) atomicMin(reinterpret_cast<long long*>(&tlo[slot]), val);
+        else if (op == AQG_RED_MAX) atomicMax(reinterpret_cast<long long*>(&tlo[slot]), val);
+        else {
+            const unsigned long long old = atomicAdd(&tlo[slot], (unsigned long long)val);
+            const unsigned long long carry = old + (unsigned long long)val < old ? 1ull : 0ull;
+            const unsigned long long hi_add = (val < 0 ? ~0ull : 0ull) + carry;
+            if (hi_add) atomicAdd(&thi[slot], hi_add);
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t <= MERGE_CAP; t += blockDim.x) if (tfirst[t] != 0xFFFFFFFFu) occ[atomicAdd(&s_g, 1u)] = t;
+    __syncthreads();
+    const uint32_t G = s_g;
+    for (uint32_t e = threadIdx.x; e < G; e += blockDim.x) {
+        const uint32_t slot = occ[e], mine = tfirst[slot];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < G; ++j) rank += tfirst[occ[j]] < mine;      // first occurrences are distinct rows
+        const unsigned long long key = slot == MERGE_CAP ? MERGE_EMPTY : tkey[slot];
+        switch (aqg_dtype_size_dev(key_dt)) {
+        case 1: static_cast<uint8_t*>(keys_out)[rank] = (uint8_t)key; break;
+        case 2: static_cast<uint16_t*>(keys_out)[rank] = (uint16_t)key; break;
+        case 4: static_cast<uint32_t*>(keys_out)[rank] = (uint32_t)key; break;
+        default: static_cast<unsigned long long*>(keys_out)[rank] = key; break;
+        }
+        first_out[rank] = mine;
+        if (op == AQG_RED_MIN || op == AQG_RED_MAX) static_cast<unsigned long long*>(res_out)[rank] = tlo[slot];
+        else { static_cast<aqg_i128*>(res_out)[rank] = aqg_i128{tlo[slot], thi[slot]}; }
+    }
+    if (threadIdx.x == 0) { info[0] = s_bad ? 0u : G; info[1] = s_bad; info[2] = total; }
 }
 
 } // namespace
@@ -1354,20 +1449,63 @@ int aqg_groupby_pack(aqg_groupby* g, int agg_index, uint32_t gmax, int64_t* out_
 int aqg_groupby_merge_packed(aqg_ctx* ctx, const int64_t* gathered_dev, uint32_t world, uint32_t gmax, int key_dtype, int op, aqg_groupby** out) {
     if (!ctx || !gathered_dev || !out || world == 0 || world > 64) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_merge_packed: bad argument (1..64 shards)");
     if (!(op == AQG_RED_SUM || op == AQG_RED_MIN || op == AQG_RED_MAX || op == AQG_RED_COUNT)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_merge_packed: SUM / COUNT / MIN / MAX");
-    // the shards' group counts (one small copy), then the concatenation and a plain group-by over it
-    long long cnt[64];
-    for (uint32_t r = 0; r < world; ++r)
-        AQG_HIP(ctx, hipMemcpyAsync(&cnt[r], gathered_dev + (size_t)r * (gmax + 1) * 2, 8, hipMemcpyDeviceToHost, ctx->stream));
-    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    uint64_t total = 0;
-    for (uint32_t r = 0; r < world; ++r) { if (cnt[r] < 0 || (uint64_t)cnt[r] > gmax) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_merge_packed: corrupt shard header"); total += (uint64_t)cnt[r]; }
+    // the concatenation (offsets from the shard headers, on the device) and a plain group-by over it; the host learns the row
+    // count from ONE small copy (it used to fetch every shard header: `world` copies and their latency in front of the merge)
+    const uint64_t cap_rows = (uint64_t)world * gmax;
+    if (cap_rows > AQG_MAX_ROWS) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_merge_packed: world x gmax too large");
     aqg_groupby* h = *out ? *out : new aqg_groupby();
     h->ctx = ctx;
-    int rc = dev_realloc(ctx, &h->xkeys, &h->cap_xkeys, (total + 1) * 8);
-    if (rc == AQG_OK) rc = dev_realloc(ctx, &h->xvals, &h->cap_xvals, (total + 1) * 8);
+    const bool int_key = key_dtype == AQG_INT8 || key_dtype == AQG_INT16 || key_dtype == AQG_INT32 || key_dtype == AQG_INT64 || key_dtype == AQG_UINT8 ||
+                         key_dtype == AQG_UINT16 || key_dtype == AQG_UINT32 || key_dtype == AQG_UINT64 || key_dtype == AQG_BOOL;
+    if (cap_rows <= MERGE_ROWS && int_key && getenv("AQG_DISABLE_SMALL_MERGE") == nullptr) {
+        // ---- a few small shard tables: one workgroup does the whole merge ------------------------------------------------
+        const int mop = op == AQG_RED_COUNT ? AQG_RED_SUM : op;
+        int rc = AQG_OK;
+        if (h->cap_groups < MERGE_ROWS || !h->keys_out[0] || !h->first_rows || !h->counts) {
+            for (int k = 0; k < MAXKEYS; ++k) if (h->keys_out[k]) { hipFree(h->keys_out[k]); h->keys_out[k] = nullptr; }
+            if (h->first_rows) { hipFree(h->first_rows); h->first_rows = nullptr; }
+            if (h->counts) { hipFree(h->counts); h->counts = nullptr; }
+            size_t c = 0;
+            rc = dev_realloc(ctx, &h->keys_out[0], &c, (size_t)MERGE_ROWS * 8);
+            c = 0; if (rc == AQG_OK) rc = dev_realloc(ctx, (void**)&h->first_rows, &c, (size_t)MERGE_ROWS * 4);
+            c = 0; if (rc == AQG_OK) rc = dev_realloc(ctx, (void**)&h->counts, &c, (size_t)MERGE_ROWS * 4);
+            if (rc == AQG_OK) h->cap_groups = MERGE_ROWS;
+        }
+        if (rc == AQG_OK) rc = dev_realloc(ctx, &h->results[0], &h->cap_results[0], (size_t)MERGE_ROWS * 16);
+        if (rc == AQG_OK) rc = aqg_ws_reset(ctx);
+        if (rc == AQG_OK) rc = aqg_ws_ensure(ctx, 4096);
+        uint32_t* info = nullptr;
+        if (rc == AQG_OK) rc = aqg_ws_get(ctx, 4, &info);
+        if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
+        const size_t lds = (size_t)(MERGE_CAP + 1) * 28 + (size_t)MERGE_ROWS * 4 + 64;
+        rc = aqg_allow_lds(ctx, reinterpret_cast<const void*>(&merge_small_kernel), lds);
+        if (rc == AQG_OK) {
+            hipLaunchKernelGGL(merge_small_kernel, dim3(1), dim3(1024), lds, ctx->stream, reinterpret_cast<const long long*>(gathered_dev), world, gmax, key_dtype, mop,
+                               h->keys_out[0], h->results[0], h->first_rows, info);
+            rc = aqg_check_launch(ctx, "merge_small_kernel");
+        }
+        uint32_t ih[3] = {0, 0, 0};
+        if (rc == AQG_OK) rc = aqg_d2h(ctx, ih, info, 12);
+        if (rc == AQG_OK && ih[1]) rc = aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_merge_packed: corrupt shard header");
+        if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
+        h->n = ih[2]; h->ngroups = ih[0];
+        h->nkeys = 1; h->key_dt[0] = key_dtype;
+        h->has_counts = false; h->has_reversemap = false;
+        h->nagg = 1; h->res_dt[0] = aqg_reduce_out_dtype(mop, AQG_INT64);
+        *out = h;
+        return AQG_OK;
+    }
+    int rc = dev_realloc(ctx, &h->xkeys, &h->cap_xkeys, (cap_rows + 2) * 8);
+    if (rc == AQG_OK) rc = dev_realloc(ctx, &h->xvals, &h->cap_xvals, (cap_rows + 2) * 8);
     if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
-    if (total) hipLaunchKernelGGL(unpack_kernel, dim3(world), dim3(256), 0, ctx->stream, reinterpret_cast<const long long*>(gathered_dev), world, gmax, key_dtype, h->xkeys,
-                                  static_cast<long long*>(h->xvals));
+    uint32_t* total_dev = reinterpret_cast<uint32_t*>(static_cast<char*>(h->xvals) + (cap_rows + 1) * 8);     // the spare word behind the values
+    hipLaunchKernelGGL(unpack_kernel, dim3(world), dim3(256), 0, ctx->stream, reinterpret_cast<const long long*>(gathered_dev), world, gmax, key_dtype, h->xkeys,
+                       static_cast<long long*>(h->xvals), total_dev);
+    uint32_t th[2] = {0, 0};
+    rc = aqg_d2h(ctx, th, total_dev, 8);
+    if (rc == AQG_OK && th[1]) rc = aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_merge_packed: corrupt shard header");
+    if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
+    const uint64_t total = th[0];
     const void* kc[1] = {h->xkeys};
     const void* vc[1] = {h->xvals};
     const int mop = op == AQG_RED_COUNT ? AQG_RED_SUM : op, vdt = AQG_INT64;

@@ -200,29 +200,45 @@ def test_shard_exchange_pack_and_merge(gpu, oracle):
     buffer an all_gather would fill, merged by aqg_groupby_merge_packed == the group-by of the whole table"""
     import aquery2_amd
     rng = np.random.default_rng(81)
-    n, world, gmax = 900_001, 3, 64
-    key = rng.integers(-20, 21, n).astype(np.int32)
-    key[: n // 3] = rng.integers(0, 5, n // 3)                 # the first shard sees only a few of the keys
+    n, world = 900_001, 3
+    key32 = rng.integers(-20, 21, n).astype(np.int32)
+    key32[: n // 3] = rng.integers(0, 5, n // 3)                 # the first shard sees only a few of the keys
+    # 8-byte keys: -0x7FFFFFFFFFFFFFFF is the empty mark of the one-workgroup merge, -1 that of the device tables
+    lut = np.array([-0x7FFFFFFFFFFFFFFF, -1, 0, np.iinfo(np.int64).min, np.iinfo(np.int64).max] + [int(v) * 3_000_000_019 for v in range(-18, 18)], dtype=np.int64)
+    key64 = lut[key32.astype(np.int64) + 20]
     val = rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)
-    gathered = gpu.empty(world * (gmax + 1) * 2, np.int64)
     bounds = [0, n // 3, n // 3, n]                             # the second shard is EMPTY
-    for op in (ck.RED_SUM, ck.RED_MIN, ck.RED_MAX, ck.RED_COUNT):
-        for r in range(world):
-            lo, hi = bounds[r], bounds[r + 1]
-            gb = gpu.groupby_agg([key[lo:hi]], [op], [val[lo:hi]])
-            gpu.groupby_pack(gb, 0, gmax, gathered.ptr + r * (gmax + 1) * 2 * 8)
-            gb.destroy()
-        merged = gpu.groupby_merge_packed(gathered.ptr, world, gmax, ck.INT32, op)
+    # world x gmax <= 2048: one workgroup merges (merge_small_kernel); above: concatenation + the generic group-by
+    for key, tag, gmax in ((key32, ck.INT32, 64), (key32, ck.INT32, 1024), (key64, ck.INT64, 64)):
+        gathered = gpu.empty(world * (gmax + 1) * 2, np.int64)
         o = oracle.groupby([key])
-        assert merged.ngroups == o["ngroups"]
-        assert np.array_equal(merged.keys(0, np.int32), key[o["first_rows"]])            # global first-occurrence order
-        want = oracle.grouped_reduce(op, val, o)
-        got = merged.result(0, ck.RED_SUM if op == ck.RED_COUNT else op, ck.INT64)
-        if op in (ck.RED_SUM, ck.RED_COUNT):
-            assert ck.i128_to_int(got) == (ck.i128_to_int(want) if op == ck.RED_SUM else [int(c) for c in want])
-        else:
-            assert np.array_equal(got.astype(np.int64), want.astype(np.int64))
-        merged.destroy()
+        for op in (ck.RED_SUM, ck.RED_MIN, ck.RED_MAX, ck.RED_COUNT):
+            for r in range(world):
+                lo, hi = bounds[r], bounds[r + 1]
+                gb = gpu.groupby_agg([key[lo:hi]], [op], [val[lo:hi]])
+                gpu.groupby_pack(gb, 0, gmax, gathered.ptr + r * (gmax + 1) * 2 * 8)
+                gb.destroy()
+            merged = gpu.groupby_merge_packed(gathered.ptr, world, gmax, tag, op)
+            assert merged.ngroups == o["ngroups"]
+            assert np.array_equal(merged.keys(0, key.dtype), key[o["first_rows"]])            # global first-occurrence order
+            want = oracle.grouped_reduce(op, val, o)
+            got = merged.result(0, ck.RED_SUM if op == ck.RED_COUNT else op, ck.INT64)
+            if op in (ck.RED_SUM, ck.RED_COUNT):
+                assert ck.i128_to_int(got) == (ck.i128_to_int(want) if op == ck.RED_SUM else [int(c) for c in want]), (gmax, op)
+            else:
+                assert np.array_equal(got.astype(np.int64), want.astype(np.int64)), (gmax, op)
+            merged.destroy()
+        gathered.free()
+    # sums that need more than 64 bits: int64 partials near the limits, merged exactly into 128 bits
+    big = np.array([2**62, 2**62, 2**62, -2**62, 2**63 - 1, -2**63], dtype=np.int64)
+    gathered = gpu.empty(6 * 2 * 2, np.int64)
+    for r in range(6):
+        gb = gpu.groupby_agg([np.array([7], np.int32)], [ck.RED_MAX], [big[r:r + 1]])       # MAX of one row: the value itself
+        gpu.groupby_pack(gb, 0, 1, gathered.ptr + r * 2 * 2 * 8)
+        gb.destroy()
+    merged = gpu.groupby_merge_packed(gathered.ptr, 6, 1, ck.INT32, ck.RED_SUM)
+    assert merged.ngroups == 1 and ck.i128_to_int(merged.result(0, ck.RED_SUM, ck.INT64)) == [sum(int(v) for v in big)]
+    merged.destroy()
 
 
 def test_maximum_row_count(gpu):
