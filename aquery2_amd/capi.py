@@ -335,6 +335,29 @@ class Device:
         gb._ops = list(ops)
         return gb
 
+    def prepare_groupby_agg(self, keys, ops, vals, hint=0):
+        """the same call as groupby_agg with its argument arrays marshalled once: returns a function that runs it again on the
+        same device columns and handle (a prepared statement; the per-call Python work drops to one foreign call)"""
+        kd, dts, ptrs = self._keyargs(keys)
+        vd = [self._dev(v) if v is not None else None for v in vals]
+        vdt = (C.c_int * len(vd))(*[(v.tag if v is not None else INT32) for v in vd])
+        vp = (C.c_void_p * len(vd))(*[(v.ptr if v is not None else None) for v in vd])
+        opa = (C.c_int * len(ops))(*ops)
+        h = C.c_void_p()
+        args = (self.ctx, len(kd), dts, ptrs, len(ops), opa, vdt, vp, C.c_uint32(kd[0].n), C.c_uint32(hint), C.byref(h))
+        fn, chk = self.lib.aqg_groupby_agg, self._chk
+        gb = GroupBy(self, h)                      # the handle is created by the first run
+        gb._val_tags = [v.tag if v is not None else INT32 for v in vd]
+        gb._ops = list(ops)
+        gb._keep = (kd, vd, dts, ptrs, vdt, vp, opa)
+
+        def run():
+            rc = fn(*args)
+            if rc != 0:
+                chk(rc, "aqg_groupby_agg")
+            return gb
+        return run, gb
+
     def join_groupby_sum(self, dim_keys, dim_vals, fact_fk, group_keys, fact_vals, hint=0, handle=None):
         """fact JOIN dim ON fk = key, then sum(val * w) by group key -- one fused pass (aqg_join_groupby_sum)"""
         dk, dv, fk, gk, fv = (self._dev(a) for a in (dim_keys, dim_vals, fact_fk, group_keys, fact_vals))

@@ -124,7 +124,9 @@ def main():
         if join:
             gb = dev.join_groupby_sum(dim_key, dim_w, id4, id1, v1, hint=128, handle=state["gb"])
         else:
-            gb = dev.groupby_agg([id1], [ck.RED_SUM], [v1], hint=128, handle=state["gb"])
+            if state.get("q1") is None:           # argument arrays marshalled once (a prepared call); every step runs the whole call
+                state["q1"], state["gb"] = dev.prepare_groupby_agg([id1], [ck.RED_SUM], [v1], hint=128)
+            gb = state["q1"]()
         state["gb"] = gb
         if record:
             kernel_ms.append(dev.last_kernel_ms())
