@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(256) occ_iota_kernel(uint32_t* __restrict__ oc
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) occ[i] = i;
 }
 __global__ void __launch_bounds__(256) gt_init_kernel(GTable gt, AccSpec as) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) gt.flags[threadIdx.x] = 0;          // the 64 flag words, too (one launch instead of a fill behind it)
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s <= gt.cap; s += gridDim.x * blockDim.x) {
         *gt.key_p(s) = EMPTY64;
         *gt.first_p(s) = NOROW;
@@ -1118,7 +1119,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(aqg_ws_get(ctx, ntiles + 1, &tile_total));
     }
     if (!use_part) hipLaunchKernelGGL(gt_init_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, gt, as);
-    AQG_HIP(ctx, hipMemsetAsync(gt.flags, 0, 64 * 4, ctx->stream));
+    else AQG_HIP(ctx, hipMemsetAsync(gt.flags, 0, 64 * 4, ctx->stream));
     if (bitmap) AQG_HIP(ctx, hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, ctx->stream));
 
     // fast path eligibility: LDS mode, one 4-byte integer key, 1..3 four-byte value columns, plain additive accumulators
