@@ -622,12 +622,7 @@ __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __
         uint64_t key = s == gt.cap ? EMPTY64 : (*gt.key_p(s));
         for (int k = 0; k < es.nkeys; ++k) {
             uint64_t bits = es.wide ? load_bits(es.key_dt[k], es.key_col[k], (size_t)(uint32_t)key) : key >> es.key_shift[k];
-            switch (aqg_dtype_size_dev(es.key_dt[k])) {
-            case 1: static_cast<uint8_t*>(es.key_out[k])[g] = (uint8_t)bits; break;
-            case 2: static_cast<uint16_t*>(es.key_out[k])[g] = (uint16_t)bits; break;
-            case 4: static_cast<uint32_t*>(es.key_out[k])[g] = (uint32_t)bits; break;
-            default: static_cast<uint64_t*>(es.key_out[k])[g] = bits; break;
-            }
+            store_sized(es.key_out[k], g, aqg_dtype_size_dev(es.key_dt[k]), bits);
         }
         es.first_out[g] = (*gt.first_p(s));
         uint32_t cnt = gt.has_count ? (*gt.count_p(s)) : 0;
@@ -813,19 +808,14 @@ __global__ void __launch_bounds__(256) unpack_kernel(const long long* __restrict
     }
     __syncthreads();
     if (off[world] > world * gmax) return;
+    const int key_size = aqg_dtype_size_dev(key_dt);
     for (uint32_t r = blockIdx.x; r < world; r += gridDim.x) {
         const long long* src = gathered + (size_t)r * (gmax + 1) * 2;
         const uint32_t cnt = off[r + 1] - off[r];
         for (uint32_t i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const long long k = src[2 + 2 * i];
             const uint32_t d = off[r] + i;
-            switch (aqg_dtype_size_dev(key_dt)) {
-            case 1: static_cast<uint8_t*>(keys)[d] = (uint8_t)k; break;
-            case 2: static_cast<uint16_t*>(keys)[d] = (uint16_t)k; break;
-            case 4: static_cast<uint32_t*>(keys)[d] = (uint32_t)k; break;
-            default: static_cast<long long*>(keys)[d] = k; break;
-            }
             vals[d] = src[3 + 2 * i];
+            store_sized(keys, d, key_size, (unsigned long long)src[2 + 2 * i]);
         }
     }
 }
@@ -901,13 +891,8 @@ __global__ void __launch_bounds__(1024) merge_small_kernel(const long long* __re
         uint32_t rank = 0;
         for (uint32_t j = 0; j < G; ++j) rank += tfirst[occ[j]] < mine;      // first occurrences are distinct rows
         const unsigned long long key = slot == MERGE_CAP ? MERGE_EMPTY : tkey[slot];
-        switch (aqg_dtype_size_dev(key_dt)) {
-        case 1: static_cast<uint8_t*>(keys_out)[rank] = (uint8_t)key; break;
-        case 2: static_cast<uint16_t*>(keys_out)[rank] = (uint16_t)key; break;
-        case 4: static_cast<uint32_t*>(keys_out)[rank] = (uint32_t)key; break;
-        default: static_cast<unsigned long long*>(keys_out)[rank] = key; break;
-        }
         first_out[rank] = mine;
+        store_sized(keys_out, rank, aqg_dtype_size_dev(key_dt), key);
         if (op == AQG_RED_MIN || op == AQG_RED_MAX) static_cast<unsigned long long*>(res_out)[rank] = tlo[slot];
         else { static_cast<aqg_i128*>(res_out)[rank] = aqg_i128{tlo[slot], thi[slot]}; }
     }

@@ -46,6 +46,16 @@ __host__ __device__ inline int aqg_dtype_size_dev(int dt) {
     default: return 8;
     }
 }
+// element `i` of a column of 1 / 2 / 4 / 8-byte integers := the low bytes of `bits`.  Deliberately NOT inlined: with the size switch
+// inlined into unpack_kernel's copy loop, hipcc (ROCm 7.2, -O3) left the register holding the row index undefined on the 8-byte
+// path and the store of the value column that followed the switch went to a wild address (found by a GPU memory fault in the
+// merge of int64-keyed shard tables; the ISA showed `implicit-def $vgpr10_vgpr11` on that path).
+__device__ __noinline__ static void store_sized(void* __restrict__ col, size_t i, int size, unsigned long long bits) {
+    if (size == 1) static_cast<uint8_t*>(col)[i] = (uint8_t)bits;
+    else if (size == 2) static_cast<uint16_t*>(col)[i] = (uint16_t)bits;
+    else if (size == 4) static_cast<uint32_t*>(col)[i] = (uint32_t)bits;
+    else static_cast<unsigned long long*>(col)[i] = bits;
+}
 // slot of a 4-byte key in a power-of-two table of 2^bits slots: the TOP bits of a Fibonacci hash.  They depend on every key
 // bit (keys that are all multiples of 1024 made the low bits of the product useless: 350 ms instead of 1.4 ms per 1e9 rows),
 // and runs of consecutive keys -- dictionary ids -- land evenly spaced (three-distance theorem): 100 consecutive keys never share

@@ -354,3 +354,45 @@ def test_scans_and_windows_over_row_range_shards(gpu, oracle):
                     assert np.all(np.abs(got - ref) <= 1e-12 * np.maximum(np.abs(ref), 1.0)), (name, r)
                 else:
                     assert gu.same_bits(got, ref), (dt, name, r)
+
+
+def test_merge_packed_against_hand_packed_tables(gpu):
+    """aqg_groupby_merge_packed fed with hand-packed shard tables ({count, 0; key, partial} int64 pairs): both the one-workgroup
+    merge (world x gmax <= 2048) and the concatenation + generic group-by, checked against a plain dictionary merge in rank order"""
+    rng = np.random.default_rng(2024)
+    pool = np.array([0, -1, 1, -0x7FFFFFFFFFFFFFFF, np.iinfo(np.int64).min, np.iinfo(np.int64).max] + [int(v) for v in rng.integers(-2**62, 2**62, 300)], dtype=np.int64)
+    for world, gmax in ((1, 1), (2, 7), (8, 128), (16, 128), (5, 700), (64, 32), (3, 2000)):
+        for op in (ck.RED_SUM, ck.RED_MIN, ck.RED_MAX):
+            host = np.zeros((world, gmax + 1, 2), dtype=np.int64)
+            merged_ref = {}
+            for r in range(world):
+                cnt = int(rng.integers(0, min(gmax, len(pool)) + 1))
+                keys = rng.choice(pool, cnt, replace=False)
+                vals = rng.integers(-2**63, 2**63 - 1, cnt, dtype=np.int64) if op != ck.RED_SUM else rng.integers(-2**62, 2**62, cnt, dtype=np.int64) * 2
+                host[r, 0, 0] = cnt
+                host[r, 1:cnt + 1, 0] = keys
+                host[r, 1:cnt + 1, 1] = vals
+                for k, v in zip(keys.tolist(), vals.tolist()):
+                    if k not in merged_ref:
+                        merged_ref[k] = v
+                    else:
+                        merged_ref[k] = merged_ref[k] + v if op == ck.RED_SUM else (min(merged_ref[k], v) if op == ck.RED_MIN else max(merged_ref[k], v))
+            dev = gpu.to_device(host.reshape(-1))
+            merged = gpu.groupby_merge_packed(dev.ptr, world, gmax, ck.INT64, op)
+            assert merged.ngroups == len(merged_ref), (world, gmax, op)
+            assert merged.keys(0, np.int64).tolist() == list(merged_ref.keys()), (world, gmax, op)      # dict order = first occurrence
+            got = merged.result(0, op, ck.INT64)
+            if op == ck.RED_SUM:
+                assert ck.i128_to_int(got) == list(merged_ref.values()), (world, gmax)
+            else:
+                assert got.astype(np.int64).tolist() == list(merged_ref.values()), (world, gmax, op)
+            merged.destroy(); dev.free()
+    # a corrupt header is refused by both paths
+    import aquery2_amd
+    for world, gmax in ((2, 8), (3, 2000)):
+        host = np.zeros((world, gmax + 1, 2), dtype=np.int64)
+        host[1, 0, 0] = gmax + 1
+        dev = gpu.to_device(host.reshape(-1))
+        with pytest.raises(aquery2_amd.capi.AqgError):
+            gpu.groupby_merge_packed(dev.ptr, world, gmax, ck.INT64, ck.RED_SUM)
+        dev.free()
