@@ -199,3 +199,31 @@ def test_fast_kernel_8_byte_value_columns(gpu, oracle, n):
                 else:
                     assert gu.same_bits(got, want), (nm, v.dtype, names)
             gb.destroy()
+
+
+@pytest.mark.parametrize("n", [13, 200_003, 1_500_000])
+def test_build_and_postproc_with_8_byte_and_mixed_keys(gpu, oracle, n):
+    """aqg_groupby_build (reversemap, counts, first rows) and ht_postproc (descending row lists) for the key shapes whose first pass
+    takes the fast kernel's 8-byte layouts: one int64 / uint64 column (with the -1 and INT64_MIN sentinels), two 4-byte columns;
+    plus shapes that stay on the generic path: int64 + int32, int16 + int64 + uint8 (hasher.h:146-199)"""
+    rng = np.random.default_rng(31 + n)
+    k64 = rng.integers(-3, 40, n).astype(np.int64) * 5_000_000_029
+    k64[k64 == -3 * 5_000_000_029] = -1
+    k64[k64 == -2 * 5_000_000_029] = np.iinfo(np.int64).min
+    shapes = [[k64], [rng.integers(0, 30, n).astype(np.uint64) * np.uint64(600_000_000_000_000_007)],
+              [rng.integers(-5, 5, n).astype(np.int32), rng.integers(0, 6, n).astype(np.uint32) * np.uint32(700_000_001)],
+              [k64, rng.integers(0, 3, n).astype(np.int32)],
+              [rng.integers(0, 4, n).astype(np.int16), rng.integers(0, 5, n).astype(np.int64) << 40, rng.integers(0, 2, n).astype(np.uint8)]]
+    for keys in shapes:
+        o = oracle.groupby(keys)
+        g = gpu.groupby_build(keys)
+        assert g.ngroups == o["ngroups"]
+        assert np.array_equal(g.reversemap(), o["reversemap"])
+        assert np.array_equal(g.counts(), o["counts"])
+        assert np.array_equal(g.first_rows(), o["first_rows"])
+        for k, key in enumerate(keys):
+            assert np.array_equal(g.keys(k, key.dtype), key[o["first_rows"]])
+        off, rows = g.postproc()
+        assert np.array_equal(off[:-1], o["offsets"]) and off[-1] == n
+        assert np.array_equal(rows, o["row_ids"])
+        g.destroy()
