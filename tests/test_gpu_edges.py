@@ -135,3 +135,26 @@ def test_running_minmax_changes_across_many_links(gpu, oracle, dt):
         assert gu.same_bits(gpu.scan(ck.SCAN_MINS, d), oracle.scan(ck.SCAN_MINS, arr))
         assert gu.same_bits(gpu.scan(ck.SCAN_MAXS, d), oracle.scan(ck.SCAN_MAXS, arr))
         d.free()
+
+
+@pytest.mark.parametrize("dt", [np.int8, np.uint8, np.int16, np.uint16, np.int32, np.uint32, np.int64, np.uint64, np.float32, np.float64])
+def test_scan_resume_every_dtype_and_tile_boundary(gpu, oracle, dt):
+    """aqg_scan_resume: sums / avgs of the second part of a column, resumed from the carry of the first part, equal the tail of
+    the whole-column scan -- for every numeric dtype and for splits around the 2048-row tile (aggregations.h:203-236)"""
+    rng = np.random.default_rng(3)
+    n = 10_000
+    x = rand(rng, dt, n, small=np.dtype(dt).kind == "f")
+    for split in (0, 1, 2047, 2048, 2049, 9_999):
+        head, tail = x[:split], np.ascontiguousarray(x[split:])
+        for name in ("sums", "avgs"):
+            op = ck.SCAN_NAMES[name]
+            want = oracle.scan(op, x)[split:]
+            if np.dtype(dt).kind == "f":
+                carry = float(np.sum(head.astype(np.float64))) if split else -0.0
+            else:
+                carry = sum(int(v) for v in head.tolist())
+            got = gpu.scan_resume(op, tail, carry, split)
+            if np.dtype(dt).kind == "f":
+                assert np.all(np.abs(got - want) <= 1e-9 * np.maximum(np.abs(want), 1.0)), (name, split)
+            else:
+                assert gu.same_bits(got, want), (name, split)
