@@ -95,6 +95,13 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     assert stream, "expected a non-default stream handle"
     dev = aquery2_amd.Device(gpu, stream=stream)
+    if world > 1:
+        # communicator set-up (lazy in RCCL: seconds on the first collective) happens here, never inside the timed region
+        _probe = torch.zeros(world, dtype=torch.int64, device=xdev)
+        dist.all_gather_into_tensor(_probe, torch.full((1,), rank, dtype=torch.int64, device=xdev))
+        if xdev == "cuda":
+            torch.cuda.synchronize()
+        assert _probe.tolist() == list(range(world))
     id1 = dev.gen_column(ck.GEN_ID1, 42, rank * n, n, n_total, 100)
     v1 = dev.gen_column(ck.GEN_V1, 42, rank * n, n, n_total, 100)
     join = args.workload == "join"
