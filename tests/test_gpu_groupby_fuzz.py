@@ -2,6 +2,8 @@
 from a handful to hundreds of thousands, row counts around the plan thresholds (2^20: partition / dense / big LDS; 2^22: the
 sample-based cardinality estimate when no hint is given), hints that are absent, exact, too small and too large, and random
 aggregate sets -- every result against the oracle's first-occurrence order, keys, first rows and aggregates."""
+import os
+
 import numpy as np
 import pytest
 
@@ -55,9 +57,10 @@ def make_case(seed):
     return n, keys, aggs, str(hint_mode)
 
 
-@pytest.mark.parametrize("seed", range(60))      # (200 seeds were run once while writing this: all green)
+# AQG_FUZZ_SEEDS / AQG_FUZZ_BASE: a longer or different sweep (2300 more seeds were run at the end of round 1: all green)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AQG_FUZZ_SEEDS", "60"))))
 def test_groupby_random_shapes(gpu, oracle, seed):
-    n, keys, aggs, hint_mode = make_case(1000 + seed)
+    n, keys, aggs, hint_mode = make_case(int(os.environ.get("AQG_FUZZ_BASE", "1000")) + seed)
     o = oracle.groupby(keys)
     G = o["ngroups"]
     hint = {"none": 0, "exact": G, "small": max(1, G // 10), "large": min(n, G * 10 + 7)}[hint_mode]
