@@ -1119,16 +1119,18 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     // value columns: 4 bytes wide, or 4 and 8 bytes wide (an int64 sum takes two accumulators)
     auto wide_dt = [](int dt) { return dt == AQG_INT64 || dt == AQG_UINT64 || dt == AQG_DOUBLE; };
     auto narrow_dt = [](int dt) { return dt == AQG_INT32 || dt == AQG_UINT32 || dt == AQG_FLOAT; };
-    bool fast_v8 = false;                       // some value column is 8 bytes wide: the VW = 8 instantiation (it takes 4-byte ones, too)
-    for (int a = 0; a < as.nacc; ++a) fast_v8 = fast_v8 || wide_dt(as.dt[a]);
+    auto tiny_dt = [](int dt) { return dt == AQG_INT8 || dt == AQG_UINT8 || dt == AQG_BOOL || dt == AQG_INT16 || dt == AQG_UINT16; };
+    bool fast_v8 = false;                       // some value column is 1, 2 or 8 bytes wide: the VW = 8 instantiation (it takes 4-byte ones, too)
+    for (int a = 0; a < as.nacc; ++a) fast_v8 = fast_v8 || wide_dt(as.dt[a]) || tiny_dt(as.dt[a]);
     fast_v8 = fast_v8 && getenv("AQG_DISABLE_FAST64") == nullptr;
     for (int a = 0; a < as.nacc && fast; ++a) {
         const int dt = as.dt[a];
         if ((uintptr_t)as.col[a] & 15) fast = false;
-        if (fast_v8) { if (!wide_dt(dt) && !narrow_dt(dt)) fast = false; }
+        if (fast_v8) { if (!wide_dt(dt) && !narrow_dt(dt) && !tiny_dt(dt)) fast = false; }
         else if (as.part[a] || !narrow_dt(dt)) fast = false;
         fv.col[a] = as.col[a];
-        fv.vkind[a] = dt == AQG_INT32 ? 0 : dt == AQG_UINT32 ? 1 : dt == AQG_FLOAT ? 2 : dt == AQG_INT64 ? 3 : dt == AQG_UINT64 ? 4 : 5;
+        fv.vkind[a] = dt == AQG_INT32 ? 0 : dt == AQG_UINT32 ? 1 : dt == AQG_FLOAT ? 2 : dt == AQG_INT64 ? 3 : dt == AQG_UINT64 ? 4 : dt == AQG_DOUBLE ? 5 :
+                      dt == AQG_INT8 ? 6 : (dt == AQG_UINT8 || dt == AQG_BOOL) ? 7 : dt == AQG_INT16 ? 8 : 9;
         fv.kind[a] = as.kind[a];
         fv.square[a] = as.square[a];
         fv.part[a] = as.part[a];

@@ -10,7 +10,8 @@ namespace {
 // Same LDS open-addressing idea as agg_kernel, pared down to what these shapes need: the slot is the packed key alone (4 or 8
 // bytes), eight rows per lane per step with all probes issued before the first compare, and NO first-row bookkeeping in the
 // loop -- first rows are recovered afterwards by first_rows_kernel, which stops as soon as every group has one (a few tiles on
-// h2o data).  vkind: 0 int32, 1 uint32, 2 float (VW = 4) or 3 int64, 4 uint64, 5 double (VW = 8: some value column is 8 bytes wide;
+// h2o data).  vkind: 0 int32, 1 uint32, 2 float (VW = 4) or also 3 int64, 4 uint64, 5 double, 6 int8, 7 uint8 / bool, 8 int16, 9 uint16
+// (VW = 8: some value column is not 4 bytes wide;
 // an int64 sum is two accumulators over the same column, `part` 1 / 2 = its low / high half);
 // kind: ACC_ADD_I / ACC_ADD_F / ACC_MIN / ACC_MAX; square: accumulate x*x.
 // (The generic agg_kernel ran max(v1),min(v2) by id1 at 27 % of the HBM roofline and var(v1) at 18 %; this kernel does SUM at 75 %.)
@@ -65,7 +66,11 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
             case 2: return val_operand_t(__uint_as_float((uint32_t)bits), fv.kind[a], fv.square[a]);
             case 3: return val_operand_t((int64_t)bits, fv.kind[a], fv.square[a], fv.part[a]);
             case 4: return val_operand_t((uint64_t)bits, fv.kind[a], fv.square[a], fv.part[a]);
-            default: return val_operand_t(__builtin_bit_cast(double, (uint64_t)bits), fv.kind[a], fv.square[a]);
+            case 5: return val_operand_t(__builtin_bit_cast(double, (uint64_t)bits), fv.kind[a], fv.square[a]);
+            case 6: return val_operand_t((int8_t)(uint8_t)bits, fv.kind[a], fv.square[a]);
+            case 7: return val_operand_t((uint8_t)bits, fv.kind[a], fv.square[a]);
+            case 8: return val_operand_t((int16_t)(uint16_t)bits, fv.kind[a], fv.square[a]);
+            default: return val_operand_t((uint16_t)bits, fv.kind[a], fv.square[a]);
             }
         } else {
             switch (fv.vkind[a]) {
@@ -107,10 +112,14 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
             if constexpr (VW == 8) {
                 if (a > 0 && fv.col[a] == fv.col[a - 1]) {   // both halves of an int64 sum (or sum and sum of squares) read one column
                     _Pragma("unroll") for (int q = 0; q < 4; ++q) w[a][q] = w[a - 1][q];
-                } else if (fv.vkind[a] >= 3) {
+                } else if (fv.vkind[a] >= 3 && fv.vkind[a] <= 5) {
                     _Pragma("unroll") for (int q = 0; q < 4; ++q) w[a][q] = *reinterpret_cast<const pack<uint64_t, 2>*>(static_cast<const uint64_t*>(fv.col[a]) + base + 2 * q);
-                } else {                                     // a 4-byte column beside 8-byte ones: eight rows in the first two register pairs
+                } else if (fv.vkind[a] <= 2) {               // a 4-byte column: eight rows in the first two register pairs
                     _Pragma("unroll") for (int q = 0; q < 2; ++q) w[a][q] = *reinterpret_cast<const pack<uint64_t, 2>*>(static_cast<const uint32_t*>(fv.col[a]) + base + 4 * q);
+                } else if (fv.vkind[a] <= 7) {               // a 1-byte column: eight rows in one 8-byte load
+                    w[a][0].v[0] = *reinterpret_cast<const uint64_t*>(static_cast<const uint8_t*>(fv.col[a]) + base);
+                } else {                                     // a 2-byte column: eight rows in one 16-byte load
+                    w[a][0] = *reinterpret_cast<const pack<uint64_t, 2>*>(static_cast<const uint16_t*>(fv.col[a]) + base);
                 }
             } else {
                 v0[a] = *reinterpret_cast<const pack<uint32_t, 4>*>(static_cast<const uint32_t*>(fv.col[a]) + base);
@@ -119,8 +128,10 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
         }
         auto raw = [&](int a, int j) -> VB {
             if constexpr (VW == 8) {
-                if (fv.vkind[a] >= 3) return w[a][j >> 1].v[j & 1];
-                return (w[a][j >> 2].v[(j >> 1) & 1] >> (32 * (j & 1))) & 0xFFFFFFFFull;
+                if (fv.vkind[a] >= 3 && fv.vkind[a] <= 5) return w[a][j >> 1].v[j & 1];
+                if (fv.vkind[a] <= 2) return (w[a][j >> 2].v[(j >> 1) & 1] >> (32 * (j & 1))) & 0xFFFFFFFFull;
+                if (fv.vkind[a] <= 7) return (w[a][0].v[0] >> (8 * j)) & 0xFFull;
+                return (w[a][0].v[j >> 2] >> (16 * (j & 3))) & 0xFFFFull;
             } else return j < 4 ? v0[a].v[j] : v1[a].v[j - 4];
         };
         KT k[8], cur[8];
@@ -172,9 +183,25 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = val_operand_t(raw64(j), fv.kind[a], fv.square[a], fv.part[a]);
                         break;
-                    default:
+                    case 5:
 #pragma unroll
                         for (int j = 0; j < 8; ++j) o[j] = val_operand_t(__builtin_bit_cast(double, raw64(j)), fv.kind[a], fv.square[a]);
+                        break;
+                    case 6:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = val_operand_t((int8_t)(uint8_t)(w[a][0].v[0] >> (8 * j)), fv.kind[a], fv.square[a]);
+                        break;
+                    case 7:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = val_operand_t((uint8_t)(w[a][0].v[0] >> (8 * j)), fv.kind[a], fv.square[a]);
+                        break;
+                    case 8:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = val_operand_t((int16_t)(uint16_t)(w[a][0].v[j >> 2] >> (16 * (j & 3))), fv.kind[a], fv.square[a]);
+                        break;
+                    default:
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = val_operand_t((uint16_t)(w[a][0].v[j >> 2] >> (16 * (j & 3))), fv.kind[a], fv.square[a]);
                         break;
                     }
                     switch (fv.kind[a]) {
@@ -258,7 +285,10 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
         if (row < n) {
             VB vb[NV ? NV : 1];
             _Pragma("unroll") for (int a = 0; a < NV; ++a) {
-                if (VW == 8 && fv.vkind[a] < 3) vb[a] = static_cast<const uint32_t*>(fv.col[a])[row]; else vb[a] = static_cast<const VB*>(fv.col[a])[row];
+                if (VW == 8 && fv.vkind[a] <= 2) vb[a] = static_cast<const uint32_t*>(fv.col[a])[row];
+                else if (VW == 8 && fv.vkind[a] >= 8) vb[a] = static_cast<const uint16_t*>(fv.col[a])[row];
+                else if (VW == 8 && fv.vkind[a] >= 6) vb[a] = static_cast<const uint8_t*>(fv.col[a])[row];
+                else vb[a] = static_cast<const VB*>(fv.col[a])[row];
             }
             KT key;
             if constexpr (K64) key = keys_hi ? ((uint64_t)keys[row] | ((uint64_t)keys_hi[row] << 32)) : reinterpret_cast<const uint64_t*>(keys)[row]; else key = keys[row];

@@ -169,10 +169,15 @@ def test_fast_kernel_8_byte_value_columns(gpu, oracle, n):
     i32 = rand(rng, np.int32, n, small=True)
     u32 = rng.integers(0, 1 << 32, n, dtype=np.uint32)
     f32 = np.round(rng.uniform(0, 100, n), 6).astype(np.float32)
+    i8, u8 = rng.integers(-128, 128, n).astype(np.int8), rng.integers(0, 256, n).astype(np.uint8)
+    i16, u16 = rng.integers(-2**15, 2**15, n).astype(np.int16), rng.integers(0, 2**16, n).astype(np.uint16)
+    b8 = (rng.random(n) < 0.4).astype(np.uint8)
     shapes = [(["sum"], [f64]), (["avg"], [f64]), (["min", "max"], [f64, f64]), (["var"], [f64]), (["sum"], [i64]), (["sum"], [u64]),
               (["min", "max"], [i64, u64]), (["sum", "avg"], [i64, f64]), (["sum", "count", "max"], [f64, f64, i64]), (["avg", "avg", "sum"], [f64, -f64, u64]),
               # 4-byte columns beside 8-byte ones
-              (["sum", "avg"], [i32, f64]), (["sum", "sum", "max"], [f32, i64, u32]), (["min", "var"], [u32, f64]), (["avg", "max", "min", "sum"], [i32, f64, f32, f64])]
+              (["sum", "avg"], [i32, f64]), (["sum", "sum", "max"], [f32, i64, u32]), (["min", "var"], [u32, f64]), (["avg", "max", "min", "sum"], [i32, f64, f32, f64]),
+              # 1- and 2-byte columns (masks, small integers), alone and beside wider ones
+              (["sum"], [b8]), (["sum", "min", "max"], [i8, i8, u8]), (["var", "avg"], [i16, u16]), (["sum", "sum", "max", "min"], [b8, f64, i16, i32]), (["count", "sum"], [u16, i8])]
     # one 8-byte key column takes the same kernel (its bits are the packed key): -1 is the table's empty mark, INT64_MIN and huge
     # unsigned values exercise the hash of the high half
     k64 = rng.integers(-3, 60, n).astype(np.int64) * 3_000_000_019
