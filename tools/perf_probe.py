@@ -70,6 +70,9 @@ if which in ("all", "generic"):
     timeit("sum(v1 int64) by id1", 12, aggg("i", [id1], [ck.RED_SUM], [v1l]))
     timeit("sum(v3 double) by id1,id2%7", 16, aggg("j", [id1, k7], [ck.RED_SUM], [v3d]))
     timeit("sum(v1),avg(v3 double) by id1", 16, aggg("n", [id1], [ck.RED_SUM, ck.RED_AVG], [v1, v3d]))
+    m8 = d.ewise(ck.OP_GT, v1, np.int32(2), keep=True)                       # a bool mask (1 byte per row) as the value column
+    timeit("sum(v1 > 2) by id1 (1-byte mask)", 5, aggg("o", [id1], [ck.RED_SUM], [m8]))
+    m8.free()
     id1l = d.ewise(ck.OP_MUL, id1, np.int64(1_000_000_007), ot=ck.INT64, keep=True)
     timeit("sum(v1) by id1 (one int64 key)", 12, aggg("l", [id1l], [ck.RED_SUM], [v1]))
     timeit("sum(v3 double) by id1 (int64 key)", 16, aggg("m", [id1l], [ck.RED_SUM], [v3d]))
