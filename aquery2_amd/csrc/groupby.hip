@@ -9,7 +9,8 @@
 // is not observable in results (only dense ids are), so the device uses its own.
 //
 // Plans (run_agg picks by the group-count hint, key shape and row count)
-//   agg32_kernel       one 4-byte key, 4-byte SUM/AVG/COUNT values, <= 3072 groups: LDS table, 8 probes in flight (h2o Q1/Q4)
+//   agg32_kernel       (groupby_fast.hip) one or two 4-byte keys or one 8-byte key, up to four accumulators over 1- to 8-byte values,
+//                      <= 3072 groups: LDS table, 8 probes in flight (h2o Q1/Q4)
 //   agg_kernel<LDS>    any dtypes / MIN / MAX / VAR, packed tuples: {key, first_row, accumulators} open-addressing table in
 //                      LDS (64 KB tables, several workgroups per CU; or one 150 KB table per CU and up to 4 passes over
 //                      the rows), merged into the global table with device-scope atomics
@@ -1107,8 +1108,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     else AQG_HIP(ctx, hipMemsetAsync(gt.flags, 0, 64 * 4, ctx->stream));
     if (bitmap) AQG_HIP(ctx, hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, ctx->stream));
 
-    // fast path eligibility: LDS mode, one 4-byte integer key, 1..3 four-byte value columns, plain additive accumulators
-    // (also the first pass of aqg_groupby_build: no accumulators, only the distinct keys)
+    // fast path eligibility: LDS mode, 16-byte aligned columns, one or two 4-byte integer keys or one 8-byte key, up to four accumulators
+    // of any kind over integer / floating value columns (also the first pass of aqg_groupby_build: no accumulators, only the distinct keys)
     auto key32 = [&](int j) { return (ks.dt[j] == AQG_INT32 || ks.dt[j] == AQG_UINT32) && ((uintptr_t)ks.col[j] & 15) == 0; };
     // two 4-byte key columns, or one 8-byte key column whose bits are the packed key
     const bool fast_key8 = ks.nkeys == 1 && !ks.wide && (ks.dt[0] == AQG_INT64 || ks.dt[0] == AQG_UINT64) && ((uintptr_t)ks.col[0] & 15) == 0 && getenv("AQG_DISABLE_FAST64") == nullptr;
