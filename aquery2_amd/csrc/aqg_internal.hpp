@@ -25,6 +25,8 @@ struct aqg_ctx {
     size_t ws_cap = 0, ws_off = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evk0 = nullptr, evk1 = nullptr;   // bracket the dominant kernel of the last call
+    hipEvent_t ev_flags = nullptr;               // recorded behind the copy of a group table's flag words (run_agg)
+    bool tail_in_flight = false;                 // the last group-by returned with its tail kernels still queued (stream-ordered)
     bool evk_valid = false;
     std::unordered_map<const void*, aqg_pin> pins;
     std::unordered_map<const void*, int> max_lds;   // largest dynamic LDS size already granted per kernel (aqg_allow_lds)

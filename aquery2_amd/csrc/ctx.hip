@@ -83,6 +83,7 @@ int aqg_ctx_create(int device, void* hip_stream, aqg_ctx** out) {
     hipEventCreate(&ctx->ev1);
     hipEventCreate(&ctx->evk0);
     hipEventCreate(&ctx->evk1);
+    hipEventCreate(&ctx->ev_flags);
     *out = ctx;
     return AQG_OK;
 }
@@ -98,6 +99,7 @@ void aqg_ctx_destroy(aqg_ctx* ctx) {
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->evk0) hipEventDestroy(ctx->evk0);
     if (ctx->evk1) hipEventDestroy(ctx->evk1);
+    if (ctx->ev_flags) hipEventDestroy(ctx->ev_flags);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -1201,9 +1201,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (!(n && use_part)) hipLaunchKernelGGL(collect_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, gt, occ);
     uint32_t fl[4] = {0, 0, 0, 0};                    // [0] overflow, [1] occupied slots, [3] a row outside the sampled key ranges
     uint32_t G = 0;
-    auto read_flags = [&]() -> int {
-        AQG_HIP(ctx, hipMemcpyAsync(fl, gt.flags, 16, hipMemcpyDeviceToHost, ctx->stream));
-        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    auto judge_flags = [&]() -> int {
         if (dense && fl[3]) { h->dense_exact = true; return AQG_ERR_RANGE_MISS; }
         if (fl[0]) return AQG_ERR_OVERFLOW;
         G = fl[1];
@@ -1211,12 +1209,26 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         if (use_lds && G > lds_group_cap && G > hint) return AQG_ERR_OVERFLOW;   // correct but slow (overflow rows took the HBM path): re-plan
         return AQG_OK;
     };
+    auto read_flags = [&]() -> int {
+        AQG_HIP(ctx, hipMemcpyAsync(fl, gt.flags, 16, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return judge_flags();
+    };
     // The fast kernel or the fused star join with a small table (h2o Q1 / Q4, config 4): every kernel of the tail reads the group count from the device flags and
-    // the outputs are sized by the table, so the host waits ONCE, at the end, instead of once here and once after emit (the
-    // round trip in the middle cost 26 us of a 1.45 ms step).  An overflow is then noticed after the tail has run on it: the
-    // kernels are bounded by the table and by `gmax`, the results are discarded and the call re-plans as before.
+    // the outputs are sized by the table, so nothing on the host stands between collect and emit (a round trip there cost 26 us
+    // of a 1.45 ms step).  The flag words -- final once collect has run -- are copied to pinned memory right here, behind
+    // collect and in FRONT of the tail, and the host waits for that copy only: the call returns with first rows / rank / emit
+    // still queued (stream-ordered, like every device result of this library), so the host's way to the next call overlaps them.
+    // An overflow is noticed with the tail already queued on it: those kernels are bounded by the table and by `gmax`, their
+    // results are discarded and the call re-plans as before.
     const bool defer = n && (fast || plan.sj) && small_rank && !dense && !use_part;
     const uint32_t gupper = (uint32_t)(slots + 1 < 4096 ? slots + 1 : 4096);
+    uint32_t* pinned_flags = nullptr;
+    if (defer) {
+        AQG_TRY(aqg_host_stage(ctx, 16, reinterpret_cast<void**>(&pinned_flags)));
+        AQG_HIP(ctx, hipMemcpyAsync(pinned_flags, gt.flags, 16, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipEventRecord(ctx->ev_flags, ctx->stream));
+    }
     if (!defer) AQG_TRY(read_flags());
     if ((defer || G) && n && fast) {
         // two launches: 32 workgroups over the first 32768 rows (where every group of an h2o-like column already shows up), then
@@ -1285,7 +1297,12 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt, occ, gid_of_occ, es, (const uint32_t*)order, defer ? 4096u : 0u);
         AQG_TRY(aqg_check_launch(ctx, "emit_kernel"));
     }
-    if (defer) AQG_TRY(read_flags());
+    if (defer) {
+        AQG_HIP(ctx, hipEventSynchronize(ctx->ev_flags));
+        memcpy(fl, pinned_flags, 16);
+        AQG_TRY(judge_flags());
+        ctx->tail_in_flight = true;
+    }
     h->ngroups = G;
     if (gt_out) *gt_out = gt;
     if (dense_out) { dense_out->used = dense; if (dense) dense_out->spec = dspec; }
@@ -1381,9 +1398,10 @@ int aqg_groupby_agg(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* 
     AQG_TRY(make_plan(ctx, naggs, ops, val_dtypes, vals, n, &plan));
     aqg_groupby* h = *out ? *out : new aqg_groupby();
     h->ctx = ctx; h->n = n; h->has_reversemap = false;
+    ctx->tail_in_flight = false;
     int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, false, h, nullptr, nullptr);
     if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
-    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->tail_in_flight) AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (small tables: the group count is known, the tail is stream-ordered)
     *out = h;
     return AQG_OK;
 }
@@ -1415,9 +1433,10 @@ int aqg_join_groupby_sum(aqg_ctx* ctx, int key_dtype, const void* dim_keys, int 
     plan.sj = &sj;
     aqg_groupby* h = *out ? *out : new aqg_groupby();
     h->ctx = ctx; h->n = n; h->has_reversemap = false;
+    ctx->tail_in_flight = false;
     int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, false, h, nullptr, nullptr);
     if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
-    AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->tail_in_flight) AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (small tables: the group count is known, the tail is stream-ordered)
     *out = h;
     return AQG_OK;
 }
