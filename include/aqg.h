@@ -203,7 +203,10 @@ int aqg_grouped_reduce(aqg_ctx* ctx, const aqg_groupby* g, int op, int t, const 
  * `*out` is in/out: pass NULL to create a handle, or an earlier handle to reuse its buffers
  * (steady-state calls then allocate nothing).  max_groups_hint sizes the hash tables
  * (0 = unknown: start small and grow); the call retries internally when the hint is too low.
- * Synchronous: on return the handle's ngroups is final.                                         */
+ * On return the handle's ngroups is final; the device columns behind the handle (keys, first rows,
+ * counts, results) may still be being written by kernels queued on the context's stream: read
+ * them through this library (aqg_groupby_keys, aqg_d2h, ...: all ordered behind those kernels),
+ * from the same stream, or after aqg_sync.                                                       */
 int aqg_groupby_agg(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* const* keys,
                     int naggs, const int* ops, const int* val_dtypes, const void* const* vals,
                     uint32_t n, uint32_t max_groups_hint, aqg_groupby** out);
