@@ -232,3 +232,34 @@ def test_build_and_postproc_with_8_byte_and_mixed_keys(gpu, oracle, n):
         assert np.array_equal(off[:-1], o["offsets"]) and off[-1] == n
         assert np.array_equal(rows, o["row_ids"])
         g.destroy()
+
+
+def test_handle_reuse_with_the_tail_still_queued(gpu, oracle):
+    """small-table calls return once the group count is known, with first rows / rank / emit still queued on the stream: reusing the
+    handle at once for another input, reading results right after a call, and the prepared call of bench.py must all see their
+    own call's results (stream order)"""
+    rng = np.random.default_rng(77)
+    n = 600_011
+    cases = []
+    for t in range(3):
+        keys = [rng.integers(-30 - t, 30 + t, n).astype(np.int32)]
+        v = rng.integers(-1000, 1000, n).astype(np.int32)
+        o = oracle.groupby(keys)
+        cases.append((gpu.to_device(keys[0]), gpu.to_device(v), keys[0], o, ck.i128_to_int(oracle.grouped_reduce(ck.RED_SUM, v, o))))
+    gb = None
+    for it in range(12):
+        dk, dv, hk, o, want = cases[it % 3]
+        gb = gpu.groupby_agg([dk], [ck.RED_SUM], [dv], hint=128, handle=gb)
+        if it % 2:                                              # every other call: straight into the next one, nothing read in between
+            continue
+        assert gb.ngroups == o["ngroups"]
+        assert np.array_equal(gb.keys(0, np.int32), hk[o["first_rows"]])
+        assert np.array_equal(gb.first_rows(), o["first_rows"])
+        assert ck.i128_to_int(gb.result(0, ck.RED_SUM, ck.INT32)) == want
+    gb.destroy()
+    dk, dv, hk, o, want = cases[1]
+    run, pgb = gpu.prepare_groupby_agg([dk], [ck.RED_SUM], [dv], hint=128)
+    for _ in range(5):
+        run()
+    assert pgb.ngroups == o["ngroups"] and ck.i128_to_int(pgb.result(0, ck.RED_SUM, ck.INT32)) == want
+    pgb.destroy()
