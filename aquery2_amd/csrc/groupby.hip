@@ -29,6 +29,7 @@
 // partition.hip
 size_t aqg_partition_ws_bytes(uint32_t n, int ksz, const AccSpec& as, uint32_t pbits);
 int aqg_partition_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t pbits, uint32_t lcap, int need_count, GTable out, uint32_t out_cap);
+#include "partition1.hpp"
 
 namespace {
 
@@ -1066,6 +1067,13 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         while (pbits < 16 && ((uint64_t)hint >> pbits) * 1000 > (uint64_t)part_lcap * lf1000) ++pbits;
         gcap = (uint32_t)((uint64_t)hint + hint / 4 + 4096 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : (uint64_t)hint + hint / 4 + 4096);   // compact record table
     }
+    // partition1.hip: ONE level up to ~1000 partitions (every plane moves once), two levels of <= 64 bins up to 4096 (the runs a
+    // tile writes stay a kilobyte long); beyond that the round-1 pipeline of partition.hip
+    static const bool p1_off = getenv("AQG_DISABLE_P1") != nullptr;          // A/B measurements only
+    static const uint32_t p1_max = getenv("AQG_P1_MAX") ? (uint32_t)atoi(getenv("AQG_P1_MAX")) : 1024u;
+    const uint32_t parts = use_part && !p1_off ? aqg_partition_parts(ks.total_bytes <= 4 ? 4 : 8, as, plan.need_count, hint) : 0;
+    const uint32_t p1_bins = parts && parts <= p1_max && parts <= AQG_P1_MAXBINS ? parts : 0;
+    const uint32_t p2_parts = parts && !p1_bins && parts <= AQG_P2_MAXPARTS ? parts : 0;
 
     // ---- workspace ----------------------------------------------------------------------------
     size_t slots = (size_t)gcap + 1;
@@ -1075,7 +1083,9 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (!small_rank) need += (size_t)nwords * 8 + (size_t)ntiles * 4 + 4096;
     const bool ordered_emit = !small_rank && hint >= (1u << 20);
     if (ordered_emit) need += slots * 4 + 4096;
-    if (use_part) need += aqg_partition_ws_bytes(n, ks.total_bytes <= 4 ? 4 : 8, as, pbits) + 65536;
+    if (p1_bins) need += aqg_partition1_ws_bytes(ctx, ks, n, as, p1_bins) + 65536;
+    else if (p2_parts) need += aqg_partition2_ws_bytes(ctx, ks, n, as, p2_parts) + 65536;
+    else if (use_part) need += aqg_partition_ws_bytes(n, ks.total_bytes <= 4 ? 4 : 8, as, pbits) + 65536;
     AQG_TRY(aqg_ws_reset(ctx));
     AQG_TRY(aqg_ws_ensure(ctx, need));
     GTable gt;
@@ -1156,7 +1166,9 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     } else if (n && dense) {
         AQG_TRY(aqg_dense_aggregate(ctx, ks, dspec, as, n, plan.need_count, gt));
     } else if (n && use_part) {
-        AQG_TRY(aqg_partition_aggregate(ctx, ks, as, n, pbits, part_lcap, plan.need_count, gt, gcap));
+        if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap));
+        else if (p2_parts) AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap));
+        else AQG_TRY(aqg_partition_aggregate(ctx, ks, as, n, pbits, part_lcap, plan.need_count, gt, gcap));
         hipLaunchKernelGGL(occ_iota_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, occ, (uint32_t)slots);
     } else if (n) {
         uint32_t lrep = 1;

@@ -1,0 +1,847 @@
+// partition1.hip -- high-cardinality group-by in ONE partition level (h2o Q3 / Q5 / Q7 at 1e7 groups): replaces AQHashTable's
+// robin-hood build (reference server/hasher.h:146-199, server/unordered_dense.h:1117-1147) and the generated per-group loop
+// (engine/ast.py:722-789) where the groups do not fit one workgroup's LDS.
+//
+// Round 1 partitioned {key, row id, values} in two MSD levels of <= 8 bits: every level reads and writes all planes, ~100 B
+// moved per row for 16 algorithmic (h2o Q5).  This plan moves them ONCE:
+//   p1_hist     one workgroup per CHUNK of rows (a multiple of the 32768-row tile): bin counts of the chunk, [bin][chunk]
+//   scan        exclusive scan of that matrix = start of every (bin, chunk) run
+//   p1_scatter  one workgroup per chunk walks its tiles carrying the running bin cursors in LDS: rows are ranked inside their
+//               bins with returning LDS atomics, each dword plane is staged bin-major in LDS (128 KB) and streamed out, so a
+//               tile writes one run per bin and plane and consecutive tiles of a chunk continue each other's runs
+//   p1_agg      one 1024-thread workgroup per partition: open-addressing KEY table {key, dense id} at a low load factor and
+//               DENSE accumulator arrays indexed by the id -- the accumulators (28 B per group for Q5) are not multiplied by the
+//               table's slack, which is what lets a partition hold ~3700 groups in 150 KB and 1e7 groups fit ~2900 bins
+// Up to MAXBINS bins (LDS of the scatter: 128 KB of staging + 8 B per bin).  More groups than that: partition.hip (two levels).
+#include <cmath>
+
+#include "groupby_dev.hpp"
+#include "partition1.hpp"
+
+namespace {
+
+constexpr int SB = 1024;          // threads per workgroup
+constexpr int SR = 32;            // rows per thread and tile
+constexpr int PT = SB * SR;       // rows per tile: 32768 (one staged dword plane = 128 KB)
+constexpr int MAXPL = 4 + 2 * MAXACC;
+
+template <bool K64> struct KeyWord { using type = uint32_t; };
+template <> struct KeyWord<true> { using type = uint64_t; };
+template <bool K64> using key_t_ = typename KeyWord<K64>::type;
+
+template <bool K64> __device__ inline uint32_t key_hash(key_t_<K64> k) { return lds_h1<!K64>((uint64_t)k); }
+
+// A lane owns SR / 4 groups of FOUR consecutive rows of a tile (one 16-byte load per 4-byte column and group).
+__device__ inline uint32_t tile_row(int r) { return (uint32_t)(r >> 2) * (SB * 4) + threadIdx.x * 4 + (r & 3); }
+// Loader of one BATCH of R rows of a lane: rows r0 .. r0 + R - 1 of the lane's SR rows of the tile.
+// FULL: the tile has all its rows (every tile but the last one of the input): vector loads, no bounds.  Otherwise row by row
+// with a clamped index (every load is issued, none sits behind a branch; the caller masks rows >= nrows).
+template <bool FULL, class T, int R> __device__ inline void load_rows(const T* __restrict__ p, size_t tile_first, uint32_t nrows, int r0, T (&t)[R]) {
+    const T* tp = p + tile_first;
+    if constexpr (FULL) {
+#pragma unroll
+        for (int c = 0; c < R / 4; ++c) __builtin_memcpy(&t[4 * c], tp + tile_row(r0 + 4 * c), 4 * sizeof(T));
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const uint32_t o = tile_row(r0 + r); t[r] = tp[o < nrows ? o : nrows - 1]; }
+    }
+}
+
+// Everything the scatter moves is a DWORD PLANE: one 32-bit word per row, read from a column of 4-byte elements (stride 1) or
+// from one half of a column of 8-byte elements (stride 2 dwords), or made from the row index, and written at a dword stride.
+// The key is one column of key words (4 or 8 bytes): tuples of several columns and 1- / 2-byte values are packed / widened into
+// such columns first (p1_pack_keys_kernel, p1_widen_kernel).
+enum : int { PL_LOAD = 0, PL_ROWIDX = 1 };
+struct Plane {
+    const uint32_t* src; int src_stride_dw; int src_off_dw;
+    uint32_t* dst; int dst_stride_dw; int dst_off_dw;
+    int kind;
+};
+struct Planes { int n; Plane p[MAXPL]; };
+
+// Chunks of whole tiles cover rows [0, nfull); the rows behind the last whole tile, if any, are one more chunk (the TAIL chunk,
+// index nchunks - 1), scattered by its own small kernel so that the main kernel never sees a partial tile.
+struct Chunks { uint32_t n, nfull, chunk_rows, nchunks, nbins, has_tail; };
+__device__ inline void chunk_range(const Chunks& ch, uint32_t c, uint64_t& b, uint64_t& e) {
+    if (ch.has_tail && c + 1 == ch.nchunks) { b = ch.nfull; e = ch.n; return; }
+    b = (uint64_t)c * ch.chunk_rows;
+    e = b + ch.chunk_rows < ch.nfull ? b + ch.chunk_rows : ch.nfull;
+    if (b > e) b = e;
+}
+
+// ---- key tuples of several columns -> one column of key words; 1- / 2-byte values -> dwords -------------------------------------
+template <bool K64>
+__global__ void __launch_bounds__(256) p1_pack_keys_kernel(KeySpec ks, uint32_t n, key_t_<K64>* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (key_t_<K64>)pack_key(ks, i);
+}
+__global__ void __launch_bounds__(256) p1_widen_kernel(const void* __restrict__ col, int esz, uint32_t n, uint32_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = esz == 1 ? (uint32_t)static_cast<const uint8_t*>(col)[i] : (uint32_t)static_cast<const uint16_t*>(col)[i];
+}
+
+// ---- bin counts of every chunk -----------------------------------------------------------------------------------------------
+constexpr int HR = 16;   // rows per thread and step of the histogram pass
+template <bool K64>
+__global__ void __launch_bounds__(SB) p1_hist_kernel(const key_t_<K64>* __restrict__ keys, Chunks ch, uint32_t* __restrict__ hist /* [bin][chunk] */) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);
+    for (uint32_t b = threadIdx.x; b < ch.nbins; b += SB) cnt[b] = 0;
+    __syncthreads();
+    uint64_t cb, ce;
+    chunk_range(ch, blockIdx.x, cb, ce);
+    for (uint64_t rb = cb; rb < ce; rb += (uint64_t)SB * HR) {
+        const uint32_t nrows = ce - rb < (uint64_t)SB * HR ? (uint32_t)(ce - rb) : SB * HR;
+        key_t_<K64> key[HR];
+        if (nrows == SB * HR) load_rows<true>(keys, rb, nrows, 0, key); else load_rows<false>(keys, rb, nrows, 0, key);
+#pragma unroll
+        for (int r = 0; r < HR; ++r)
+            if (tile_row(r) < nrows) atomicAdd(&cnt[__umulhi(key_hash<K64>(key[r]), ch.nbins)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < ch.nbins; b += SB) hist[(size_t)b * ch.nchunks + blockIdx.x] = cnt[b];
+}
+
+// ---- scatter -------------------------------------------------------------------------------------------------------------------
+// One tile: rank the rows inside their bins, then stage and stream out plane after plane.  A lane's SR rows are handled in
+// batches of H (all loads of a batch are issued before the first use: memory-level parallelism is what bounds these kernels,
+// and 32 rows at once did not fit 128 registers); the keys are not kept: the key planes load them again (from L2).
+constexpr int H = 16;
+template <bool K64, bool FULL>
+__device__ inline void scatter_tile(const key_t_<K64>* __restrict__ keys, const Planes& pl, uint32_t NB, uint64_t rb, uint32_t nrows, uint32_t* stage, uint32_t* lb, uint32_t* gd, uint32_t* wsum) {
+    for (uint32_t b = threadIdx.x; b <= NB; b += SB) lb[b] = 0;
+    __syncthreads();
+    uint32_t pos[SR];                                         // (bin << 15) | rank, later the staged position
+#pragma unroll
+    for (int h = 0; h < SR; h += H) {
+        key_t_<K64> key[H];
+        load_rows<FULL>(keys, rb, nrows, h, key);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < H; ++r) {
+            const uint32_t d = __umulhi(key_hash<K64>(key[r]), NB);
+            pos[h + r] = FULL || tile_row(h + r) < nrows ? (d << 15) | atomicAdd(&lb[d], 1u) : 0xFFFFFFFFu;
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the bin counts: a thread owns bins 4 tid .. 4 tid + 3 (NB <= 4096)
+        uint32_t c[4], s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t b = threadIdx.x * 4 + k; c[k] = b < NB ? lb[b] : 0; s += c[k]; }
+        const uint32_t incl = wave_scan_incl(s, OpAdd{}, lane_id());
+        if (lane_id() == 63) wsum[wave_id()] = incl;
+        __syncthreads();
+        uint32_t base = incl - s;
+        for (int w = 0; w < wave_id(); ++w) base += wsum[w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t b = threadIdx.x * 4 + k;
+            if (b < NB) { lb[b] = base; gd[b] -= base; }
+            base += c[k];
+        }
+        if (threadIdx.x == SB - 1) lb[NB] = base;             // == nrows
+    }
+    __syncthreads();
+    // staged position of every row (two 15-bit positions per register); the bin of every staged position goes through the
+    // stage buffer to the lane that will stream that position out (two 12-bit bin ids per register): the destination of
+    // staged position j is j + gd[bin(j)]
+    uint32_t ppos[SR / 2];
+#pragma unroll
+    for (int r = 0; r < SR; ++r) {
+        uint32_t p = 0;
+        if (FULL || pos[r] != 0xFFFFFFFFu) {
+            const uint32_t d = pos[r] >> 15;
+            p = lb[d] + (pos[r] & 0x7FFFu);
+            stage[p] = d;
+        }
+        if (r & 1) ppos[r >> 1] |= p << 16; else ppos[r >> 1] = p;
+    }
+    __syncthreads();
+    uint32_t pbin[SR / 2];
+#pragma unroll
+    for (int i = 0; i < SR; ++i) {
+        const uint32_t j = i * SB + threadIdx.x;
+        const uint32_t d = FULL || j < nrows ? stage[j] : 0;
+        if (i & 1) pbin[i >> 1] |= d << 16; else pbin[i >> 1] = d;
+    }
+#pragma nounroll
+    for (int ci = 0; ci < pl.n; ++ci) {
+        const Plane& P = pl.p[ci];
+        __syncthreads();                       // the previous plane (or the bin ids) has left `stage`
+#pragma unroll
+        for (int h = 0; h < SR; h += H) {
+            uint32_t v[H];
+            if (P.kind == PL_ROWIDX) {
+#pragma unroll
+                for (int r = 0; r < H; ++r) v[r] = (uint32_t)rb + tile_row(h + r);
+            } else if (P.src_stride_dw == 1) {
+                load_rows<FULL>(P.src, rb, nrows, h, v);
+            } else {                                   // one half of every element of an 8-byte column
+                const uint32_t* tp = P.src + 2 * rb + P.src_off_dw;
+#pragma unroll
+                for (int r = 0; r < H; ++r) { const uint32_t o = tile_row(h + r); v[r] = tp[2 * (size_t)(FULL || o < nrows ? o : nrows - 1)]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < H; ++r) if (FULL || tile_row(h + r) < nrows) stage[(ppos[(h + r) >> 1] >> (((h + r) & 1) * 16)) & 0xFFFFu] = v[r];
+        }
+        __syncthreads();
+        uint32_t* dst = P.dst + P.dst_off_dw;
+        const uint32_t dstride = (uint32_t)P.dst_stride_dw;
+#pragma unroll
+        for (int i = 0; i < SR; ++i) {
+            const uint32_t j = i * SB + threadIdx.x;
+            if (FULL || j < nrows) dst[(size_t)(j + gd[(pbin[i >> 1] >> ((i & 1) * 16)) & 0xFFFFu]) * dstride] = stage[j];
+        }
+    }
+    __syncthreads();
+    // cursors for the next tile: cursor + count = (cursor - lb[b]) + lb[b + 1]
+    for (uint32_t b = threadIdx.x; b < NB; b += SB) gd[b] += lb[b + 1];
+    __syncthreads();
+}
+
+template <bool K64>
+__global__ void __launch_bounds__(SB) p1_scatter_kernel(const key_t_<K64>* __restrict__ keys, Planes pl, Chunks ch, const uint32_t* __restrict__ hist_scanned) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);      // [PT] one plane of the tile, bin-major
+    uint32_t* lb = stage + PT;                                    // [nbins + 1] counts, then first staged position of every bin
+    uint32_t* gd = lb + (ch.nbins + 1);                           // [nbins] between tiles: global cursor; inside: cursor - lb
+    __shared__ uint32_t wsum[SB / 64];
+    const uint32_t NB = ch.nbins;
+    uint64_t cb, ce;
+    chunk_range(ch, blockIdx.x, cb, ce);
+    for (uint32_t b = threadIdx.x; b < NB; b += SB) gd[b] = hist_scanned[(size_t)b * ch.nchunks + blockIdx.x];
+    for (uint64_t rb = cb; rb + PT <= ce; rb += PT) scatter_tile<K64, true>(keys, pl, NB, rb, PT, stage, lb, gd, wsum);
+}
+// the tail chunk: fewer rows than a tile (one workgroup, once per call)
+template <bool K64>
+__global__ void __launch_bounds__(SB) p1_scatter_tail_kernel(const key_t_<K64>* __restrict__ keys, Planes pl, Chunks ch, const uint32_t* __restrict__ hist_scanned) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);
+    uint32_t* lb = stage + PT;
+    uint32_t* gd = lb + (ch.nbins + 1);
+    __shared__ uint32_t wsum[SB / 64];
+    const uint32_t NB = ch.nbins, c = ch.nchunks - 1;
+    for (uint32_t b = threadIdx.x; b < NB; b += SB) gd[b] = hist_scanned[(size_t)b * ch.nchunks + c];
+    scatter_tile<K64, false>(keys, pl, NB, ch.nfull, ch.n - ch.nfull, stage, lb, gd, wsum);
+}
+
+// ---- aggregate each partition in LDS ---------------------------------------------------------------------------------------------
+struct AggIn { const void* col[MAXACC]; int esz[MAXACC]; };   // partitioned value arrays (4- or 8-byte elements); null: the row id
+constexpr uint32_t ID_PENDING = 0xFFFFu, ID_OVER = 0xFFFEu;
+
+__device__ inline uint64_t val_operand_bits(int dt, uint64_t bits, int kind, int square, int part) {
+    switch (dt) {
+    case AQG_INT8: return val_operand_t((int8_t)bits, kind, square);
+    case AQG_INT16: return val_operand_t((int16_t)bits, kind, square);
+    case AQG_INT32: return val_operand_t((int32_t)bits, kind, square);
+    case AQG_INT64: return val_operand_t((int64_t)bits, kind, square, part);
+    case AQG_UINT8: case AQG_BOOL: return val_operand_t((uint8_t)bits, kind, square);
+    case AQG_UINT16: return val_operand_t((uint16_t)bits, kind, square);
+    case AQG_UINT32: return val_operand_t((uint32_t)bits, kind, square);
+    case AQG_UINT64: return val_operand_t((uint64_t)bits, kind, square, part);
+    case AQG_FLOAT: return val_operand_t(__uint_as_float((uint32_t)bits), kind, square);
+    default: return val_operand_t(__builtin_bit_cast(double, bits), kind, square);
+    }
+}
+
+template <bool K64> __device__ inline key_t_<K64> empty_key() { if constexpr (K64) return EMPTY64; else return EMPTY32; }
+
+constexpr int AR = 4;      // consecutive rows per lane and step (one 16-byte load per 4-byte plane)
+// LDS: keytab K[cap] | first u32[gmax] | count u32[gmax] (need_count) | acc u64[NACC][gmax] | idtab u16[cap]
+// dense id 0 is reserved for the group whose packed key equals the empty mark.
+template <int NACC, bool K64>
+__global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rkeys, const uint32_t* __restrict__ rrows, AccSpec as, AggIn in,
+                                                    const uint32_t* __restrict__ pstart, uint32_t pstride, uint32_t NB, uint32_t ntotal, uint32_t cap, uint32_t gmax, int need_count,
+                                                    GTable out, uint32_t out_cap) {
+    using K = key_t_<K64>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint64_t* lacc = reinterpret_cast<uint64_t*>(smem_raw);                       // [NACC][gmax]
+    K* ktab = reinterpret_cast<K*>(lacc + (size_t)NACC * gmax);                   // [cap]
+    uint32_t* lfirst = reinterpret_cast<uint32_t*>(ktab + cap);                   // [gmax]
+    uint32_t* lcount = lfirst + gmax;                                             // [gmax] (only when need_count)
+    uint16_t* idtab = reinterpret_cast<uint16_t*>(lcount + (need_count ? gmax : 0));   // [cap]
+    __shared__ uint32_t lused, lemit, gbase;
+    const K EMPTYK = empty_key<K64>();
+    for (uint32_t part = blockIdx.x; part < NB; part += gridDim.x) {
+        const uint32_t b = pstart[(size_t)part * pstride];
+        const uint32_t e = part + 1 < NB ? pstart[(size_t)(part + 1) * pstride] : ntotal;
+        if (b == e) continue;
+        for (uint32_t s = threadIdx.x; s < cap; s += SB) { ktab[s] = EMPTYK; idtab[s] = (uint16_t)ID_PENDING; }
+        for (uint32_t g = threadIdx.x; g < gmax; g += SB) {
+            lfirst[g] = NOROW;
+            if (need_count) lcount[g] = 0;
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) lacc[(size_t)a * gmax + g] = acc_init(as.kind[a]);
+        }
+        if (threadIdx.x == 0) { lused = 1; lemit = 0; }
+        __syncthreads();
+        for (uint32_t i0 = b; i0 < e; i0 += SB * AR) {
+            const uint32_t o = i0 + threadIdx.x * AR;
+            const bool full = o + AR <= e;
+            K key[AR];
+            uint32_t row[AR];
+            uint64_t vb[NACC ? NACC : 1][AR];
+            bool live[AR];
+#pragma unroll
+            for (int q = 0; q < AR; ++q) live[q] = o + q < e;
+            if (full) {
+                __builtin_memcpy(key, static_cast<const K*>(rkeys) + o, sizeof key);
+                __builtin_memcpy(row, rrows + o, sizeof row);
+            } else {
+#pragma unroll
+                for (int q = 0; q < AR; ++q) { const uint32_t i = live[q] ? o + q : e - 1; key[q] = static_cast<const K*>(rkeys)[i]; row[q] = rrows[i]; }
+            }
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                if (!in.col[a]) {
+#pragma unroll
+                    for (int q = 0; q < AR; ++q) vb[a][q] = row[q];
+                } else if (in.esz[a] == 4) {
+                    uint32_t t[AR];
+                    if (full) __builtin_memcpy(t, static_cast<const uint32_t*>(in.col[a]) + o, sizeof t);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < AR; ++q) t[q] = static_cast<const uint32_t*>(in.col[a])[live[q] ? o + q : e - 1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < AR; ++q) vb[a][q] = t[q];
+                } else {
+                    if (full) __builtin_memcpy(vb[a], static_cast<const uint64_t*>(in.col[a]) + o, sizeof(uint64_t) * AR);
+                    else {
+#pragma unroll
+                        for (int q = 0; q < AR; ++q) vb[a][q] = static_cast<const uint64_t*>(in.col[a])[live[q] ? o + q : e - 1];
+                    }
+                }
+            }
+            uint32_t slot[AR];
+            K w[AR];
+#pragma unroll
+            for (int q = 0; q < AR; ++q) { slot[q] = __umulhi(key_hash<K64>(key[q]) * NB, cap); w[q] = ktab[slot[q]]; }   // AR probes in flight
+            uint32_t pend = 0, special = 0;
+#pragma unroll
+            for (int q = 0; q < AR; ++q) {
+                if (!live[q]) slot[q] = FAIL;
+                else if (key[q] == EMPTYK) special |= 1u << q;
+                else if (w[q] != key[q]) pend |= 1u << q;
+            }
+            // rows that missed on their first probe walk their probe sequences together: one LDS round trip per step
+            for (uint32_t step = 0; pend && step <= cap; ++step) {
+#pragma unroll
+                for (int q = 0; q < AR; ++q) {
+                    if (!(pend & (1u << q))) continue;
+                    K cur = w[q];
+                    if (cur == EMPTYK) {
+                        if constexpr (K64) cur = atomicCAS(reinterpret_cast<unsigned long long*>(&ktab[slot[q]]), (unsigned long long)EMPTYK, (unsigned long long)key[q]);
+                        else cur = atomicCAS(&ktab[slot[q]], EMPTYK, key[q]);
+                        if (cur == EMPTYK) {
+                            const uint32_t id = atomicAdd(&lused, 1u);
+                            idtab[slot[q]] = (uint16_t)(id < gmax ? id : ID_OVER);
+                            cur = key[q];
+                        }
+                    }
+                    if (cur == key[q]) { pend &= ~(1u << q); continue; }
+                    slot[q] = slot[q] + 1 == cap ? 0 : slot[q] + 1;
+                }
+#pragma unroll
+                for (int q = 0; q < AR; ++q) if (pend & (1u << q)) w[q] = ktab[slot[q]];
+            }
+            uint32_t id[AR];
+#pragma unroll
+            for (int q = 0; q < AR; ++q) {
+                if (special & (1u << q)) { id[q] = 0; continue; }
+                if (slot[q] == FAIL || (pend & (1u << q))) { id[q] = ID_OVER; if (slot[q] != FAIL) out.flags[0] = 1; continue; }
+                const volatile uint16_t* ip = idtab + slot[q];
+                uint32_t v = *ip;
+                while (v == ID_PENDING) { __builtin_amdgcn_s_sleep(1); v = *ip; }   // the inserting lane (of another wavefront) is about to publish it
+                id[q] = v;
+                if (v == ID_OVER) out.flags[0] = 1;                                // more groups than the dense arrays hold: the host re-plans
+            }
+#pragma unroll
+            for (int q = 0; q < AR; ++q) if (id[q] != ID_OVER && row[q] < lfirst[id[q]]) atomicMin(&lfirst[id[q]], row[q]);
+            if (need_count) {
+#pragma unroll
+                for (int q = 0; q < AR; ++q) if (id[q] != ID_OVER) atomicAdd(&lcount[id[q]], 1u);
+            }
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+#pragma unroll
+                for (int q = 0; q < AR; ++q)
+                    if (id[q] != ID_OVER) acc_apply(&lacc[(size_t)a * gmax + id[q]], as.kind[a], val_operand_bits(as.dt[a] == AQG_NONE ? AQG_UINT32 : as.dt[a], vb[a][q], as.kind[a], as.square[a], as.part[a]));
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t used = (lused < gmax ? lused : gmax) - 1 + (lfirst[0] != NOROW ? 1u : 0u);
+            gbase = atomicAdd(&out.flags[1], used);
+        }
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s <= cap; s += SB) {
+            uint32_t id; uint64_t k;
+            if (s == cap) { if (lfirst[0] == NOROW) continue; id = 0; k = K64 ? EMPTY64 : (uint64_t)EMPTY32; }
+            else { if (ktab[s] == EMPTYK) continue; id = idtab[s]; k = (uint64_t)ktab[s]; if (id >= gmax) continue; }
+            const uint32_t g = gbase + atomicAdd(&lemit, 1u);
+            if (g >= out_cap) { out.flags[0] = 1; continue; }
+            *out.key_p(g) = k;
+            *out.first_p(g) = lfirst[id];
+            *out.count_p(g) = need_count ? lcount[id] : 0;
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) *out.acc_p(a, g) = lacc[(size_t)a * gmax + id];
+        }
+        __syncthreads();
+    }
+}
+
+
+// ==== two levels (more partitions than one level writes well) ==================================================================
+// The run a tile writes per bin and plane is (LDS staging bytes / bins) long: 3000 bins leave 44-byte runs, and partial lines are
+// what the memory system charges for (measured at 1e9 rows, 5 planes: the one-level scatter takes 8.0 ms at 64 bins, 10.6 at 256,
+// 17 at 1024, 31 at 2900 -- the bytes at the L2 / fabric interface only grow from 41 to 53 GB).  Beyond ~1000 partitions the rows
+// therefore move TWICE, through <= 64 coarse and then 64 fine bins per coarse one, in runs of a kilobyte:
+//   p2_hist      sizes of the P fine partitions (P = 64 B1; LDS counters per workgroup, merged with global atomics)
+//   p2_setup     exclusive scan -> partition starts; the write cursors of both levels
+//   p2_scatter   level 1: user columns -> buffer set A by coarse bin; level 2: set A -> set B by fine bin inside each coarse
+//                partition.  A tile is independent: it ranks its rows inside their bins (LDS atomics), RESERVES its run of every
+//                bin with one global atomicAdd on that bin's cursor, stages each plane bin-major and streams it out.  No per-tile
+//                histogram, no scan between the levels; rows inside a partition end up in arrival order (the aggregation does not
+//                care: first rows come from the carried row ids).
+//   p1_agg       as for one level, over the P fine partitions
+struct P2Level {
+    const uint32_t* seg_start;    // [nseg + 1] rows of every segment (level 1: the whole input; level 2: the coarse partitions)
+    const uint32_t* tile_prefix;  // [nseg + 1] first tile of every segment
+    uint32_t* cursor;             // write cursors: level 1 [B1], level 2 [P]
+    uint32_t nseg, P, shift, mask, nbins, cursor_per_seg;
+};
+
+template <int TB> __device__ inline uint32_t trow(int r) { return (uint32_t)(r >> 2) * (TB * 4) + threadIdx.x * 4 + (r & 3); }
+template <int TB, bool FULL, class T, int R> __device__ inline void load_rows_t(const T* __restrict__ p, size_t tile_first, uint32_t nrows, int r0, T (&t)[R]) {
+    const T* tp = p + tile_first;
+    if constexpr (FULL) {
+#pragma unroll
+        for (int c = 0; c < R / 4; ++c) __builtin_memcpy(&t[4 * c], tp + trow<TB>(r0 + 4 * c), 4 * sizeof(T));
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { const uint32_t o = trow<TB>(r0 + r); t[r] = tp[o < nrows ? o : nrows - 1]; }
+    }
+}
+
+constexpr int HB = 16;    // rows per thread and step of the fine histogram
+template <bool K64>
+__global__ void __launch_bounds__(1024) p2_hist_kernel(const key_t_<K64>* __restrict__ keys, uint32_t n, uint32_t P, uint32_t* __restrict__ ftot) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);
+    for (uint32_t b = threadIdx.x; b < P; b += 1024) cnt[b] = 0;
+    __syncthreads();
+    const uint64_t step = (uint64_t)1024 * HB;
+    for (uint64_t rb = (uint64_t)blockIdx.x * step; rb < n; rb += (uint64_t)gridDim.x * step) {
+        const uint32_t nrows = n - rb < step ? (uint32_t)(n - rb) : (uint32_t)step;
+        key_t_<K64> key[HB];
+        if (nrows == step) load_rows_t<1024, true>(keys, rb, nrows, 0, key); else load_rows_t<1024, false>(keys, rb, nrows, 0, key);
+#pragma unroll
+        for (int r = 0; r < HB; ++r) if (trow<1024>(r) < nrows) atomicAdd(&cnt[__umulhi(key_hash<K64>(key[r]), P)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < P; b += 1024) { const uint32_t c = cnt[b]; if (c) atomicAdd(&ftot[b], c); }
+}
+
+// one workgroup: fstart = exclusive scan of the P partition sizes (P <= 4096); segments, tile counts and cursors of both levels
+__global__ void __launch_bounds__(1024) p2_setup_kernel(const uint32_t* __restrict__ ftot, uint32_t P, uint32_t n, uint32_t tile_rows,
+                                                        uint32_t* __restrict__ fstart /* [P + 1] */, uint32_t* __restrict__ cur2 /* [P] */,
+                                                        uint32_t* __restrict__ seg1 /* [2] */, uint32_t* __restrict__ tp1 /* [2] */, uint32_t* __restrict__ cur1 /* [P / 64] */,
+                                                        uint32_t* __restrict__ seg2 /* [P / 64 + 1] */, uint32_t* __restrict__ tp2 /* [P / 64 + 1] */) {
+    __shared__ uint32_t wsum[16], fs[4097], tcount[65];
+    uint32_t c[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint32_t b = threadIdx.x * 4 + k; c[k] = b < P ? ftot[b] : 0; s += c[k]; }
+    const uint32_t incl = wave_scan_incl(s, OpAdd{}, lane_id());
+    if (lane_id() == 63) wsum[wave_id()] = incl;
+    __syncthreads();
+    uint32_t base = incl - s;
+    for (int w = 0; w < wave_id(); ++w) base += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t b = threadIdx.x * 4 + k;
+        if (b < P) { fstart[b] = base; cur2[b] = base; fs[b] = base; }
+        base += c[k];
+    }
+    if (threadIdx.x == 0) { fstart[P] = n; fs[P] = n; seg1[0] = 0; seg1[1] = n; tp1[0] = 0; tp1[1] = (uint32_t)(((uint64_t)n + tile_rows - 1) / tile_rows); }
+    __syncthreads();
+    const uint32_t B1 = P >> 6;
+    if (threadIdx.x <= B1) { seg2[threadIdx.x] = fs[threadIdx.x << 6]; if (threadIdx.x < B1) cur1[threadIdx.x] = fs[threadIdx.x << 6]; }
+    if (threadIdx.x < 64) {
+        const uint32_t len = threadIdx.x < B1 ? fs[(threadIdx.x + 1) << 6] - fs[threadIdx.x << 6] : 0;
+        const uint32_t t = (uint32_t)(((uint64_t)len + tile_rows - 1) / tile_rows);
+        const uint32_t ti = wave_scan_incl(t, OpAdd{}, lane_id());
+        tp2[threadIdx.x] = ti - t;
+        if (threadIdx.x == 63) tcount[0] = ti;
+        if (threadIdx.x + 1 == B1) tp2[B1] = ti;
+    }
+}
+
+// FULL: grid over all tiles of all segments, whole tiles only.  !FULL: one workgroup per segment takes its last, partial tile.
+template <int TB, int TR, bool K64, bool FULL>
+__global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 64 / 4 : 1) p2_scatter_kernel(const key_t_<K64>* __restrict__ keys, Planes pl, P2Level lv) {
+    constexpr int TPT = TB * TR;
+    constexpr int HH = TR < 16 ? TR : 16;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);      // [TPT]
+    __shared__ uint32_t lb[65], gd[64];
+    uint32_t seg, rb, nrows;
+    if constexpr (FULL) {
+        const uint32_t t = blockIdx.x;
+        if (t >= lv.tile_prefix[lv.nseg]) return;
+        uint32_t lo = 0, hi = lv.nseg;                           // largest segment with tile_prefix[seg] <= t
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lv.tile_prefix[mid] <= t) lo = mid; else hi = mid; }
+        seg = lo;
+        const uint64_t b = (uint64_t)lv.seg_start[seg] + (uint64_t)(t - lv.tile_prefix[seg]) * TPT;
+        if (b + TPT > lv.seg_start[seg + 1]) return;             // the partial tile of the segment: the tail launch
+        rb = (uint32_t)b; nrows = TPT;
+    } else {
+        seg = blockIdx.x;
+        const uint32_t len = lv.seg_start[seg + 1] - lv.seg_start[seg];
+        nrows = len % TPT;
+        if (!nrows) return;
+        rb = lv.seg_start[seg + 1] - nrows;
+    }
+    const uint32_t NB = lv.nbins;
+    if (threadIdx.x <= 64) lb[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t pos[TR];                                         // (bin << 15) | rank, later the staged position
+#pragma unroll
+    for (int h = 0; h < TR; h += HH) {
+        key_t_<K64> key[HH];
+        load_rows_t<TB, FULL>(keys, rb, nrows, h, key);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < HH; ++r) {
+            const uint32_t d = (__umulhi(key_hash<K64>(key[r]), lv.P) >> lv.shift) & lv.mask;
+            pos[h + r] = FULL || trow<TB>(h + r) < nrows ? (d << 15) | atomicAdd(&lb[d], 1u) : 0xFFFFFFFFu;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // first wavefront: exclusive scan of the bin counts; reserve this tile's run of every bin
+        const uint32_t c = threadIdx.x < NB ? lb[threadIdx.x] : 0;
+        const uint32_t excl = wave_scan_incl(c, OpAdd{}, lane_id()) - c;
+        const uint32_t base = c ? atomicAdd(&lv.cursor[(size_t)seg * lv.cursor_per_seg + threadIdx.x], c) : 0;
+        lb[threadIdx.x] = excl;
+        gd[threadIdx.x] = base - excl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < TR; ++r) {
+        if (FULL || pos[r] != 0xFFFFFFFFu) {
+            const uint32_t d = pos[r] >> 15, p = lb[d] + (pos[r] & 0x7FFFu);
+            pos[r] = p;
+            stage[p] = d;
+        }
+    }
+    __syncthreads();
+    uint32_t dlt[TR];                                         // destination row minus staged position, per output position
+#pragma unroll
+    for (int i = 0; i < TR; ++i) { const uint32_t j = i * TB + threadIdx.x; dlt[i] = FULL || j < nrows ? gd[stage[j]] : 0; }
+#pragma nounroll
+    for (int ci = 0; ci < pl.n; ++ci) {
+        const Plane& Q = pl.p[ci];
+        __syncthreads();                       // the previous plane (or the bin ids) has left `stage`
+#pragma unroll
+        for (int h = 0; h < TR; h += HH) {
+            uint32_t v[HH];
+            if (Q.kind == PL_ROWIDX) {
+#pragma unroll
+                for (int r = 0; r < HH; ++r) v[r] = rb + trow<TB>(h + r);
+            } else if (Q.src_stride_dw == 1) {
+                load_rows_t<TB, FULL>(Q.src, rb, nrows, h, v);
+            } else {                                   // one half of every element of an 8-byte column
+                const uint32_t* tp = Q.src + 2 * (size_t)rb + Q.src_off_dw;
+#pragma unroll
+                for (int r = 0; r < HH; ++r) { const uint32_t o = trow<TB>(h + r); v[r] = tp[2 * (size_t)(FULL || o < nrows ? o : nrows - 1)]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < HH; ++r) if (FULL || pos[h + r] != 0xFFFFFFFFu) stage[pos[h + r]] = v[r];
+        }
+        __syncthreads();
+        uint32_t* dst = Q.dst + Q.dst_off_dw;
+        const uint32_t dstride = (uint32_t)Q.dst_stride_dw;
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+            const uint32_t j = i * TB + threadIdx.x;
+            if (FULL || j < nrows) dst[(size_t)(j + dlt[i]) * dstride] = stage[j];
+        }
+    }
+}
+
+size_t part_val_bytes(int dt) { return aqg_dtype_size(dt) <= 4 ? 4 : 8; }   // narrow values travel widened to one dword
+constexpr size_t AGG_LDS = 150 * 1024;
+constexpr uint32_t LF1000 = 500;    // load factor of the key table
+
+} // namespace
+
+// groups one partition's LDS holds, and its key-table capacity, for (ksz, as, need_count)
+static void p1_capacity(int ksz, const AccSpec& as, int need_count, uint32_t* gmax, uint32_t* cap) {
+    static const int lf_env = getenv("AQG_P1_LF1000") ? atoi(getenv("AQG_P1_LF1000")) : 0;
+    const uint32_t lf = lf_env > 0 ? (uint32_t)lf_env : LF1000;
+    const double dense = 4.0 + (need_count ? 4.0 : 0.0) + 8.0 * as.nacc;
+    const double slot = (double)(ksz + 2) * 1000.0 / lf;
+    uint32_t g = (uint32_t)((double)(AGG_LDS - 64) / (dense + slot));
+    if (g > 65000) g = 65000;                 // dense ids are 16 bits
+    g &= ~3u;
+    *gmax = g;
+    *cap = ((uint32_t)((uint64_t)g * 1000 / lf) + 7) & ~7u;
+}
+
+// number of partitions for `hint` expected groups: mean + 5 sigma of a partition's group count must fit gmax (0: no plan)
+uint32_t aqg_partition_parts(int ksz, const AccSpec& as, int need_count, uint32_t hint) {
+    uint32_t gmax, cap;
+    p1_capacity(ksz, as, need_count, &gmax, &cap);
+    // mu + 5 sqrt(mu) <= gmax - 1
+    double mu = (double)gmax - 1.0;
+    for (int it = 0; it < 8; ++it) mu = (double)gmax - 1.0 - 5.0 * sqrt(mu);
+    if (mu < 16) return 0;
+    uint64_t bins = (uint64_t)((double)hint / mu) + 1;
+    if (bins < 256) bins = 256;               // every CU gets a partition
+    { static const int forced = getenv("AQG_P1_BINS") ? atoi(getenv("AQG_P1_BINS")) : 0; if (forced > 0) bins = (uint64_t)forced; }   // measurements only
+    return bins <= (1u << 20) ? (uint32_t)bins : 0;
+}
+
+static void p1_geometry(const aqg_ctx* ctx, uint32_t n, Chunks* ch) {
+    const uint64_t tiles = (uint64_t)n / PT;                                 // whole tiles
+    const uint64_t target = (uint64_t)ctx->num_cu * 4;                       // chunks: four rounds of one workgroup per CU
+    uint64_t tiles_per_chunk = (tiles + target - 1) / target;
+    if (tiles_per_chunk < 1) tiles_per_chunk = 1;
+    ch->n = n;
+    ch->nfull = (uint32_t)(tiles * PT);
+    ch->has_tail = ch->nfull != n;
+    ch->chunk_rows = (uint32_t)(tiles_per_chunk * PT);
+    ch->nchunks = (uint32_t)((tiles + tiles_per_chunk - 1) / tiles_per_chunk) + ch->has_tail;
+    ch->nbins = 0;
+}
+
+// distinct value columns of `as` (an accumulator over the row index has none)
+struct ValCols { int n; const void* col[MAXACC]; int dt[MAXACC]; int of_acc[MAXACC]; };
+static void p1_val_cols(const AccSpec& as, ValCols* vc) {
+    vc->n = 0;
+    for (int a = 0; a < as.nacc; ++a) {
+        vc->of_acc[a] = -1;
+        if (as.dt[a] == AQG_NONE) continue;
+        for (int u = 0; u < vc->n; ++u) if (vc->col[u] == as.col[a]) vc->of_acc[a] = u;
+        if (vc->of_acc[a] < 0) { vc->col[vc->n] = as.col[a]; vc->dt[vc->n] = as.dt[a]; vc->of_acc[a] = vc->n++; }
+    }
+}
+static bool p1_key_is_column(const KeySpec& ks, int ksz) { return ks.nkeys == 1 && (int)aqg_dtype_size(ks.dt[0]) == ksz; }
+
+// aggregate the partitions [pstart[p * pstride], pstart[(p + 1) * pstride]) (the last one ends at n) of the partitioned planes
+static int p1_launch_agg(aqg_ctx* ctx, int ksz, const AccSpec& as, const ValCols& vc, const void* pkeys, const void* prows, void* const* pvals,
+                         const uint32_t* pstart, uint32_t pstride, uint32_t nparts, uint32_t n, int need_count, GTable out, uint32_t out_cap) {
+    AggIn in;
+    memset(&in, 0, sizeof in);
+    for (int a = 0; a < as.nacc; ++a) {
+        if (vc.of_acc[a] >= 0) { in.col[a] = pvals[vc.of_acc[a]]; in.esz[a] = (int)part_val_bytes(vc.dt[vc.of_acc[a]]); }
+        else { in.col[a] = nullptr; in.esz[a] = 4; }     // row-index operands: the carried row id
+    }
+    uint32_t gmax, cap;
+    p1_capacity(ksz, as, need_count, &gmax, &cap);
+    const size_t lds = (size_t)gmax * (4 + (need_count ? 4 : 0) + 8 * (size_t)as.nacc) + (size_t)cap * (ksz + 2) + 16;
+    const unsigned grid = nparts < (unsigned)ctx->num_cu ? nparts : (unsigned)ctx->num_cu;
+    auto launch = [&](auto kern) -> int {
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
+        aqg_kernel_timer_begin(ctx);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SB), lds, ctx->stream, pkeys, static_cast<const uint32_t*>(prows), as, in, pstart, pstride, nparts, n, cap, gmax, need_count, out, out_cap);
+        aqg_kernel_timer_end(ctx);
+        return aqg_check_launch(ctx, "p1_agg_kernel");
+    };
+#define AQG_P1_CASE(N) case N: return ksz == 4 ? launch(&p1_agg_kernel<N, false>) : launch(&p1_agg_kernel<N, true>);
+    switch (as.nacc) {
+    AQG_P1_CASE(0) AQG_P1_CASE(1) AQG_P1_CASE(2) AQG_P1_CASE(3) AQG_P1_CASE(4) AQG_P1_CASE(5) AQG_P1_CASE(6) AQG_P1_CASE(7)
+    default: return ksz == 4 ? launch(&p1_agg_kernel<8, false>) : launch(&p1_agg_kernel<8, true>);
+    }
+#undef AQG_P1_CASE
+}
+
+size_t aqg_partition1_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t nbins) {
+    const int ksz = ks.total_bytes <= 4 ? 4 : 8;
+    ValCols vc;
+    p1_val_cols(as, &vc);
+    size_t per_row = (size_t)ksz + 4;
+    if (!p1_key_is_column(ks, ksz)) per_row += ksz;                          // the packed key column
+    for (int u = 0; u < vc.n; ++u) per_row += part_val_bytes(vc.dt[u]) + (aqg_dtype_size(vc.dt[u]) < 4 ? 4 : 0);   // + the widened copy
+    Chunks ch;
+    p1_geometry(ctx, n, &ch);
+    const size_t hcount = (size_t)nbins * ch.nchunks;
+    return ((size_t)n + 64) * per_row + 256 * (4 + 2 * MAXACC) + hcount * 4 + (hcount / 2048 + 64) * 4 + 65536;
+}
+
+// Partitioned aggregation of (ks, as) over n rows into the compact record table `out` (AoS records, `out_cap` slots,
+// flags[1] = number of groups written, flags[0] = overflow).  Needs packed (<= 8 byte) keys and nbins from aqg_partition1_bins.
+int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap) {
+    if (nbins < 1 || nbins > AQG_P1_MAXBINS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "one-level partitioned group-by: 1..3584 bins");
+    const int ksz = ks.total_bytes <= 4 ? 4 : 8;
+    Chunks ch;
+    p1_geometry(ctx, n, &ch);
+    ch.nbins = nbins;
+    ValCols vc;
+    p1_val_cols(as, &vc);
+
+    // the key as ONE column of 4- or 8-byte words: the user's column, or the packed tuple
+    const void* keycol = ks.col[0];
+    if (!p1_key_is_column(ks, ksz)) {
+        void* packed;
+        AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * ksz, &packed));
+        const unsigned g = aqg_grid(ctx, n, 256, 4, 16);
+        if (ksz == 4) hipLaunchKernelGGL(p1_pack_keys_kernel<false>, dim3(g), dim3(256), 0, ctx->stream, ks, n, static_cast<uint32_t*>(packed));
+        else hipLaunchKernelGGL(p1_pack_keys_kernel<true>, dim3(g), dim3(256), 0, ctx->stream, ks, n, static_cast<uint64_t*>(packed));
+        keycol = packed;
+    }
+    void *pkeys, *prows, *pvals[MAXACC];
+    AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * ksz, &pkeys));
+    AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * 4, &prows));
+    const void* vsrc[MAXACC];
+    for (int u = 0; u < vc.n; ++u) {
+        AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * part_val_bytes(vc.dt[u]), &pvals[u]));
+        vsrc[u] = vc.col[u];
+        const int esz = (int)aqg_dtype_size(vc.dt[u]);
+        if (esz < 4) {                                                       // 1- / 2-byte values travel as dwords
+            void* wide;
+            AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * 4, &wide));
+            hipLaunchKernelGGL(p1_widen_kernel, dim3(aqg_grid(ctx, n, 256, 4, 16)), dim3(256), 0, ctx->stream, vc.col[u], esz, n, static_cast<uint32_t*>(wide));
+            vsrc[u] = wide;
+        }
+    }
+    const size_t hcount = (size_t)nbins * ch.nchunks;
+    uint32_t *hist, *bsum;
+    AQG_TRY(aqg_ws_get(ctx, hcount, &hist));
+    AQG_TRY(aqg_ws_get(ctx, hcount / 2048 + 64, &bsum));
+
+    Planes pl;
+    memset(&pl, 0, sizeof pl);
+    auto add = [&](int kind, const void* s, int sstride, int soff, void* d, int dstride, int doff) {
+        Plane& P = pl.p[pl.n++];
+        P.kind = kind; P.src = static_cast<const uint32_t*>(s); P.src_stride_dw = sstride; P.src_off_dw = soff;
+        P.dst = static_cast<uint32_t*>(d); P.dst_stride_dw = dstride; P.dst_off_dw = doff;
+    };
+    if (ksz == 4) add(PL_LOAD, keycol, 1, 0, pkeys, 1, 0);
+    else { add(PL_LOAD, keycol, 2, 0, pkeys, 2, 0); add(PL_LOAD, keycol, 2, 1, pkeys, 2, 1); }
+    add(PL_ROWIDX, nullptr, 0, 0, prows, 1, 0);
+    for (int u = 0; u < vc.n; ++u) {
+        if (part_val_bytes(vc.dt[u]) == 4) add(PL_LOAD, vsrc[u], 1, 0, pvals[u], 1, 0);
+        else { add(PL_LOAD, vsrc[u], 2, 0, pvals[u], 2, 0); add(PL_LOAD, vsrc[u], 2, 1, pvals[u], 2, 1); }
+    }
+    const size_t hist_lds = (size_t)nbins * 4;
+    const size_t scat_lds = (size_t)PT * 4 + ((size_t)nbins * 2 + 1) * 4;
+    const unsigned nmain = ch.nchunks - ch.has_tail;
+    auto run = [&](auto k64) -> int {
+        constexpr bool K = decltype(k64)::value;
+        const key_t_<K>* kc = static_cast<const key_t_<K>*>(keycol);
+        hipLaunchKernelGGL((p1_hist_kernel<K>), dim3(ch.nchunks), dim3(SB), hist_lds, ctx->stream, kc, ch, hist);
+        AQG_TRY(aqg_exclusive_scan_u32(ctx, hist, hcount, bsum));
+        if (nmain) {
+            AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p1_scatter_kernel<K>), scat_lds));
+            hipLaunchKernelGGL((p1_scatter_kernel<K>), dim3(nmain), dim3(SB), scat_lds, ctx->stream, kc, pl, ch, (const uint32_t*)hist);
+        }
+        if (ch.has_tail) {
+            AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p1_scatter_tail_kernel<K>), scat_lds));
+            hipLaunchKernelGGL((p1_scatter_tail_kernel<K>), dim3(1), dim3(SB), scat_lds, ctx->stream, kc, pl, ch, (const uint32_t*)hist);
+        }
+        return aqg_check_launch(ctx, "one-level partition scatter");
+    };
+    if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
+
+    return p1_launch_agg(ctx, ksz, as, vc, pkeys, prows, pvals, hist, ch.nchunks, nbins, n, need_count, out, out_cap);
+}
+
+
+// ---- two levels: host ---------------------------------------------------------------------------------------------------------------
+constexpr int P2_TB = 1024, P2_TR = 16, P2_PT = P2_TB * P2_TR;     // 16384-row tiles: 64 KB of staging, two workgroups per CU
+
+static uint32_t p2_round_parts(uint32_t parts) { return (parts + 63) & ~63u; }
+
+size_t aqg_partition2_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t parts) {
+    const int ksz = ks.total_bytes <= 4 ? 4 : 8;
+    ValCols vc;
+    p1_val_cols(as, &vc);
+    size_t per_row = 2 * ((size_t)ksz + 4);
+    if (!p1_key_is_column(ks, ksz)) per_row += ksz;
+    for (int u = 0; u < vc.n; ++u) per_row += 2 * part_val_bytes(vc.dt[u]) + (aqg_dtype_size(vc.dt[u]) < 4 ? 4 : 0);
+    return ((size_t)n + 64) * per_row + 256 * (8 + 4 * MAXACC) + (size_t)p2_round_parts(parts) * 16 + 65536;
+}
+
+int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap) {
+    const uint32_t P = p2_round_parts(parts), B1 = P >> 6;
+    if (P < 64 || P > AQG_P2_MAXPARTS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "two-level partitioned group-by: 64..4096 partitions");
+    const int ksz = ks.total_bytes <= 4 ? 4 : 8;
+    ValCols vc;
+    p1_val_cols(as, &vc);
+    const void* keycol = ks.col[0];
+    if (!p1_key_is_column(ks, ksz)) {
+        void* packed;
+        AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * ksz, &packed));
+        const unsigned g = aqg_grid(ctx, n, 256, 4, 16);
+        if (ksz == 4) hipLaunchKernelGGL(p1_pack_keys_kernel<false>, dim3(g), dim3(256), 0, ctx->stream, ks, n, static_cast<uint32_t*>(packed));
+        else hipLaunchKernelGGL(p1_pack_keys_kernel<true>, dim3(g), dim3(256), 0, ctx->stream, ks, n, static_cast<uint64_t*>(packed));
+        keycol = packed;
+    }
+    void *keysA, *rowsA, *valsA[MAXACC], *keysB, *rowsB, *valsB[MAXACC];
+    const void* vsrc[MAXACC];
+    AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * ksz, &keysA));
+    AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * 4, &rowsA));
+    AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * ksz, &keysB));
+    AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * 4, &rowsB));
+    for (int u = 0; u < vc.n; ++u) {
+        AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * part_val_bytes(vc.dt[u]), &valsA[u]));
+        AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * part_val_bytes(vc.dt[u]), &valsB[u]));
+        vsrc[u] = vc.col[u];
+        const int esz = (int)aqg_dtype_size(vc.dt[u]);
+        if (esz < 4) {
+            void* wide;
+            AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * 4, &wide));
+            hipLaunchKernelGGL(p1_widen_kernel, dim3(aqg_grid(ctx, n, 256, 4, 16)), dim3(256), 0, ctx->stream, vc.col[u], esz, n, static_cast<uint32_t*>(wide));
+            vsrc[u] = wide;
+        }
+    }
+    uint32_t *ftot, *fstart, *cur2, *seg1, *tp1, *cur1, *seg2, *tp2;
+    AQG_TRY(aqg_ws_get(ctx, (size_t)P, &ftot));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)P + 1, &fstart));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)P, &cur2));
+    AQG_TRY(aqg_ws_get(ctx, 2, &seg1));
+    AQG_TRY(aqg_ws_get(ctx, 2, &tp1));
+    AQG_TRY(aqg_ws_get(ctx, 64, &cur1));
+    AQG_TRY(aqg_ws_get(ctx, 65, &seg2));
+    AQG_TRY(aqg_ws_get(ctx, 65, &tp2));
+    AQG_HIP(ctx, hipMemsetAsync(ftot, 0, (size_t)P * 4, ctx->stream));
+
+    auto planes = [&](bool level1) {
+        Planes pl;
+        memset(&pl, 0, sizeof pl);
+        auto add = [&](int kind, const void* s, int sstride, int soff, void* d, int dstride, int doff) {
+            Plane& Q = pl.p[pl.n++];
+            Q.kind = kind; Q.src = static_cast<const uint32_t*>(s); Q.src_stride_dw = sstride; Q.src_off_dw = soff;
+            Q.dst = static_cast<uint32_t*>(d); Q.dst_stride_dw = dstride; Q.dst_off_dw = doff;
+        };
+        const void* ksrc = level1 ? keycol : keysA;
+        void* kdst = level1 ? keysA : keysB;
+        if (ksz == 4) add(PL_LOAD, ksrc, 1, 0, kdst, 1, 0);
+        else { add(PL_LOAD, ksrc, 2, 0, kdst, 2, 0); add(PL_LOAD, ksrc, 2, 1, kdst, 2, 1); }
+        if (level1) add(PL_ROWIDX, nullptr, 0, 0, rowsA, 1, 0); else add(PL_LOAD, rowsA, 1, 0, rowsB, 1, 0);
+        for (int u = 0; u < vc.n; ++u) {
+            const void* vs = level1 ? vsrc[u] : valsA[u];
+            void* vd = level1 ? valsA[u] : valsB[u];
+            if (part_val_bytes(vc.dt[u]) == 4) add(PL_LOAD, vs, 1, 0, vd, 1, 0);
+            else { add(PL_LOAD, vs, 2, 0, vd, 2, 0); add(PL_LOAD, vs, 2, 1, vd, 2, 1); }
+        }
+        return pl;
+    };
+    const size_t scat_lds = (size_t)P2_PT * 4;
+    const unsigned tiles1 = (unsigned)(((uint64_t)n + P2_PT - 1) / P2_PT), tiles2 = (unsigned)((uint64_t)n / P2_PT) + B1 + 1;
+    auto run = [&](auto k64) -> int {
+        constexpr bool K = decltype(k64)::value;
+        const unsigned hgrid = aqg_grid(ctx, n, 1024, HB, 4);
+        hipLaunchKernelGGL((p2_hist_kernel<K>), dim3(hgrid), dim3(1024), (size_t)P * 4, ctx->stream, static_cast<const key_t_<K>*>(keycol), n, P, ftot);
+        hipLaunchKernelGGL(p2_setup_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)ftot, P, n, (uint32_t)P2_PT, fstart, cur2, seg1, tp1, cur1, seg2, tp2);
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, K, true>), scat_lds));
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, K, false>), scat_lds));
+        P2Level l1{seg1, tp1, cur1, 1u, P, 6u, 0xFFFFFFFFu, B1, 0u};
+        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, true>), dim3(tiles1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keycol), planes(true), l1);
+        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, false>), dim3(1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keycol), planes(true), l1);
+        P2Level l2{seg2, tp2, cur2, B1, P, 0u, 63u, 64u, 64u};
+        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, true>), dim3(tiles2), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keysA), planes(false), l2);
+        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, false>), dim3(B1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keysA), planes(false), l2);
+        return aqg_check_launch(ctx, "two-level partition scatter");
+    };
+    if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
+    return p1_launch_agg(ctx, ksz, as, vc, keysB, rowsB, valsB, fstart, 1u, P, n, need_count, out, out_cap);
+}

@@ -1,0 +1,12 @@
+// partition1.hpp -- host entry points of the partition plans of partition1.hip, called by run_agg (groupby.hip)
+#pragma once
+#include "groupby_dev.hpp"
+
+constexpr uint32_t AQG_P1_MAXBINS = 3584;    // one level: scatter LDS = 128 KB of staging + 8 B per bin
+constexpr uint32_t AQG_P2_MAXPARTS = 4096;   // two levels: 64 x 64 bins
+// partitions needed for `hint` expected groups (mean + 5 sigma of a partition's groups fit its LDS tables); 0: none
+uint32_t aqg_partition_parts(int ksz, const AccSpec& as, int need_count, uint32_t hint);
+size_t aqg_partition1_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t nbins);
+int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap);
+size_t aqg_partition2_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t parts);
+int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap);
