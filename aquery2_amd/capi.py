@@ -397,6 +397,14 @@ class Device:
                                           C.byref(m)), "aqg_join_pairs")
         return pr.to_host(), br.to_host()
 
+    def join_count(self, build, probe):
+        """number of matching (probe row, build row) pairs, in 64 bits (aqg_join_count)"""
+        bd, pd = self._dev(build), self._dev(probe)
+        m = C.c_uint64()
+        self._chk(self.lib.aqg_join_count(self.ctx, bd.tag, C.c_void_p(bd.ptr), C.c_uint32(bd.n), C.c_void_p(pd.ptr),
+                                          C.c_uint32(pd.n), C.byref(m)), "aqg_join_count")
+        return m.value
+
     def join_lookup(self, build, probe):
         bd, pd = self._dev(build), self._dev(probe)
         out = self.empty(pd.n, np.uint32)

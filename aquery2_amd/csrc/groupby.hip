@@ -423,15 +423,18 @@ __global__ void __launch_bounds__(256) starjoin_kernel(const uint32_t* __restric
 // a workgroup stops as soon as its next tile starts beyond the largest candidate (no later row can lower any of them).
 __global__ void __launch_bounds__(256) first_rows_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_hi, int key8, uint32_t t0 /* first tile */, uint32_t n /* rows end */, GTable gt, const uint32_t* __restrict__ occ) {
     __shared__ uint32_t red[4];
-    __shared__ uint32_t stop;
+    __shared__ uint32_t stop, all_seen;
     const uint32_t G = gt.flags[1];
     constexpr int FR = 4;                      // rows per lane and tile: the first round covers gridDim x 1024 rows (16 rows: 28 us on h2o Q1)
     constexpr uint32_t TILE = 256 * FR;
     for (uint32_t t = t0 + blockIdx.x; (uint64_t)t * TILE < n; t += gridDim.x) {
         const uint32_t tbase = t * TILE;
-        if (threadIdx.x == 0) stop = 0;
+        // ONE lane samples the counter other workgroups keep incrementing: the branch below holds barriers, so every wavefront of
+        // the workgroup must take the same side of it (a per-lane load could split them: divergent barrier, stale `red` / `stop`)
+        if (threadIdx.x == 0) { stop = 0; all_seen = __hip_atomic_load(&gt.flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G; }
+        if (threadIdx.x < 4) red[threadIdx.x] = 0;
         __syncthreads();
-        if (__hip_atomic_load(&gt.flags[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G) {
+        if (all_seen) {
             uint32_t m = 0;
             for (uint32_t i = threadIdx.x; i < G; i += blockDim.x) {
                 uint32_t f = __hip_atomic_load(gt.first_p(occ[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1274,20 +1277,13 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     memset(&es, 0, sizeof es);
     es.nkeys = ks.nkeys;
     es.wide = ks.wide;
-    {
-        size_t kc[MAXKEYS];
-        for (int k = 0; k < ks.nkeys; ++k) {
-            h->key_dt[k] = ks.dt[k];
-            kc[k] = h->cap_groups * aqg_dtype_size(ks.dt[k]);
-            if (h->cap_groups < gcapn || !h->keys_out[k]) { size_t c = h->keys_out[k] ? kc[k] : 0; AQG_TRY(dev_realloc(ctx, &h->keys_out[k], &c, gcapn * 8)); }
-            es.key_dt[k] = ks.dt[k]; es.key_shift[k] = ks.shift[k]; es.key_out[k] = h->keys_out[k]; es.key_col[k] = ks.col[k];
-        }
-        if (h->cap_groups < gcapn || !h->first_rows) {
-            size_t c = h->first_rows ? h->cap_groups * 4 : 0; AQG_TRY(dev_realloc(ctx, (void**)&h->first_rows, &c, gcapn * 4));
-            c = h->counts ? h->cap_groups * 4 : 0; AQG_TRY(dev_realloc(ctx, (void**)&h->counts, &c, gcapn * 4));
-            if (h->cap_groups < gcapn) h->cap_groups = gcapn;
-        }
+    for (int k = 0; k < ks.nkeys; ++k) {
+        h->key_dt[k] = ks.dt[k];
+        AQG_TRY(dev_realloc(ctx, &h->keys_out[k], &h->cap_keys[k], gcapn * 8));
+        es.key_dt[k] = ks.dt[k]; es.key_shift[k] = ks.shift[k]; es.key_out[k] = h->keys_out[k]; es.key_col[k] = ks.col[k];
     }
+    AQG_TRY(dev_realloc(ctx, (void**)&h->first_rows, &h->cap_first, gcapn * 4));
+    AQG_TRY(dev_realloc(ctx, (void**)&h->counts, &h->cap_counts, gcapn * 4));
     es.first_out = h->first_rows;
     h->has_counts = plan.need_count && !for_build;
     es.count_out = h->has_counts ? h->counts : nullptr;
@@ -1481,16 +1477,9 @@ int aqg_groupby_merge_packed(aqg_ctx* ctx, const int64_t* gathered_dev, uint32_t
         // ---- a few small shard tables: one workgroup does the whole merge ------------------------------------------------
         const int mop = op == AQG_RED_COUNT ? AQG_RED_SUM : op;
         int rc = AQG_OK;
-        if (h->cap_groups < MERGE_ROWS || !h->keys_out[0] || !h->first_rows || !h->counts) {
-            for (int k = 0; k < MAXKEYS; ++k) if (h->keys_out[k]) { hipFree(h->keys_out[k]); h->keys_out[k] = nullptr; }
-            if (h->first_rows) { hipFree(h->first_rows); h->first_rows = nullptr; }
-            if (h->counts) { hipFree(h->counts); h->counts = nullptr; }
-            size_t c = 0;
-            rc = dev_realloc(ctx, &h->keys_out[0], &c, (size_t)MERGE_ROWS * 8);
-            c = 0; if (rc == AQG_OK) rc = dev_realloc(ctx, (void**)&h->first_rows, &c, (size_t)MERGE_ROWS * 4);
-            c = 0; if (rc == AQG_OK) rc = dev_realloc(ctx, (void**)&h->counts, &c, (size_t)MERGE_ROWS * 4);
-            if (rc == AQG_OK) h->cap_groups = MERGE_ROWS;
-        }
+        rc = dev_realloc(ctx, &h->keys_out[0], &h->cap_keys[0], (size_t)MERGE_ROWS * 8);
+        if (rc == AQG_OK) rc = dev_realloc(ctx, (void**)&h->first_rows, &h->cap_first, (size_t)MERGE_ROWS * 4);
+        if (rc == AQG_OK) rc = dev_realloc(ctx, (void**)&h->counts, &h->cap_counts, (size_t)MERGE_ROWS * 4);
         if (rc == AQG_OK) rc = dev_realloc(ctx, &h->results[0], &h->cap_results[0], (size_t)MERGE_ROWS * 16);
         if (rc == AQG_OK) rc = aqg_ws_reset(ctx);
         if (rc == AQG_OK) rc = aqg_ws_ensure(ctx, 4096);

@@ -20,7 +20,9 @@ struct aqg_groupby {
     void* results[MAXAGG] = {nullptr};
     int nagg = 0;
     int res_dt[MAXAGG] = {0};
-    size_t cap_groups = 0, cap_rows = 0, cap_results[MAXAGG] = {0};
+    // allocated BYTES of every group-sized buffer, each tracked by itself: a reused handle may gain a key column (or come from
+    // the small merge path, which keeps one) while others are already large
+    size_t cap_keys[MAXKEYS] = {0}, cap_first = 0, cap_counts = 0, cap_rows = 0, cap_results[MAXAGG] = {0};
     uint32_t hint_used = 0;
     bool dense_exact = false;         // a sampled key range missed values once: take exact ranges from now on
     aqg_groupby* scratch = nullptr;   // reusable handle for aqg_grouped_reduce

@@ -138,6 +138,13 @@ __global__ void __launch_bounds__(256) match_count_kernel(const uint32_t* __rest
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= np; i += gridDim.x * blockDim.x)
         cnt[i] = (i < np && gid[i] != NONE) ? counts[gid[i]] : 0;
 }
+// 64-bit total of the per-probe-row match counts (their 32-bit exclusive scan wraps beyond 2^32 matches: 70,000 x 70,000 equal keys)
+__global__ void __launch_bounds__(256) match_total_kernel(const uint32_t* __restrict__ cnt, uint32_t np, unsigned long long* __restrict__ total) {
+    unsigned long long s = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < np; i += gridDim.x * blockDim.x) s += cnt[i];
+    s = wave_reduce(s, OpAdd{});
+    if (lane_id() == 0 && s) atomicAdd(total, s);
+}
 __global__ void __launch_bounds__(256) expand_kernel(const uint32_t* __restrict__ gid, uint32_t np, const uint32_t* __restrict__ out_off,
                                                      const uint32_t* __restrict__ grp_off, const uint32_t* __restrict__ rows_desc,
                                                      uint32_t* __restrict__ probe_rows, uint32_t* __restrict__ build_rows) {
@@ -199,11 +206,13 @@ int join_core(aqg_ctx* ctx, int t, const void* bk, uint32_t nb, const void* pk, 
     if (rc != AQG_OK) { cleanup(); return rc; }
     // 2. distinct build key -> group id, probe
     rc = aqg_ws_reset(ctx);
-    size_t need = (size_t)pow2_at_least((uint64_t)G * 2) * 12 + ((size_t)np + 1) * 8 + (((size_t)np + 1) / 2048 + 2) * 4 + 16384;
+    size_t need = (size_t)pow2_at_least((uint64_t)G * 2) * 12 + ((size_t)np + 1) * 8 + (((size_t)np + 1) / 2048 + 2) * 4 + 16384 + 256;
     if (rc == AQG_OK) rc = aqg_ws_ensure(ctx, need);
     JTable jt;
     uint32_t *gid = nullptr, *cnt = nullptr, *bsum = nullptr;
+    unsigned long long* total = nullptr;
     if (rc == AQG_OK) rc = make_table(ctx, t, dkeys, G, &jt);
+    if (rc == AQG_OK) rc = aqg_ws_get(ctx, 1, &total);
     if (rc == AQG_OK) rc = aqg_ws_get(ctx, (size_t)np + 1, &gid);
     if (rc == AQG_OK) rc = aqg_ws_get(ctx, (size_t)np + 1, &cnt);
     if (rc == AQG_OK) rc = aqg_ws_get(ctx, ((size_t)np + 1) / 2048 + 2, &bsum);
@@ -211,13 +220,19 @@ int join_core(aqg_ctx* ctx, int t, const void* bk, uint32_t nb, const void* pk, 
     unsigned pg = aqg_grid(ctx, np, 256, 4, 8);
     launch_probe(ctx, t, pk, np, jt, gid);
     hipLaunchKernelGGL(match_count_kernel, dim3(pg), dim3(256), 0, ctx->stream, gid, np, aqg_groupby_counts(gb), cnt);
-    rc = aqg_exclusive_scan_u32(ctx, cnt, (uint64_t)np + 1, bsum);
-    uint32_t m32 = 0;
-    if (rc == AQG_OK) rc = aqg_d2h(ctx, &m32, cnt + np, 4);
+    // the number of matches in 64 bits, BEFORE the 32-bit offsets are trusted: with duplicate keys it passes 2^32 at small inputs
+    rc = hipMemsetAsync(total, 0, 8, ctx->stream) == hipSuccess ? AQG_OK : AQG_ERR_HIP;
+    if (rc == AQG_OK) hipLaunchKernelGGL(match_total_kernel, dim3(pg), dim3(256), 0, ctx->stream, (const uint32_t*)cnt, np, total);
+    unsigned long long m64 = 0;
+    if (rc == AQG_OK) rc = aqg_d2h(ctx, &m64, total, 8);
     if (rc != AQG_OK) { cleanup(); return rc; }
-    *m_host = m32;
-    if (probe_rows && build_rows && m32) {
-        if (capacity < m32) { cleanup(); return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_join_pairs: output capacity too small"); }
+    *m_host = m64;
+    if (probe_rows && build_rows && m64) {
+        // pairs are addressed by uint32 offsets like every row index of this library
+        if (m64 > (unsigned long long)AQG_MAX_ROWS) { cleanup(); return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_join_pairs: more than AQG_MAX_ROWS matching pairs (*m_host holds the count)"); }
+        if (capacity < m64) { cleanup(); return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_join_pairs: output capacity too small"); }
+        rc = aqg_exclusive_scan_u32(ctx, cnt, (uint64_t)np + 1, bsum);
+        if (rc != AQG_OK) { cleanup(); return rc; }
         hipLaunchKernelGGL(expand_kernel, dim3(pg), dim3(256), 0, ctx->stream, gid, np, cnt, grp_off, rows_desc, probe_rows, build_rows);
         rc = aqg_check_launch(ctx, "expand_kernel");
         if (rc == AQG_OK) rc = aqg_sync(ctx);

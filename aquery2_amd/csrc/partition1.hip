@@ -247,13 +247,22 @@ __device__ inline uint64_t val_operand_bits(int dt, uint64_t bits, int kind, int
 template <bool K64> __device__ inline key_t_<K64> empty_key() { if constexpr (K64) return EMPTY64; else return EMPTY32; }
 
 constexpr int AR = 4;      // consecutive rows per lane and step (one 16-byte load per 4-byte plane)
-// LDS: keytab K[cap] | first u32[gmax] | count u32[gmax] (need_count) | acc u64[NACC][gmax] | idtab u16[cap]
+// What an accumulator does with a row, decided once per call on the host: the common (kind, dtype) pairs get straight-line code,
+// everything else (squares, halves of 8-byte integers, 1- / 2-byte and 8-byte integer inputs) the generic operand switch.  The row
+// loop was VALU- and branch-bound with that switch evaluated per row and accumulator (h2o Q5, 1e9 rows: 9.1 ms for 20 GB).
+enum : int { OPC_ADDI_I32 = 0, OPC_ADDI_U32, OPC_ADDF_F32, OPC_ADDF_F64, OPC_MIN_I32, OPC_MAX_I32, OPC_MIN_U32, OPC_MAX_U32, OPC_MIN_F32, OPC_MAX_F32, OPC_GENERIC };
+struct AggOps { int opc[MAXACC]; };
+
+// LDS: acc u64[NACC][gmax] | keytab K[cap] | first u32[gmax] | count u32[gmax] (need_count) | idtab u16[cap]
 // dense id 0 is reserved for the group whose packed key equals the empty mark.
-template <int NACC, bool K64>
-__global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rkeys, const uint32_t* __restrict__ rrows, AccSpec as, AggIn in,
+// V8: some value plane has 8-byte elements (then every value travels through the loop as 64 bits)
+template <int NACC, bool K64, bool V8>
+__global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rkeys, const uint32_t* __restrict__ rrows, AccSpec as, AggIn in, AggOps ops,
                                                     const uint32_t* __restrict__ pstart, uint32_t pstride, uint32_t NB, uint32_t ntotal, uint32_t cap, uint32_t gmax, int need_count,
                                                     GTable out, uint32_t out_cap) {
     using K = key_t_<K64>;
+    using VT = std::conditional_t<V8, uint64_t, uint32_t>;
+    constexpr int NA = NACC ? NACC : 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint64_t* lacc = reinterpret_cast<uint64_t*>(smem_raw);                       // [NACC][gmax]
     K* ktab = reinterpret_cast<K*>(lacc + (size_t)NACC * gmax);                   // [cap]
@@ -262,10 +271,45 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
     uint16_t* idtab = reinterpret_cast<uint16_t*>(lcount + (need_count ? gmax : 0));   // [cap]
     __shared__ uint32_t lused, lemit, gbase;
     const K EMPTYK = empty_key<K64>();
+    struct Batch { K key[AR]; uint32_t row[AR]; VT v[NA][AR]; };
+    // rows o .. o + AR - 1 of this lane; beyond `e` a clamped index (every load is issued; the caller masks those rows)
+    auto load = [&](uint32_t i0, uint32_t e, Batch& t) {
+        const uint32_t o = i0 + threadIdx.x * AR;
+        if (o + AR <= e) {
+            __builtin_memcpy(t.key, static_cast<const K*>(rkeys) + o, sizeof t.key);
+            __builtin_memcpy(t.row, rrows + o, sizeof t.row);
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                if (!in.col[a]) continue;
+                if (!V8 || in.esz[a] == 4) {
+                    uint32_t w[AR];
+                    __builtin_memcpy(w, static_cast<const uint32_t*>(in.col[a]) + o, sizeof w);
+                    _Pragma("unroll") for (int q = 0; q < AR; ++q) t.v[a][q] = w[q];
+                } else {
+                    if constexpr (V8) __builtin_memcpy(t.v[a], static_cast<const uint64_t*>(in.col[a]) + o, sizeof(uint64_t) * AR);
+                }
+            }
+        } else {
+            _Pragma("unroll") for (int q = 0; q < AR; ++q) {
+                const uint32_t i = o + q < e ? o + q : e - 1;
+                t.key[q] = static_cast<const K*>(rkeys)[i]; t.row[q] = rrows[i];
+                _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                    if (!in.col[a]) continue;
+                    if (!V8 || in.esz[a] == 4) t.v[a][q] = static_cast<const uint32_t*>(in.col[a])[i];
+                    else if constexpr (V8) t.v[a][q] = static_cast<const uint64_t*>(in.col[a])[i];
+                }
+            }
+        }
+        _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+            if (in.col[a]) continue;
+            _Pragma("unroll") for (int q = 0; q < AR; ++q) t.v[a][q] = t.row[q];      // row-index operand: the carried row id
+        }
+    };
     for (uint32_t part = blockIdx.x; part < NB; part += gridDim.x) {
         const uint32_t b = pstart[(size_t)part * pstride];
         const uint32_t e = part + 1 < NB ? pstart[(size_t)(part + 1) * pstride] : ntotal;
         if (b == e) continue;
+        Batch cur;
+        load(b, e, cur);                                       // in flight while the tables are cleared
         for (uint32_t s = threadIdx.x; s < cap; s += SB) { ktab[s] = EMPTYK; idtab[s] = (uint16_t)ID_PENDING; }
         for (uint32_t g = threadIdx.x; g < gmax; g += SB) {
             lfirst[g] = NOROW;
@@ -274,97 +318,85 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
         }
         if (threadIdx.x == 0) { lused = 1; lemit = 0; }
         __syncthreads();
-        for (uint32_t i0 = b; i0 < e; i0 += SB * AR) {
+        for (uint32_t i0 = b;;) {
+            const uint32_t inext = i0 + SB * AR;
+            const bool more = inext < e;
+            Batch nxt;
+            if (more) load(inext, e, nxt);                     // the next step's rows are in flight while this step's are aggregated
+            __builtin_amdgcn_sched_barrier(0);
             const uint32_t o = i0 + threadIdx.x * AR;
-            const bool full = o + AR <= e;
-            K key[AR];
-            uint32_t row[AR];
-            uint64_t vb[NACC ? NACC : 1][AR];
-            bool live[AR];
-#pragma unroll
-            for (int q = 0; q < AR; ++q) live[q] = o + q < e;
-            if (full) {
-                __builtin_memcpy(key, static_cast<const K*>(rkeys) + o, sizeof key);
-                __builtin_memcpy(row, rrows + o, sizeof row);
-            } else {
-#pragma unroll
-                for (int q = 0; q < AR; ++q) { const uint32_t i = live[q] ? o + q : e - 1; key[q] = static_cast<const K*>(rkeys)[i]; row[q] = rrows[i]; }
-            }
-            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
-                if (!in.col[a]) {
-#pragma unroll
-                    for (int q = 0; q < AR; ++q) vb[a][q] = row[q];
-                } else if (in.esz[a] == 4) {
-                    uint32_t t[AR];
-                    if (full) __builtin_memcpy(t, static_cast<const uint32_t*>(in.col[a]) + o, sizeof t);
-                    else {
-#pragma unroll
-                        for (int q = 0; q < AR; ++q) t[q] = static_cast<const uint32_t*>(in.col[a])[live[q] ? o + q : e - 1];
-                    }
-#pragma unroll
-                    for (int q = 0; q < AR; ++q) vb[a][q] = t[q];
-                } else {
-                    if (full) __builtin_memcpy(vb[a], static_cast<const uint64_t*>(in.col[a]) + o, sizeof(uint64_t) * AR);
-                    else {
-#pragma unroll
-                        for (int q = 0; q < AR; ++q) vb[a][q] = static_cast<const uint64_t*>(in.col[a])[live[q] ? o + q : e - 1];
-                    }
-                }
-            }
             uint32_t slot[AR];
             K w[AR];
 #pragma unroll
-            for (int q = 0; q < AR; ++q) { slot[q] = __umulhi(key_hash<K64>(key[q]) * NB, cap); w[q] = ktab[slot[q]]; }   // AR probes in flight
+            for (int q = 0; q < AR; ++q) { slot[q] = __umulhi(key_hash<K64>(cur.key[q]) * NB, cap); w[q] = ktab[slot[q]]; }   // AR probes in flight
             uint32_t pend = 0, special = 0;
 #pragma unroll
             for (int q = 0; q < AR; ++q) {
-                if (!live[q]) slot[q] = FAIL;
-                else if (key[q] == EMPTYK) special |= 1u << q;
-                else if (w[q] != key[q]) pend |= 1u << q;
+                if (!(o + q < e)) slot[q] = FAIL;
+                else if (cur.key[q] == EMPTYK) special |= 1u << q;
+                else if (w[q] != cur.key[q]) pend |= 1u << q;
             }
             // rows that missed on their first probe walk their probe sequences together: one LDS round trip per step
             for (uint32_t step = 0; pend && step <= cap; ++step) {
 #pragma unroll
                 for (int q = 0; q < AR; ++q) {
                     if (!(pend & (1u << q))) continue;
-                    K cur = w[q];
-                    if (cur == EMPTYK) {
-                        if constexpr (K64) cur = atomicCAS(reinterpret_cast<unsigned long long*>(&ktab[slot[q]]), (unsigned long long)EMPTYK, (unsigned long long)key[q]);
-                        else cur = atomicCAS(&ktab[slot[q]], EMPTYK, key[q]);
-                        if (cur == EMPTYK) {
+                    K c = w[q];
+                    if (c == EMPTYK) {
+                        if constexpr (K64) c = atomicCAS(reinterpret_cast<unsigned long long*>(&ktab[slot[q]]), (unsigned long long)EMPTYK, (unsigned long long)cur.key[q]);
+                        else c = atomicCAS(&ktab[slot[q]], EMPTYK, cur.key[q]);
+                        if (c == EMPTYK) {
                             const uint32_t id = atomicAdd(&lused, 1u);
                             idtab[slot[q]] = (uint16_t)(id < gmax ? id : ID_OVER);
-                            cur = key[q];
+                            c = cur.key[q];
                         }
                     }
-                    if (cur == key[q]) { pend &= ~(1u << q); continue; }
+                    if (c == cur.key[q]) { pend &= ~(1u << q); continue; }
                     slot[q] = slot[q] + 1 == cap ? 0 : slot[q] + 1;
                 }
 #pragma unroll
                 for (int q = 0; q < AR; ++q) if (pend & (1u << q)) w[q] = ktab[slot[q]];
             }
             uint32_t id[AR];
+            bool ok[AR];
 #pragma unroll
             for (int q = 0; q < AR; ++q) {
-                if (special & (1u << q)) { id[q] = 0; continue; }
-                if (slot[q] == FAIL || (pend & (1u << q))) { id[q] = ID_OVER; if (slot[q] != FAIL) out.flags[0] = 1; continue; }
+                if (special & (1u << q)) { id[q] = 0; ok[q] = true; continue; }
+                if (slot[q] == FAIL || (pend & (1u << q))) { id[q] = 0; ok[q] = false; if (slot[q] != FAIL) out.flags[0] = 1; continue; }
                 const volatile uint16_t* ip = idtab + slot[q];
                 uint32_t v = *ip;
                 while (v == ID_PENDING) { __builtin_amdgcn_s_sleep(1); v = *ip; }   // the inserting lane (of another wavefront) is about to publish it
-                id[q] = v;
-                if (v == ID_OVER) out.flags[0] = 1;                                // more groups than the dense arrays hold: the host re-plans
+                ok[q] = v != ID_OVER;
+                id[q] = ok[q] ? v : 0;
+                if (!ok[q]) out.flags[0] = 1;                                      // more groups than the dense arrays hold: the host re-plans
             }
 #pragma unroll
-            for (int q = 0; q < AR; ++q) if (id[q] != ID_OVER && row[q] < lfirst[id[q]]) atomicMin(&lfirst[id[q]], row[q]);
+            for (int q = 0; q < AR; ++q) if (ok[q] && cur.row[q] < lfirst[id[q]]) atomicMin(&lfirst[id[q]], cur.row[q]);
             if (need_count) {
 #pragma unroll
-                for (int q = 0; q < AR; ++q) if (id[q] != ID_OVER) atomicAdd(&lcount[id[q]], 1u);
+                for (int q = 0; q < AR; ++q) if (ok[q]) atomicAdd(&lcount[id[q]], 1u);
             }
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
-#pragma unroll
-                for (int q = 0; q < AR; ++q)
-                    if (id[q] != ID_OVER) acc_apply(&lacc[(size_t)a * gmax + id[q]], as.kind[a], val_operand_bits(as.dt[a] == AQG_NONE ? AQG_UINT32 : as.dt[a], vb[a][q], as.kind[a], as.square[a], as.part[a]));
+                uint64_t* acc = lacc + (size_t)a * gmax;
+#define AQG_ROWS(expr) _Pragma("unroll") for (int q = 0; q < AR; ++q) if (ok[q]) { const VT x = cur.v[a][q]; (void)x; expr; } break
+                switch (ops.opc[a]) {
+                case OPC_ADDI_I32: AQG_ROWS(atomicAdd(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(long long)(int32_t)(uint32_t)x));
+                case OPC_ADDI_U32: AQG_ROWS(atomicAdd(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(uint32_t)x));
+                case OPC_ADDF_F32: AQG_ROWS(atomicAdd(reinterpret_cast<double*>(acc + id[q]), (double)__uint_as_float((uint32_t)x)));
+                case OPC_ADDF_F64: AQG_ROWS(atomicAdd(reinterpret_cast<double*>(acc + id[q]), __builtin_bit_cast(double, (uint64_t)x)));
+                case OPC_MIN_I32: AQG_ROWS(atomicMin(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)map_i((int32_t)(uint32_t)x)));
+                case OPC_MAX_I32: AQG_ROWS(atomicMax(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)map_i((int32_t)(uint32_t)x)));
+                case OPC_MIN_U32: AQG_ROWS(atomicMin(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(uint32_t)x));
+                case OPC_MAX_U32: AQG_ROWS(atomicMax(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(uint32_t)x));
+                case OPC_MIN_F32: AQG_ROWS(atomicMin(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)map_f((double)__uint_as_float((uint32_t)x))));
+                case OPC_MAX_F32: AQG_ROWS(atomicMax(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)map_f((double)__uint_as_float((uint32_t)x))));
+                default: AQG_ROWS(acc_apply(acc + id[q], as.kind[a], val_operand_bits(as.dt[a] == AQG_NONE ? AQG_UINT32 : as.dt[a], (uint64_t)x, as.kind[a], as.square[a], as.part[a])));
+                }
+#undef AQG_ROWS
             }
+            if (!more) break;
+            cur = nxt;
+            i0 = inext;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -634,6 +666,21 @@ static int p1_launch_agg(aqg_ctx* ctx, int ksz, const AccSpec& as, const ValCols
         if (vc.of_acc[a] >= 0) { in.col[a] = pvals[vc.of_acc[a]]; in.esz[a] = (int)part_val_bytes(vc.dt[vc.of_acc[a]]); }
         else { in.col[a] = nullptr; in.esz[a] = 4; }     // row-index operands: the carried row id
     }
+    AggOps ops;
+    memset(&ops, 0, sizeof ops);
+    bool v8 = false;
+    for (int a = 0; a < as.nacc; ++a) {
+        const int dt = as.dt[a], kind = as.kind[a];
+        int opc = OPC_GENERIC;
+        if (!as.square[a] && !as.part[a]) {
+            if (dt == AQG_INT32) opc = kind == ACC_ADD_I ? OPC_ADDI_I32 : kind == ACC_MIN ? OPC_MIN_I32 : kind == ACC_MAX ? OPC_MAX_I32 : OPC_GENERIC;
+            else if (dt == AQG_UINT32) opc = kind == ACC_ADD_I ? OPC_ADDI_U32 : kind == ACC_MIN ? OPC_MIN_U32 : kind == ACC_MAX ? OPC_MAX_U32 : OPC_GENERIC;
+            else if (dt == AQG_FLOAT) opc = kind == ACC_ADD_F ? OPC_ADDF_F32 : kind == ACC_MIN ? OPC_MIN_F32 : kind == ACC_MAX ? OPC_MAX_F32 : OPC_GENERIC;
+            else if (dt == AQG_DOUBLE && kind == ACC_ADD_F) opc = OPC_ADDF_F64;
+        }
+        ops.opc[a] = opc;
+        v8 = v8 || in.esz[a] == 8;
+    }
     uint32_t gmax, cap;
     p1_capacity(ksz, as, need_count, &gmax, &cap);
     const size_t lds = (size_t)gmax * (4 + (need_count ? 4 : 0) + 8 * (size_t)as.nacc) + (size_t)cap * (ksz + 2) + 16;
@@ -641,14 +688,19 @@ static int p1_launch_agg(aqg_ctx* ctx, int ksz, const AccSpec& as, const ValCols
     auto launch = [&](auto kern) -> int {
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
         aqg_kernel_timer_begin(ctx);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(SB), lds, ctx->stream, pkeys, static_cast<const uint32_t*>(prows), as, in, pstart, pstride, nparts, n, cap, gmax, need_count, out, out_cap);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SB), lds, ctx->stream, pkeys, static_cast<const uint32_t*>(prows), as, in, ops, pstart, pstride, nparts, n, cap, gmax, need_count, out, out_cap);
         aqg_kernel_timer_end(ctx);
         return aqg_check_launch(ctx, "p1_agg_kernel");
     };
-#define AQG_P1_CASE(N) case N: return ksz == 4 ? launch(&p1_agg_kernel<N, false>) : launch(&p1_agg_kernel<N, true>);
+    auto pick = [&](auto nacc) -> int {
+        constexpr int N = decltype(nacc)::value;
+        if (ksz == 4) return v8 ? launch(&p1_agg_kernel<N, false, true>) : launch(&p1_agg_kernel<N, false, false>);
+        return v8 ? launch(&p1_agg_kernel<N, true, true>) : launch(&p1_agg_kernel<N, true, false>);
+    };
+#define AQG_P1_CASE(N) case N: return pick(std::integral_constant<int, N>{});
     switch (as.nacc) {
     AQG_P1_CASE(0) AQG_P1_CASE(1) AQG_P1_CASE(2) AQG_P1_CASE(3) AQG_P1_CASE(4) AQG_P1_CASE(5) AQG_P1_CASE(6) AQG_P1_CASE(7)
-    default: return ksz == 4 ? launch(&p1_agg_kernel<8, false>) : launch(&p1_agg_kernel<8, true>);
+    default: return pick(std::integral_constant<int, 8>{});
     }
 #undef AQG_P1_CASE
 }

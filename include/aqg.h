@@ -215,7 +215,9 @@ const void* aqg_groupby_agg_result(const aqg_groupby* g, int j);
 /* ---- hash join (new functionality; reference runs joins in MonetDB)
  * inner equi-join on one integer key: build on (build_keys, nb), probe with
  * (probe_keys, np).  Emits matching row-id pairs ordered by probe row, then by
- * build row ascending.  Two-call protocol: pass NULL outputs to get the count.  */
+ * build row ascending.  Two-call protocol: pass NULL outputs to get the count.  The count is exact in 64 bits (duplicate keys
+ * pass 2^32 pairs at small inputs: 70,000 x 70,000 equal keys); aqg_join_pairs addresses its outputs with uint32 offsets and
+ * returns AQG_ERR_OVERFLOW (with *m_host = the count, nothing written) beyond AQG_MAX_ROWS pairs.                          */
 int aqg_join_count(aqg_ctx* ctx, int t, const void* build_keys, uint32_t nb,
                    const void* probe_keys, uint32_t np, uint64_t* m_host);
 int aqg_join_pairs(aqg_ctx* ctx, int t, const void* build_keys, uint32_t nb,

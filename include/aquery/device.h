@@ -10,7 +10,12 @@
 //           the host data is assumed immutable while the mirror exists (drop_pins() at session end).
 //   RESULT  a column produced by a device kernel.  Its host buffer is allocated exactly as the reference
 //           would (malloc / scratch arena) but filled lazily: the first host access (operator[], begin(),
-//           out(), ...) downloads it.  Chained expressions such as max(price - mins(price)) never leave HBM.
+//           out(), ...) downloads it AND DROPS THE DEVICE COPY -- vector_type hands out mutable host access
+//           (operator[] returns _Ty&), so a mirror kept past that point could go stale behind a host write
+//           (`auto x = a + b; x[0] = 5; auto y = x * c;`): a later device use uploads the host data again.
+//           Chained expressions such as max(price - mins(price)) never touch the host and never leave HBM.
+//           (A grouping's row-id buffer keeps its registration after a download: `col[vecs[g]]` is recognised through it.
+//           Generated code only reads vecs[g]; its device copy and the per-grouping aggregate cache assume that, like PINNED.)
 // There is no CPU fallback: without the library or a GPU every operation aborts with a message.
 #pragma once
 #include <cstdint>
@@ -208,6 +213,8 @@ public:
         if (rc != AQG_OK) die("aqg_d2h", rc, ctx_);
         it->second.host_stale = false;
         --stale;
+        // mutable host access follows: a RESULT's device copy cannot be trusted from here on
+        if (!it->second.pinned && !it->second.gctx) { if (it->second.dptr) aqg_free(ctx_, it->second.dptr); map_.erase(it); }
     }
     // the host buffer at p is going away / being rewritten by the host
     void forget(const void* p) {

@@ -124,8 +124,8 @@ public:
     }
     inline void resize(const uint32_t sz) { grow<false, true>(sz); }
     inline void reserve(const uint32_t sz) { grow<false>(sz); }
-    inline void emplace_back(const _Ty& v) { grow(); container[size++] = v; }
-    inline void emplace_back(_Ty&& v) { grow(); container[size++] = std::move(v); }
+    inline void emplace_back(const _Ty& v) { grow(); host()[size++] = v; }
+    inline void emplace_back(_Ty&& v) { grow(); host()[size++] = std::move(v); }
     inline void clear() { size = 0; }
     inline void qpop() { size = size ? size - 1 : size; }
     inline _Ty pop() { return host()[--size]; }

@@ -25,7 +25,7 @@ def run(module, dataset, *funcs, cwd=None):
 def test_emitted_modules_compile():
     """CPU: the generated-shape translation units compile and link against the new library"""
     build()
-    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "distinct_orderby.so", "funcs_udf.so", "host_main"):
+    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "distinct_orderby.so", "funcs_udf.so", "mutate_reuse.so", "host_main"):
         assert os.path.exists(os.path.join(EM, "build", m))
 
 
@@ -178,3 +178,20 @@ def test_user_functions_inside_the_group_loop():
         g = float(got[0])
         assert (math.isnan(g) and math.isnan(v)) or abs(g - v) < 1e-5, (got, v)
         assert int(got[1]) == k and int(got[2]) == sb
+
+
+@pytest.mark.gpu
+def test_host_writes_to_device_results_are_seen_by_later_device_operations():
+    """x = a + b on the device; x[0] = 500 on the host; y = x + x on the device must read the written value (ADVICE round 1:
+    the registry kept the device mirror of a downloaded result and served it stale)"""
+    build()
+    out = run("mutate_reuse.so", "test_csv", "dll_mutate").strip().splitlines()
+    a = [1, 2, 2, 1, 1, 4, 2, 2, 1, 3, 1, 3, 2, 3, 2, 2, 2, 3, 2, 1]
+    b = [1, 1, 4, 2, 2, 2, 1, 1, 2, 2, 2, 2, 1, 3, 2, 3, 4, 4, 3, 2]
+    x = [p + q for p, q in zip(a, b)]
+    x[0], x[2] = 500, -7
+    assert [int(v) for v in out[0].split()] == [2 * x[0], 2 * x[1], 2 * x[2], sum(x)]
+    w = [2 * (p - q) for p, q in zip(a, b)][1:]
+    assert [int(v) for v in out[1].split()] == [sum(w), len(w)]
+    assert int(out[2]) == 1000
+    assert out[-1] == "done."

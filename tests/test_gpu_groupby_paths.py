@@ -263,3 +263,27 @@ def test_handle_reuse_with_the_tail_still_queued(gpu, oracle):
         run()
     assert pgb.ngroups == o["ngroups"] and ck.i128_to_int(pgb.result(0, ck.RED_SUM, ck.INT32)) == want
     pgb.destroy()
+
+
+def test_handle_reuse_gaining_a_key_column(gpu, oracle):
+    """a reused handle whose later calls have more key columns and more groups than the column buffers of the earlier ones were
+    sized for: every group-sized buffer is tracked by itself (keys_out[1] was allocated for 10 groups and then
+    written with 50,000)"""
+    rng = np.random.default_rng(91)
+    n = 300_000
+    v = rng.integers(-100, 100, n).astype(np.int32)
+    calls = [([rng.integers(0, 100_000, n).astype(np.int32)], 0),
+             ([rng.integers(0, 5, n).astype(np.int32), rng.integers(0, 2, n).astype(np.int32)], 0),
+             ([rng.integers(0, 250, n).astype(np.int32), rng.integers(0, 200, n).astype(np.int32)], 0),
+             ([rng.integers(0, 40, n).astype(np.int32), rng.integers(0, 40, n).astype(np.int16), rng.integers(0, 30, n).astype(np.int8)], 0)]
+    gb = None
+    for keys, hint in calls:
+        o = oracle.groupby(keys)
+        gb = gpu.groupby_agg(keys, [ck.RED_SUM, ck.RED_COUNT], [v, v], hint=hint, handle=gb)
+        assert gb.ngroups == o["ngroups"]
+        assert np.array_equal(gb.first_rows(), o["first_rows"])
+        assert np.array_equal(gb.counts(), o["counts"])
+        for k, key in enumerate(keys):
+            assert np.array_equal(gb.keys(k, key.dtype), key[o["first_rows"]])
+        assert gu.same_bits(gb.result(0, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, v, o))
+    gb.destroy()

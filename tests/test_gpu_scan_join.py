@@ -228,3 +228,21 @@ def test_large_properties(gpu):
     sm = gpu.scan(ck.SCAN_SUMS, v1, keep=True)
     last = sm.to_host()[-1]
     assert (int(last["hi"]) << 64) + int(last["lo"]) == sum(sums)
+
+
+def test_join_match_count_beyond_32_bits(gpu):
+    """70,000 x 70,000 rows with one key: 4.9e9 pairs.  The count is exact in 64 bits; the pair form refuses (its outputs are
+    addressed by uint32 offsets) instead of expanding through a wrapped 32-bit scan (join.hip)."""
+    import ctypes as C
+    import aquery2_amd.capi as capi
+    k = np.full(70_000, 7, np.int32)
+    assert gpu.join_count(k, k) == 70_000 * 70_000
+    bd, pd = gpu._dev(k), gpu._dev(k)
+    pr, br = gpu.empty(16, np.uint32), gpu.empty(16, np.uint32)
+    m = C.c_uint64()
+    rc = gpu.lib.aqg_join_pairs(gpu.ctx, bd.tag, C.c_void_p(bd.ptr), C.c_uint32(bd.n), C.c_void_p(pd.ptr), C.c_uint32(pd.n),
+                                C.c_void_p(pr.ptr), C.c_void_p(br.ptr), C.c_uint64(1 << 40), C.byref(m))
+    assert rc == 6 and m.value == 70_000 * 70_000          # AQG_ERR_OVERFLOW, true count reported
+    # exactly 2^32 pairs used to read as zero matches
+    a, b = np.full(65_536, 3, np.int32), np.full(65_536, 3, np.int32)
+    assert gpu.join_count(a, b) == 1 << 32
