@@ -202,6 +202,18 @@ class Device:
         return a if isinstance(a, DevBuf) else self.to_device(a)
 
     # -- generators
+    def col_pin(self, a):
+        """device mirror of a borrowed host column (aqg_col_pin: asynchronous, stream-ordered upload); `a` must stay alive"""
+        assert a.flags["C_CONTIGUOUS"]
+        d = C.c_void_p()
+        self._chk(self.lib.aqg_col_pin(self.ctx, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), C.byref(d)), "aqg_col_pin")
+        buf = DevBuf(self, d.value, a.dtype, a.size, owned=False)
+        buf._host = a
+        return buf
+
+    def col_unpin_all(self):
+        self._chk(self.lib.aqg_col_unpin_all(self.ctx), "aqg_col_unpin_all")
+
     def gen_column(self, col, seed, row_base, n, n_total, K, out=None):
         dt = np.float32 if col == 8 else np.int32
         out = out or self.empty(n, dt)

@@ -12,7 +12,8 @@
 
 #include "../../include/aqg.h"
 
-struct aqg_pin { void* dptr; size_t bytes; };
+// device mirror of a borrowed host column: `regs` = the host ranges page-locked for its upload (released at unpin), `ev` = upload done
+struct aqg_pin { void* dptr; size_t bytes; std::vector<std::pair<void*, size_t>> regs; hipEvent_t ev; };
 
 struct aqg_ctx {
     int device = 0;
@@ -26,6 +27,9 @@ struct aqg_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t evk0 = nullptr, evk1 = nullptr;   // bracket the dominant kernel of the last call
     hipEvent_t ev_flags = nullptr;               // recorded behind the copy of a group table's flag words (run_agg)
+    hipStream_t copy_stream = nullptr;           // uploads of borrowed host columns (aqg_col_pin), created on first use
+    void* up_buf[2] = {nullptr, nullptr};        // pinned staging of the fallback upload path (ranges the runtime refuses to copy directly)
+    hipEvent_t up_ev[2] = {nullptr, nullptr};
     bool tail_in_flight = false;                 // the last group-by returned with its tail kernels still queued (stream-ordered)
     bool evk_valid = false;
     std::unordered_map<const void*, aqg_pin> pins;

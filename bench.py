@@ -49,6 +49,79 @@ def cpu_baseline(sample_rows):
                       f"{groups} groups; host has {os.cpu_count()} cores, reference post-processor is single-threaded)"}
 
 
+def secondary_entries(dev, n, ck, aq, id1, v1):
+    """The other BASELINE configurations and the un-hinted / host-buffer forms of the headline, measured after the timed region on
+    rank 0 at N=1 (never part of `value`): h2o Q5 (config 2), the moving windows of config 3, the fused join + group-by of config 4,
+    and `seam_a` = Q1 the way the header layer calls it (hint 0, fresh handle), without and with the 8 GB host -> HBM ingest.
+    Each entry: best-of-3 HIP-event time of the whole C-ABI call, algorithmic bytes, fraction of the 8 TB/s peak."""
+    out = []
+    def timed(fn, reps=3):
+        best = 1e30
+        for _ in range(reps):
+            dev.sync(); dev.timer_start(); fn(); best = min(best, dev.timer_stop_ms())
+        return best
+    def entry(name, ms, abytes, **extra):
+        gbs = abytes / (ms * 1e-3) / 1e9
+        e = {"name": name, "ms": round(ms, 4), "rows_per_s": n / (ms * 1e-3), "algorithmic_bytes": int(abytes), "achieved_GBps": round(gbs, 1),
+             "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        e.update(extra)
+        out.append(e)
+    K = 100
+    # ---- config 2: h2o Q5 sum(v1), sum(v2), sum(v3) by id6 (benchmark/h2o/groupby.sql:9), N/K groups
+    id6, v2, v3 = (dev.gen_column(c, 42, 0, n, n, K) for c in (ck.GEN_ID6, ck.GEN_V2, ck.GEN_V3))
+    h = {}
+    def q5():
+        h["q5"] = dev.groupby_agg([id6], [ck.RED_SUM] * 3, [v1, v2, v3], hint=n // K + 1024, handle=h.get("q5"))
+    ms = timed(q5)
+    G = h["q5"].ngroups
+    entry("h2o_q5_sum_v1_v2_v3_by_id6", ms, 16 * n + 44 * G, groups=int(G), kernel_ms_last_stage=round(dev.last_kernel_ms(), 4))
+    h["q5"].destroy(); id6.free(); v2.free(); v3.free()
+    # ---- config 3: moving windows over an ordered series (tests/stock.a shapes; aggregations.h:127-281)
+    price = dev.gen_column(ck.GEN_PRICE, 42, 0, n, n, K)
+    big = dev.empty(n, ck.I128)
+    for name, op, w, bpr in (("avgw5_price", ck.SCAN_AVGW, 5, 12), ("sumw5_price", ck.SCAN_SUMW, 5, 20), ("minw10_price", ck.SCAN_MINW, 10, 8)):
+        ot = dev.lib.aqg_scan_out_dtype(op, price.tag)
+        o = aq.DevBuf(dev, big.ptr, aq.capi.TAG2NP[ot], n, owned=False)
+        ms = timed(lambda: dev.scan(op, price, w, keep=True, out=o))
+        entry(name, ms, bpr * n, kernel_ms=round(dev.last_kernel_ms(), 4))
+    big.free(); price.free()
+    # ---- config 4 (one shard of it): fact JOIN small(id4, w), sum(v1 * w) by id1, fused
+    id4 = dev.gen_column(ck.GEN_ID4, 42, 0, n, n, K)
+    rng = np.random.default_rng(4)
+    dim_key, dim_w = dev.to_device(rng.permutation(np.arange(1, K + 1, dtype=np.int32))), dev.to_device(rng.integers(1, 50, K).astype(np.int32))
+    def jf():
+        h["j"] = dev.join_groupby_sum(dim_key, dim_w, id4, id1, v1, hint=128, handle=h.get("j"))
+    ms = timed(jf)
+    entry("join_small_id4_sum_v1w_by_id1_fused", ms, 12 * n, kernel_ms=round(dev.last_kernel_ms(), 4))
+    h["j"].destroy(); id4.free()
+    # ---- seam A: the call the header layer makes (hint 0, a fresh handle per call), resident columns
+    def q1_nohint(k, v):
+        g = dev.groupby_agg([k], [ck.RED_SUM], [v], hint=0)
+        g.destroy()
+    ms = timed(lambda: q1_nohint(id1, v1))
+    entry("seam_a_q1_hint0_fresh_handle", ms, 8 * n)
+    # ---- seam A from host buffers: the two columns as the data source hands them over (pageable host memory), aqg_col_pin + Q1
+    hid1, hv1 = id1.to_host(), v1.to_host()
+    best, best_up = 1e30, 1e30
+    for _ in range(2):
+        dev.col_unpin_all(); dev.sync()
+        t0 = time.perf_counter()
+        dk, dv = dev.col_pin(hid1), dev.col_pin(hv1)
+        dev.sync()
+        t1 = time.perf_counter()
+        best_up = min(best_up, t1 - t0)
+        dev.col_unpin_all(); dev.sync()
+        t0 = time.perf_counter()
+        dk, dv = dev.col_pin(hid1), dev.col_pin(hv1)
+        q1_nohint(dk, dv)
+        dev.sync()
+        best = min(best, time.perf_counter() - t0)
+    dev.col_unpin_all()
+    entry("seam_a_q1_from_host_buffers_h2d_included", best * 1e3, 8 * n, h2d_GBps=round(8 * n / best_up / 1e9, 1), h2d_ms=round(best_up * 1e3, 2),
+          note="8 B/row cross PCIe once (aqg_col_pin: page-locked chunks + DMA), then the same call; bounded by the link, not by HBM")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -56,6 +129,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=float, default=1e9, help="rows per GPU")
     ap.add_argument("--cpu-sample", type=float, default=1e8, help="rows of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary entries (configs 2-4, seam A) on rank 0 at N=1")
     ap.add_argument("--workload", choices=["q1", "join"], default="q1",
                     help="q1 (default, the graded metric): sum(v1) by id1.  join: BASELINE config 4, fact JOIN small(id4, w) ON id4, "
                          "sum(v1 * w) by id1 through the fused aqg_join_groupby_sum, same shard merge")
@@ -199,14 +273,19 @@ def main():
                        "seed": 42, "groups": int(final.ngroups), "parallelism": f"row-range shards x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         # PMC-measured HBM bytes per launch at 1e9 rows (FETCH_SIZE x2 + WRITE_SIZE, separate passes;
-                         # profiles/r1_bench_q1_1e9_pmc.md): 8.0255 GB read + 0.0121 GB written; scaled to this run's rows
-                         # join: 12.001 GB read + 0.018 GB written (profiles/r1_groupby_join_1e9_pmc.md)
-                         "traffic": (12.019e9 if join else 8.0376e9) * n / 1e9,
+                         # `traffic` is a PMC counter of THIS run or null: bench.py collects none (counters need their own rocprofv3
+                         # passes).  The profiled figure at 1e9 rows (FETCH_SIZE x2 + WRITE_SIZE, separate passes) is carried with
+                         # the file it comes from: Q1 8.0255 GB read + 0.0121 GB written, join 12.001 + 0.018.
+                         "traffic": None,
+                         "traffic_profiled": {"bytes_at_1e9_rows": 12.019e9 if join else 8.0376e9,
+                                              "source": "profiles/r1_groupby_join_1e9_pmc.md" if join else "profiles/r1_bench_q1_1e9_pmc.md"},
                          "kernel": "starjoin_kernel" if join else "agg32_kernel<1,false,false,4>", "kernel_ms": k_ms, "algorithmic_bytes": bpr * n},
         }
         if world == 1 and args.cpu_sample > 0 and not join:
             line["cpu_baseline"] = cpu_baseline(int(args.cpu_sample))
+        if world == 1 and not join and not selfmerge and not args.no_secondary:
+            state["gb"].destroy()
+            line["secondary"] = secondary_entries(dev, n, ck, aquery2_amd, id1, v1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

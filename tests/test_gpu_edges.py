@@ -158,3 +158,27 @@ def test_scan_resume_every_dtype_and_tile_boundary(gpu, oracle, dt):
                 assert np.all(np.abs(got - want) <= 1e-9 * np.maximum(np.abs(want), 1.0)), (name, split)
             else:
                 assert gu.same_bits(got, want), (name, split)
+
+
+def test_col_pin_async_upload_is_stream_ordered(gpu, oracle):
+    """aqg_col_pin returns with the upload still running (page-locked chunks, DMA on a copy stream); calls that follow read the
+    complete column (the context's stream waits for it), for page-aligned and unaligned host ranges, sizes below and above the
+    registration threshold and a second sight of the same column (cached)"""
+    rng = np.random.default_rng(17)
+    base = rng.integers(-1000, 1000, 9_000_011).astype(np.int32)
+    alive = []                      # the mirror cache is keyed by host address: borrowed columns live until the session ends
+    al = (-base.ctypes.data % 4096) // 4          # first page-aligned element: a copy that starts in page-locked memory must not run past it
+    for off, n in ((0, 9_000_011), (3, 5_000_000), (1025, 1_000), (7, 300_001), (al, 4_000_003), (al, 1 << 20), (al + 1024, 2_097_152 + 5), (al + 1, 3_000_000)):
+        a = base[off:off + n]
+        d = gpu.col_pin(a)
+        assert int(gpu.reduce(ck.RED_SUM, d)) == int(a.sum(dtype=np.int64))
+        d2 = gpu.col_pin(a)
+        assert d2.ptr == d.ptr
+        hk = np.ascontiguousarray(a % 7)
+        alive.append(hk)
+        k = gpu.col_pin(hk)
+        gb = gpu.groupby_agg([k], [ck.RED_SUM], [d], hint=0)
+        o = oracle.groupby([hk])
+        assert gb.ngroups == o["ngroups"] and np.array_equal(gb.first_rows(), o["first_rows"])
+        gb.destroy()
+    gpu.col_unpin_all()
