@@ -1,0 +1,378 @@
+// exchange.hip -- the exchange step of row-sharded group-bys INSIDE the library (BASELINE north_star: "tables shard by
+// row range across the 8 GPUs of one node with a single RCCL reduce/all-gather over xGMI only for the final global aggregate or
+// low-cardinality group merge").  The reference has no distributed form; this replaces nothing there.
+//
+//   aqg_comm_*                 one communicator per (process, GPU): RCCL (ncclAllGather on the context's stream; librccl is opened
+//                              with dlopen when the first RCCL communicator is made, so single-GPU users never load it) or a
+//                              caller-supplied all-gather (tests and rehearsals on one GPU, hosts with their own transport)
+//   aqg_groupby_agg_sharded    group-by + aggregates over THIS rank's row range, then ONE all-gather of the shard's group table
+//                              -- k key columns, the global first row, one partial per aggregate (SUM -> sum, COUNT -> count,
+//                              MIN / MAX -> itself, AVG -> sum and count) -- and a re-aggregation of the concatenation on every
+//                              rank.  Shards are contiguous row ranges gathered in rank order, so first occurrence in the
+//                              concatenation is the global first occurrence: the merged groups come out in the reference's order
+//                              (server/hasher.h:176-198) without any row id but each group's first crossing the wire.
+// Payload of a rank (gcap = group capacity of the exchange): 8-byte words, column-major --
+//   {ngroups, 0} | key_0[gcap] ... key_{k-1}[gcap] | first_row[gcap] | partial_0[gcap] ... partial_{m-1}[gcap]
+#include <dlfcn.h>
+
+#include "aqg_internal.hpp"
+#include "dev_common.hpp"
+#include "groupby_handle.hpp"
+
+namespace {
+
+constexpr int MAXPART = 2 * MAXAGG;      // partial columns of one exchange (AVG ships two)
+
+// ---- RCCL through dlopen ------------------------------------------------------------------------------------------------------
+struct NcclId { char internal[128]; };
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(NcclId*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclId, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl* rccl(std::string* err) {
+    static Rccl r;
+    if (r.lib) return &r;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
+    if (!r.lib) { if (err) *err = std::string("librccl not found: ") + dlerror(); return nullptr; }
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { if (err) *err = "librccl lacks an expected symbol"; dlclose(r.lib); r.lib = nullptr; return nullptr; }
+    return &r;
+}
+
+struct Partial { int local_op; int val_dt; int val_index; int part_dt; int merge_op; };   // one shipped column
+
+} // namespace
+
+struct aqg_comm {
+    aqg_ctx* ctx = nullptr;
+    int rank = 0, world = 1;
+    void* nccl = nullptr;                    // ncclComm_t
+    aqg_allgather_fn fn = nullptr;
+    void* user = nullptr;
+    // grow-only device buffers
+    void *send = nullptr, *recv = nullptr, *cat = nullptr, *hdr = nullptr;
+    size_t send_cap = 0, recv_cap = 0, cat_cap = 0, hdr_cap = 0;
+    aqg_groupby *local = nullptr, *merged = nullptr;
+};
+
+namespace {
+
+int grow(aqg_ctx* ctx, void** p, size_t* cap, size_t need) {
+    if (need <= *cap && *p) return AQG_OK;
+    if (*p) { AQG_HIP(ctx, hipStreamSynchronize(ctx->stream)); AQG_HIP(ctx, hipFree(*p)); *p = nullptr; *cap = 0; }
+    const size_t want = need < 4096 ? 4096 : need;
+    if (hipMalloc(p, want) != hipSuccess) { ctx->err = "exchange: hipMalloc failed"; (void)hipGetLastError(); return AQG_ERR_NOMEM; }
+    *cap = want;
+    return AQG_OK;
+}
+
+int allgather(aqg_comm* c, const void* send, void* recv, size_t bytes) {
+    aqg_ctx* ctx = c->ctx;
+    if (c->fn) {
+        const int rc = c->fn(c->user, send, recv, bytes, (void*)ctx->stream);
+        if (rc != 0) return aqg_fail(ctx, AQG_ERR_HIP, "exchange: the caller's all-gather failed");
+        return AQG_OK;
+    }
+    Rccl* r = rccl(&ctx->err);
+    if (!r) return AQG_ERR_HIP;
+    const int rc = r->AllGather(send, recv, bytes, /*ncclInt8*/ 0, c->nccl, ctx->stream);
+    if (rc != 0) { ctx->err = std::string("ncclAllGather: ") + (r->GetErrorString ? r->GetErrorString(rc) : "error"); return AQG_ERR_HIP; }
+    return AQG_OK;
+}
+
+__device__ inline uint64_t load_native(int dt, const void* col, size_t i) {
+    switch (dt) {
+    case AQG_INT8: return (uint64_t)(int64_t)static_cast<const int8_t*>(col)[i];
+    case AQG_INT16: return (uint64_t)(int64_t)static_cast<const int16_t*>(col)[i];
+    case AQG_INT32: return (uint64_t)(int64_t)static_cast<const int32_t*>(col)[i];
+    case AQG_UINT8: case AQG_BOOL: return static_cast<const uint8_t*>(col)[i];
+    case AQG_UINT16: return static_cast<const uint16_t*>(col)[i];
+    case AQG_UINT32: case AQG_FLOAT: return static_cast<const uint32_t*>(col)[i];
+    case AQG_INT128: case AQG_UINT128: return static_cast<const uint64_t*>(col)[2 * i];          // low half: partial sums of <= 4-byte integers over < 2^32 rows fit
+    default: return static_cast<const uint64_t*>(col)[i];
+    }
+}
+__device__ inline void store_native(int dt, void* col, size_t i, uint64_t bits) {
+    switch (dt) {
+    case AQG_INT8: case AQG_UINT8: case AQG_BOOL: static_cast<uint8_t*>(col)[i] = (uint8_t)bits; break;
+    case AQG_INT16: case AQG_UINT16: static_cast<uint16_t*>(col)[i] = (uint16_t)bits; break;
+    case AQG_INT32: case AQG_UINT32: case AQG_FLOAT: static_cast<uint32_t*>(col)[i] = (uint32_t)bits; break;
+    default: static_cast<uint64_t*>(col)[i] = bits; break;
+    }
+}
+
+struct PackSpec {
+    int ncols;                        // nkeys + 1 + nparts
+    int nkeys;
+    const void* src[MAXKEYS + 1 + MAXPART];
+    int src_dt[MAXKEYS + 1 + MAXPART];
+    uint64_t row_base;
+};
+// word (c, g) of the payload: column c of group g (column nkeys = the global first row)
+__global__ void __launch_bounds__(256) xpack_kernel(PackSpec ps, uint32_t G, uint32_t gcap, uint64_t* __restrict__ out) {
+    const size_t total = (size_t)ps.ncols * G;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = G; out[1] = 0; }
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i / G);
+        const uint32_t g = (uint32_t)(i - (size_t)c * G);
+        uint64_t w = load_native(ps.src_dt[c], ps.src[c], g);
+        if (c == ps.nkeys) w = (w & 0xFFFFFFFFull) + ps.row_base;             // local first row (uint32) -> global row id
+        out[2 + (size_t)c * gcap + g] = w;
+    }
+}
+struct UnpackSpec {
+    int ncols;
+    void* dst[MAXKEYS + 1 + MAXPART];
+    int dst_dt[MAXKEYS + 1 + MAXPART];
+};
+// concatenation in rank order: rank r's groups start at the sum of the group counts before it
+__global__ void __launch_bounds__(256) xunpack_kernel(const uint64_t* __restrict__ gathered, uint32_t world, uint32_t gcap, size_t words_per_rank, UnpackSpec us) {
+    __shared__ uint32_t start[65];
+    if (threadIdx.x == 0) { uint32_t s = 0; for (uint32_t r = 0; r < world; ++r) { start[r] = s; s += (uint32_t)gathered[(size_t)r * words_per_rank]; } start[world] = s; }
+    __syncthreads();
+    for (uint32_t r = 0; r < world; ++r) {
+        const uint64_t* p = gathered + (size_t)r * words_per_rank;
+        const uint32_t G = start[r + 1] - start[r];
+        const size_t total = (size_t)us.ncols * G;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+            const int c = (int)(i / G);
+            const uint32_t g = (uint32_t)(i - (size_t)c * G);
+            store_native(us.dst_dt[c], us.dst[c], (size_t)start[r] + g, p[2 + (size_t)c * gcap + g]);
+        }
+    }
+}
+
+struct FinalSpec {
+    int nagg;
+    int op[MAXAGG], dt[MAXAGG];
+    const void* a[MAXAGG];            // merged partial (SUM / MIN / MAX / COUNT), or the merged sum of AVG
+    const void* b[MAXAGG];            // merged count of AVG (128-bit)
+    void* out[MAXAGG];
+    int out_size[MAXAGG];
+};
+__global__ void __launch_bounds__(256) xfinal_kernel(FinalSpec fs, uint32_t G) {
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < G; g += gridDim.x * 256) {
+        for (int j = 0; j < fs.nagg; ++j) {
+            const bool fp = fs.dt[j] == AQG_FLOAT || fs.dt[j] == AQG_DOUBLE;
+            const bool uns = fs.dt[j] == AQG_UINT8 || fs.dt[j] == AQG_UINT16 || fs.dt[j] == AQG_UINT32 || fs.dt[j] == AQG_UINT64 || fs.dt[j] == AQG_BOOL;
+            switch (fs.op[j]) {
+            case AQG_RED_COUNT: static_cast<uint64_t*>(fs.out[j])[g] = static_cast<const aqg_i128*>(fs.a[j])[g].lo; break;
+            case AQG_RED_AVG: {                                               // sum / (double)size (aggregations.h:28-32)
+                const aqg_i128 cn = static_cast<const aqg_i128*>(fs.b[j])[g];
+                double s;
+                if (fp) s = static_cast<const double*>(fs.a[j])[g];
+                else { const aqg_i128 v = static_cast<const aqg_i128*>(fs.a[j])[g]; s = uns ? u128_to_double(v.hi, v.lo) : i128_to_double(v); }
+                static_cast<double*>(fs.out[j])[g] = s / (double)cn.lo;
+            } break;
+            default: {                                                        // SUM / MIN / MAX: the merged column is the result
+                const unsigned char* src = static_cast<const unsigned char*>(fs.a[j]) + (size_t)g * fs.out_size[j];
+                unsigned char* dst = static_cast<unsigned char*>(fs.out[j]) + (size_t)g * fs.out_size[j];
+                for (int k = 0; k < fs.out_size[j]; ++k) dst[k] = src[k];
+            } break;
+            }
+        }
+    }
+}
+
+bool small_int(int dt) { return dt == AQG_INT8 || dt == AQG_INT16 || dt == AQG_INT32 || dt == AQG_UINT8 || dt == AQG_UINT16 || dt == AQG_UINT32 || dt == AQG_BOOL; }
+bool is_fp(int dt) { return dt == AQG_FLOAT || dt == AQG_DOUBLE; }
+
+} // namespace
+
+extern "C" {
+
+int aqg_comm_unique_id(void* id_out) {
+    if (!id_out) return AQG_ERR_ARG;
+    std::string err;
+    Rccl* r = rccl(&err);
+    if (!r) return AQG_ERR_HIP;
+    NcclId id;
+    if (r->GetUniqueId(&id) != 0) return AQG_ERR_HIP;
+    memcpy(id_out, &id, sizeof id);
+    return AQG_OK;
+}
+
+int aqg_comm_init_rccl(aqg_ctx* ctx, int rank, int world, const void* id, aqg_comm** out) {
+    if (!ctx || !id || !out || world < 1 || world > 64 || rank < 0 || rank >= world) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_comm_init_rccl: bad argument (1..64 ranks)");
+    Rccl* r = rccl(&ctx->err);
+    if (!r) return AQG_ERR_HIP;
+    AQG_HIP(ctx, hipSetDevice(ctx->device));
+    NcclId nid;
+    memcpy(&nid, id, sizeof nid);
+    void* comm = nullptr;
+    const int rc = r->CommInitRank(&comm, world, nid, rank);
+    if (rc != 0) { ctx->err = std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(rc) : "error"); return AQG_ERR_HIP; }
+    aqg_comm* c = new aqg_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world; c->nccl = comm;
+    *out = c;
+    return AQG_OK;
+}
+
+int aqg_comm_init_custom(aqg_ctx* ctx, int rank, int world, aqg_allgather_fn fn, void* user, aqg_comm** out) {
+    if (!ctx || !fn || !out || world < 1 || world > 64 || rank < 0 || rank >= world) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_comm_init_custom: bad argument (1..64 ranks)");
+    aqg_comm* c = new aqg_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world; c->fn = fn; c->user = user;
+    *out = c;
+    return AQG_OK;
+}
+
+void aqg_comm_destroy(aqg_comm* c) {
+    if (!c) return;
+    if (c->ctx) hipStreamSynchronize(c->ctx->stream);
+    if (c->nccl) { if (Rccl* r = rccl(nullptr)) r->CommDestroy(c->nccl); }
+    for (void* p : {c->send, c->recv, c->cat, c->hdr}) if (p) hipFree(p);
+    if (c->local) aqg_groupby_destroy(c->local);
+    if (c->merged) aqg_groupby_destroy(c->merged);
+    delete c;
+}
+int aqg_comm_rank(const aqg_comm* c) { return c ? c->rank : -1; }
+int aqg_comm_world(const aqg_comm* c) { return c ? c->world : 0; }
+
+const int64_t* aqg_groupby_first_rows64(const aqg_groupby* g) { return g ? g->first_rows64 : nullptr; }
+
+int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, const void* const* keys, int naggs, const int* ops, const int* val_dtypes,
+                            const void* const* vals, uint32_t n, uint64_t row_base, uint32_t max_groups_hint, uint32_t gmax, aqg_groupby** out) {
+    if (!comm || !out) return AQG_ERR_ARG;
+    aqg_ctx* ctx = comm->ctx;
+    if (nkeys < 1 || nkeys > MAXKEYS || naggs < 0 || naggs > MAXAGG) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_agg_sharded: 1..8 key columns, 0..8 aggregates");
+    // ---- what travels: one partial per aggregate (AVG: sum and count), identical (op, column) pairs once -------------------------
+    Partial parts[MAXPART];
+    int nparts = 0, part_of[MAXAGG], part2_of[MAXAGG];
+    auto add_part = [&](int lop, int j) -> int {
+        const int dt = val_dtypes[j];
+        for (int p = 0; p < nparts; ++p) if (parts[p].local_op == lop && (lop == AQG_RED_COUNT || (vals[parts[p].val_index] == vals[j] && parts[p].val_dt == dt))) return p;
+        Partial& P = parts[nparts];
+        P.local_op = lop; P.val_dt = dt; P.val_index = j;
+        if (lop == AQG_RED_SUM) { P.part_dt = is_fp(dt) ? AQG_DOUBLE : AQG_INT64; P.merge_op = AQG_RED_SUM; }
+        else if (lop == AQG_RED_COUNT) { P.part_dt = AQG_INT64; P.merge_op = AQG_RED_SUM; }
+        else { P.part_dt = dt; P.merge_op = lop; }
+        return nparts++;
+    };
+    for (int j = 0; j < naggs; ++j) {
+        const int op = ops[j], dt = val_dtypes[j];
+        part_of[j] = part2_of[j] = -1;
+        if (op != AQG_RED_COUNT && !(small_int(dt) || is_fp(dt) || ((op == AQG_RED_MIN || op == AQG_RED_MAX) && (dt == AQG_INT64 || dt == AQG_UINT64))))
+            return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: SUM / AVG over 1-, 2-, 4-byte integers and floating columns; MIN / MAX also over 8-byte integers");
+        switch (op) {
+        case AQG_RED_SUM: case AQG_RED_MIN: case AQG_RED_MAX: case AQG_RED_COUNT: part_of[j] = add_part(op, j); break;
+        case AQG_RED_AVG: part_of[j] = add_part(AQG_RED_SUM, j); part2_of[j] = add_part(AQG_RED_COUNT, j); break;
+        default: return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: SUM / COUNT / MIN / MAX / AVG (VAR / STDDEV / FIRST / LAST do not decompose through this call)");
+        }
+    }
+    if (nparts + 1 > MAXAGG) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_agg_sharded: too many partial columns (7 per call)");
+    // ---- 1. this shard ------------------------------------------------------------------------------------------------------------
+    int lops[MAXAGG], ldts[MAXAGG];
+    const void* lvals[MAXAGG];
+    for (int p = 0; p < nparts; ++p) { lops[p] = parts[p].local_op; ldts[p] = parts[p].val_dt; lvals[p] = vals[parts[p].val_index]; }
+    AQG_TRY(aqg_groupby_agg(ctx, nkeys, key_dtypes, keys, nparts, lops, ldts, lvals, n, max_groups_hint, &comm->local));
+    aqg_groupby* L = comm->local;
+    const uint32_t G = L->ngroups;
+    // ---- 2. capacity of the exchange: the caller's bound, or the largest shard table (one 8-byte all-gather and a host read) -------
+    const uint32_t world = (uint32_t)comm->world;
+    uint32_t gcap = gmax;
+    if (gmax) { if (G > gmax) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: a shard has more groups than gmax"); }
+    else {
+        AQG_TRY(grow(ctx, &comm->hdr, &comm->hdr_cap, 8 * ((size_t)world + 1)));
+        uint64_t* h = static_cast<uint64_t*>(comm->hdr);
+        const uint64_t mine = G;
+        AQG_HIP(ctx, hipMemcpyAsync(h + world, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
+        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));                    // (`mine` is a stack variable)
+        AQG_TRY(allgather(comm, h + world, h, 8));
+        uint64_t all[64];
+        AQG_HIP(ctx, hipMemcpyAsync(all, h, 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        uint64_t mx = 1;
+        for (uint32_t r = 0; r < world; ++r) mx = all[r] > mx ? all[r] : mx;
+        gcap = (uint32_t)mx;
+    }
+    const int ncols = nkeys + 1 + nparts;
+    const size_t words = 2 + (size_t)ncols * gcap, bytes = words * 8;
+    if ((uint64_t)gcap * world > AQG_MAX_ROWS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: world x group capacity exceeds AQG_MAX_ROWS");
+    AQG_TRY(grow(ctx, &comm->send, &comm->send_cap, bytes));
+    AQG_TRY(grow(ctx, &comm->recv, &comm->recv_cap, bytes * world));
+    // ---- 3. pack, ONE all-gather, concatenate ----------------------------------------------------------------------------------------
+    PackSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.ncols = ncols; ps.nkeys = nkeys; ps.row_base = row_base;
+    for (int k = 0; k < nkeys; ++k) { ps.src[k] = L->keys_out[k]; ps.src_dt[k] = key_dtypes[k]; }
+    ps.src[nkeys] = L->first_rows; ps.src_dt[nkeys] = AQG_UINT32;
+    for (int p = 0; p < nparts; ++p) { ps.src[nkeys + 1 + p] = L->results[p]; ps.src_dt[nkeys + 1 + p] = L->res_dt[p]; }
+    hipLaunchKernelGGL(xpack_kernel, dim3(aqg_grid(ctx, (uint64_t)ncols * G + 1, 256, 2, 4)), dim3(256), 0, ctx->stream, ps, G, gcap, static_cast<uint64_t*>(comm->send));
+    AQG_TRY(aqg_check_launch(ctx, "xpack_kernel"));
+    AQG_TRY(allgather(comm, comm->send, comm->recv, bytes));
+    // concatenated columns: keys in their own dtypes, first rows and partials
+    const size_t cat_rows = (size_t)gcap * world;
+    size_t col_off[MAXKEYS + 1 + MAXPART], cat_bytes = 0;
+    int col_dt[MAXKEYS + 1 + MAXPART];
+    for (int c = 0; c < ncols; ++c) {
+        col_dt[c] = c < nkeys ? key_dtypes[c] : c == nkeys ? AQG_INT64 : parts[c - nkeys - 1].part_dt;
+        col_off[c] = cat_bytes;
+        cat_bytes += (cat_rows * aqg_dtype_size(col_dt[c]) + 255) & ~(size_t)255;
+    }
+    AQG_TRY(grow(ctx, &comm->cat, &comm->cat_cap, cat_bytes + 256));
+    UnpackSpec us;
+    memset(&us, 0, sizeof us);
+    us.ncols = ncols;
+    for (int c = 0; c < ncols; ++c) { us.dst[c] = static_cast<char*>(comm->cat) + col_off[c]; us.dst_dt[c] = col_dt[c]; }
+    hipLaunchKernelGGL(xunpack_kernel, dim3(aqg_grid(ctx, (uint64_t)ncols * gcap + 1, 256, 2, 4)), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(comm->recv), world, gcap, words, us);
+    AQG_TRY(aqg_check_launch(ctx, "xunpack_kernel"));
+    // the number of concatenated rows: sum of the headers (one small copy)
+    uint64_t total = 0;
+    {
+        uint64_t hd[64];
+        for (uint32_t r = 0; r < world; ++r) AQG_HIP(ctx, hipMemcpyAsync(&hd[r], static_cast<const uint64_t*>(comm->recv) + (size_t)r * words, 8, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t r = 0; r < world; ++r) total += hd[r];
+    }
+    if (total > AQG_MAX_ROWS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: more shard groups than AQG_MAX_ROWS");
+    // ---- 4. re-aggregate the concatenation (first occurrence in it = global first occurrence) ------------------------------------------
+    int mops[MAXAGG], mdts[MAXAGG];
+    const void* mvals[MAXAGG];
+    const void* mkeys[MAXKEYS];
+    for (int k = 0; k < nkeys; ++k) mkeys[k] = us.dst[k];
+    mops[0] = AQG_RED_MIN; mdts[0] = AQG_INT64; mvals[0] = us.dst[nkeys];
+    for (int p = 0; p < nparts; ++p) { mops[1 + p] = parts[p].merge_op; mdts[1 + p] = parts[p].part_dt; mvals[1 + p] = us.dst[nkeys + 1 + p]; }
+    uint64_t mhint = total < 64 ? 64 : total;
+    if (max_groups_hint && (uint64_t)max_groups_hint * world < mhint) mhint = (uint64_t)max_groups_hint * world;
+    AQG_TRY(aqg_groupby_agg(ctx, nkeys, key_dtypes, mkeys, nparts + 1, mops, mdts, mvals, (uint32_t)total, (uint32_t)mhint, &comm->merged));
+    aqg_groupby* M = comm->merged;
+    // ---- 5. the result handle: keys and global first rows of the merged table, every aggregate in its own result dtype --------------
+    aqg_groupby* H = *out ? *out : new aqg_groupby();
+    H->ctx = ctx; H->n = n; H->ngroups = M->ngroups; H->nkeys = nkeys; H->nagg = naggs;
+    H->has_counts = false; H->has_reversemap = false; H->sharded = true;
+    const size_t GG = M->ngroups ? M->ngroups : 1;
+    auto grow_h = [&](void** p, size_t* cap, size_t need) -> int { return grow(ctx, p, cap, need); };
+    int rc = AQG_OK;
+    for (int k = 0; k < nkeys && rc == AQG_OK; ++k) {
+        H->key_dt[k] = key_dtypes[k];
+        rc = grow_h(&H->keys_out[k], &H->cap_keys[k], GG * 8);
+        if (rc == AQG_OK && M->ngroups) rc = hipMemcpyAsync(H->keys_out[k], M->keys_out[k], (size_t)M->ngroups * aqg_dtype_size(key_dtypes[k]), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? AQG_OK : AQG_ERR_HIP;
+    }
+    if (rc == AQG_OK) rc = grow_h(reinterpret_cast<void**>(&H->first_rows64), &H->cap_first64, GG * 8);
+    if (rc == AQG_OK && M->ngroups) rc = hipMemcpyAsync(H->first_rows64, M->results[0], (size_t)M->ngroups * 8, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? AQG_OK : AQG_ERR_HIP;
+    FinalSpec fs;
+    memset(&fs, 0, sizeof fs);
+    fs.nagg = naggs;
+    for (int j = 0; j < naggs && rc == AQG_OK; ++j) {
+        H->res_dt[j] = aqg_reduce_out_dtype(ops[j], val_dtypes[j]);
+        rc = grow_h(&H->results[j], &H->cap_results[j], GG * 16);
+        fs.op[j] = ops[j]; fs.dt[j] = val_dtypes[j]; fs.out[j] = H->results[j]; fs.out_size[j] = (int)aqg_dtype_size(H->res_dt[j]);
+        fs.a[j] = M->results[1 + part_of[j]];
+        fs.b[j] = part2_of[j] >= 0 ? M->results[1 + part2_of[j]] : nullptr;
+    }
+    if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(H); return rc == AQG_ERR_HIP ? aqg_fail(ctx, rc, "aqg_groupby_agg_sharded: device copy failed") : rc; }
+    if (M->ngroups && naggs) hipLaunchKernelGGL(xfinal_kernel, dim3(aqg_grid(ctx, M->ngroups, 256, 1, 4)), dim3(256), 0, ctx->stream, fs, M->ngroups);
+    AQG_TRY(aqg_check_launch(ctx, "xfinal_kernel"));
+    *out = H;
+    return AQG_OK;
+}
+
+} // extern "C"

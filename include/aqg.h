@@ -206,6 +206,10 @@ int aqg_grouped_reduce(aqg_ctx* ctx, const aqg_groupby* g, int op, int t, const 
  * `*out` is in/out: pass NULL to create a handle, or an earlier handle to reuse its buffers
  * (steady-state calls then allocate nothing).  max_groups_hint sizes the hash tables
  * (0 = unknown: start small and grow); the call retries internally when the hint is too low.
+ * Floating-point SUM / AVG / VAR accumulate with atomic adds (LDS and HBM), in whatever order the hardware schedules the rows:
+ * results are NOT bit-reproducible from run to run (the reference adds the rows of a group in one fixed order); every result lies
+ * within (n_g - 1) 2^-53 sum|x| of the exactly rounded sum of its group (n_g rows), which is what the parity tests assert.
+ * Integer aggregates, counts, MIN / MAX, keys, first rows and the group order are exact and deterministic.
  * On return the handle's ngroups is final; the device columns behind the handle (keys, first rows,
  * counts, results) may still be being written by kernels queued on the context's stream: read
  * them through this library (aqg_groupby_keys, aqg_d2h, ...: all ordered behind those kernels),

@@ -240,9 +240,29 @@ public:
     }
     void sync() { aqg_sync(ctx()); }
 
+    // Groupings made through HashTableFactory::get belong to the SESSION of the module that made them (the reference leaks them:
+    // "Memory leak here, cleanup after module is done", hasher.h:255): device handle, row ids, offsets / counts, the key vector and
+    // the vecs array are released by Context::end_session() / the module's __AQ_End_Session__ hook / the unload of the module.
+    struct SessionItem { GroupCtx* table; void* keys; void (*free_keys)(void*); void* vecs; };
+    std::vector<SessionItem> session_items;
+    void release_session() {
+        for (auto& it : session_items) {
+            if (it.table) {
+                if (it.table->row_ids) { forget(it.table->row_ids); std::free(it.table->row_ids); }
+                if (it.table->handle) aqg_groupby_destroy(it.table->handle);
+                std::free(it.table->offsets); std::free(it.table->counts);
+                delete it.table;
+            }
+            if (it.keys && it.free_keys) it.free_keys(it.keys);
+            std::free(it.vecs);
+        }
+        session_items.clear();
+    }
+
 private:
     Runtime() = default;
     ~Runtime() {
+        release_session();
         if (ctx_) {
             for (auto& kv : map_) if (kv.second.dptr) aqg_free(ctx_, kv.second.dptr);
             aqg_ctx_destroy(ctx_);

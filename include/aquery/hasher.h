@@ -33,11 +33,12 @@ namespace aq {
 
 using GroupTable = dev::GroupCtx;   // host-side view of one device group-by (offsets/counts host valid, row_ids filled lazily)
 
-inline GroupTable& build_groups(int nkeys, const int* dts, const void* const* dev_cols, uint32_t n, bool want_reversemap, uint32_t* reversemap_host) {
+inline GroupTable& build_groups(int nkeys, const int* dts, const void* const* dev_cols, uint32_t n, bool want_reversemap, uint32_t* reversemap_host,
+                                uint32_t max_groups_hint = 0) {
     auto& rt = dev::Runtime::get();
-    GroupTable& t = *new GroupTable();      // owned by whoever holds the grouping (AQHashTable / the module's lifetime)
+    GroupTable& t = *new GroupTable();      // owned by whoever holds the grouping (AQHashTable / the module's session)
     t.n = n;
-    dev::check(aqg_groupby_build(rt.ctx(), nkeys, dts, dev_cols, n, 0, &t.handle), "aqg_groupby_build");
+    dev::check(aqg_groupby_build(rt.ctx(), nkeys, dts, dev_cols, n, max_groups_hint, &t.handle), "aqg_groupby_build");
     t.G = aqg_groupby_ngroups(t.handle);
     t.offsets = static_cast<uint32_t*>(std::malloc(((size_t)t.G + 1) * 4));
     t.counts = static_cast<uint32_t*>(std::malloc(((size_t)t.G + 1) * 4));
@@ -184,11 +185,23 @@ public:
         aq::dev::In ins[] = {aq::dev::In(cols.container, (size_t)n * sizeof(value_type_r<std::decay_t<Cols>>), cols.capacity == 0)...};
         const void* ptrs[sizeof...(Cols)];
         for (size_t k = 0; k < sizeof...(Cols); ++k) ptrs[k] = ins[k].d;
-        aq::GroupTable& t = aq::build_groups((int)sizeof...(Cols), dts, ptrs, n, false, nullptr);
-        auto* keys = new std::vector<Tuple>();           // lives as long as the module, like the reference's
+        // The reference's perfect-hash decision (hasher.h:334-343): integral keys whose TableStats widths add up to at most
+        // PerfectHashingThreshold bits span a domain of 2^bits tuples.  Here that bound sizes the device plan (the direct-indexed
+        // table of dense.hip is the device form of PerfectHashTable) instead of being discovered from a sample; group order stays
+        // first occurrence, the only executable order of the reference (its PerfectHashTable::construct does not compile).
+        uint32_t hint = 0;
+        if constexpr ((std::is_integral_v<value_type_r<std::decay_t<Cols>>> && ...)) {
+            unsigned bits = 0;
+            ((bits += cols.stats.bits), ...);
+            if (bits <= (unsigned)PerfectHashingThreshold) { const uint64_t dom = 1ull << bits; hint = (uint32_t)(dom < n ? dom : n); if (!hint) hint = 1; }
+        }
+        aq::GroupTable& t = aq::build_groups((int)sizeof...(Cols), dts, ptrs, n, false, nullptr, hint);
+        auto* keys = new std::vector<Tuple>();
         aq::fetch_keys(t, *keys, std::index_sequence_for<Cols...>{});
-        HashTableComponents<value_type_r<std::decay_t<Cols>>...> c{t.G, keys, aq::make_vecs(t), t.offsets};
-        // the grouping (device handle, row ids, offsets, counts) stays alive for the lifetime of the module, like `keys`
+        auto* vecs = aq::make_vecs(t);
+        HashTableComponents<value_type_r<std::decay_t<Cols>>...> c{t.G, keys, vecs, t.offsets};
+        // the grouping (device handle, row ids, offsets, counts), `keys` and `vecs` live until the module's session ends
+        aq::dev::Runtime::get().session_items.push_back({&t, keys, [](void* p) { delete static_cast<std::vector<Tuple>*>(p); }, vecs});
         return c;
     }
 };

@@ -78,8 +78,9 @@ struct Context {
     template <class... Types> void log(Types... args) { if (log_level == LOG_INFO) print(args...); }
     template <class... Types> void err(Types... args) { if (log_level <= LOG_ERROR) print(args...); }
     void init_session() {}
-    // end of a module's session: drop the device mirrors of borrowed columns (their host buffers go away)
-    void end_session() { aq::dev::Runtime::get().drop_pins(); }
+    // end of a module's session: drop the device mirrors of borrowed columns (their host buffers go away) and the groupings that
+    // HashTableFactory::get made for the module (device handles, row ids, key vectors: 8 GB per 1e9-row group-by otherwise)
+    void end_session() { aq::dev::Runtime::get().release_session(); aq::dev::Runtime::get().drop_pins(); }
 };
 
 #define __DLLEXPORT__

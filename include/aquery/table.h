@@ -526,3 +526,19 @@ AQ_AQOP(lte, AQG_OP_LE)
 AQ_AQOP(eq, AQG_OP_EQ)
 AQ_AQOP(neq, AQG_OP_NE)
 #undef AQ_AQOP
+
+// ---- ABI facts shared with the reference's C views (server/vector_type.hpp:25-28, server/table.h:34-39 == sdk/aquery.h:105-128)
+// and probed against the reference headers themselves: one edit of these classes must not silently break
+// user modules that reinterpret a ColRef as a ColRef_storage.
+#include <cstddef>
+static_assert(sizeof(vectortype_cstorage) == 16 && sizeof(ColRef_cstorage) == 32, "C views of vector_type / ColRef");
+static_assert(sizeof(vector_type<int>) == 16 && sizeof(vector_type<double>) == 16 && sizeof(vector_type<void>) == 16, "vector_type is the packed {container, size, capacity} triple");
+static_assert(sizeof(ColRef<int>) == 40 && sizeof(ColRef<float>) == 40 && sizeof(ColRef<void>) == 40, "ColRef<4-byte T>: 40 bytes (the stride of TableInfo::colrefs)");
+static_assert(sizeof(ColRef<double>) == 48 && sizeof(ColRef<long long>) == 48, "ColRef<8-byte T>: 48 bytes");
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Winvalid-offsetof"
+namespace aq { namespace abi {
+struct ColRefProbe : ColRef<int> { static constexpr size_t name_off() { return offsetof(ColRefProbe, name); } static constexpr size_t ty_off() { return offsetof(ColRefProbe, ty); } };
+} }
+static_assert(aq::abi::ColRefProbe::name_off() == 16 && aq::abi::ColRefProbe::ty_off() == 24, "ColRef: name @16, ty @24 (ColRef_cstorage / sdk ColRef_storage)");
+#pragma GCC diagnostic pop

@@ -37,6 +37,19 @@ static std::vector<std::vector<int>> dataset(const std::string& name) {
         }
         return t;
     }
+    if (name == "synthetic_big") {  // 3,000,000 rows, ~1,000,000 groups on column a (h2o Q5-like cardinality through the header loop)
+        const int n = 3000000;
+        std::vector<std::vector<int>> t(4, std::vector<int>(n));
+        unsigned long long x = 777;
+        for (int i = 0; i < n; ++i) {
+            x = x * 6364136223846793005ULL + 1442695040888963407ULL;
+            t[0][i] = (int)((x >> 33) % 1000003);
+            t[1][i] = 7;
+            t[2][i] = (int)((x >> 20) % 97);
+            t[3][i] = 1;
+        }
+        return t;
+    }
     return {};
 }
 
@@ -66,6 +79,7 @@ int main(int argc, char** argv) {
         rc |= fn(cxt);
         std::fflush(stdout);
     }
+    if (auto fini = reinterpret_cast<void (*)(Context*)>(dlsym(handle, "__AQ_End_Session__"))) fini(cxt);   // the module's own device state
     cxt->end_session();
     return rc;
 }

@@ -69,6 +69,11 @@ def test_config2_q10_six_keys(gpu, oracle):
     assert np.array_equal(gb.counts(), o["counts"])
     for k, c in enumerate(ids):
         assert np.array_equal(gb.keys(k, np.int32), host[c][o["first_rows"]])
+    # sum(v3): float32 values accumulated in double; any summation order stays inside (n - 1) 2^-53 sum|x| of the reference's
+    got, want = gb.result(0, ck.RED_SUM, ck.FLOAT).astype(np.float64), oracle.grouped_reduce(ck.RED_SUM, host[ck.GEN_V3], o).astype(np.float64)
+    cnt = o["counts"].astype(np.float64)
+    assert np.all(np.abs(got - want) <= np.maximum(cnt - 1, 0) * 2.0 ** -53 * np.abs(want) + 1e-300)
+    assert np.array_equal(gb.result(1, ck.RED_COUNT, ck.FLOAT), oracle.grouped_reduce(ck.RED_COUNT, host[ck.GEN_V3], o))
 
 
 def test_config3_moving_windows_over_ordered_series(gpu, oracle):
