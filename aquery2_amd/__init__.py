@@ -6,4 +6,4 @@ the reference's header-level API.  This Python package is a thin ctypes harness 
 used by tests/ and bench.py; it contains no compute of its own and no CPU fallback.
 """
 from . import capi  # noqa: F401
-from .capi import Device, DevBuf, AqgError, lib_path, load_library  # noqa: F401
+from .capi import Device, DevBuf, AqgError, Comm, ThreadRanks, lib_path, load_library  # noqa: F401

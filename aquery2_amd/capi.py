@@ -54,6 +54,7 @@ def load_library():
         lib.aqg_ctx_stream.restype = C.c_void_p
         lib.aqg_groupby_ngroups.restype = C.c_uint32
         lib.aqg_groupby_nrows.restype = C.c_uint32
+        lib.aqg_groupby_first_rows64.restype = C.c_void_p
         for f in ("aqg_groupby_reversemap", "aqg_groupby_counts", "aqg_groupby_first_rows", "aqg_groupby_agg_result"):
             getattr(lib, f).restype = C.c_void_p
         _LIB = lib
@@ -125,6 +126,10 @@ class GroupBy:
     def first_rows(self):
         return self._view("aqg_groupby_first_rows", np.uint32, self.ngroups)
 
+    def first_rows64(self):
+        """global row id of every group's first row (handles of aqg_groupby_agg_sharded)"""
+        return self._view("aqg_groupby_first_rows64", np.int64, self.ngroups)
+
     def keys(self, k, dtype):
         out = self.dev.empty(self.ngroups, dtype)
         self.dev._chk(self.dev.lib.aqg_groupby_keys(self.h, k, C.c_void_p(out.ptr)), "aqg_groupby_keys")
@@ -153,6 +158,114 @@ class GroupBy:
             self.destroy()
         except Exception:
             pass
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class Comm:
+    """One communicator of the library's own exchange (include/aqg.h: aqg_comm_*).  `nccl_id`: the AQG_COMM_ID_BYTES bytes rank 0
+    got from Comm.unique_id() -- RCCL; `allgather`: a Python callable (send_ptr, recv_ptr, nbytes, stream) -> 0 -- a caller-supplied
+    transport (tests / one-GPU rehearsals)."""
+
+    def __init__(self, dev, rank, world, nccl_id=None, allgather=None):
+        self.dev, self.rank, self.world = dev, rank, world
+        h = C.c_void_p()
+        if allgather is not None:
+            self._cb = ALLGATHER_FN(lambda user, send, recv, nbytes, stream: int(allgather(send, recv, nbytes, stream)))
+            dev._chk(dev.lib.aqg_comm_init_custom(dev.ctx, rank, world, self._cb, None, C.byref(h)), "aqg_comm_init_custom")
+        else:
+            assert nccl_id is not None and len(nccl_id) == 128
+            buf = (C.c_char * 128).from_buffer_copy(bytes(nccl_id))
+            dev._chk(dev.lib.aqg_comm_init_rccl(dev.ctx, rank, world, buf, C.byref(h)), "aqg_comm_init_rccl")
+        self.h = h
+
+    @staticmethod
+    def unique_id(lib=None):
+        lib = lib or load_library()
+        buf = (C.c_char * 128)()
+        rc = lib.aqg_comm_unique_id(buf)
+        if rc != 0:
+            raise AqgError("aqg_comm_unique_id", rc)
+        return bytes(buf.raw)
+
+    def groupby_agg_sharded(self, keys, ops, vals, row_base, hint=0, gmax=0, handle=None):
+        d = self.dev
+        kd, dts, ptrs = d._keyargs(keys)
+        vd = [d._dev(v) if v is not None else None for v in vals]
+        vdt = (C.c_int * max(1, len(vd)))(*[(v.tag if v is not None else INT32) for v in vd])
+        vp = (C.c_void_p * max(1, len(vd)))(*[(v.ptr if v is not None else None) for v in vd])
+        opa = (C.c_int * max(1, len(ops)))(*ops)
+        h = handle.h if handle is not None else C.c_void_p()
+        d._chk(d.lib.aqg_groupby_agg_sharded(self.h, len(kd), dts, ptrs, len(ops), opa, vdt, vp, C.c_uint32(kd[0].n), C.c_uint64(row_base),
+                                             C.c_uint32(hint), C.c_uint32(gmax), C.byref(h)), "aqg_groupby_agg_sharded")
+        gb = handle if handle is not None else GroupBy(d, h)
+        gb._keep = (kd, vd)
+        return gb
+
+    def groupby_exchange(self, local, merge_ops, row_base, gmax=0, handle=None):
+        """the exchange alone over an existing shard table (aqg_groupby_exchange): partial p = aggregate p of `local`"""
+        d = self.dev
+        opa = (C.c_int * max(1, len(merge_ops)))(*merge_ops)
+        h = handle.h if handle is not None else C.c_void_p()
+        d._chk(d.lib.aqg_groupby_exchange(self.h, local.h, len(merge_ops), opa, C.c_uint64(row_base), C.c_uint32(gmax), C.byref(h)), "aqg_groupby_exchange")
+        return handle if handle is not None else GroupBy(d, h)
+
+    def destroy(self):
+        if self.h and self.dev.ctx:
+            self.dev.lib.aqg_comm_destroy(self.h)
+        self.h = None
+
+
+class ThreadRanks:
+    """`world` ranks as THREADS of one process, each with its own context (and stream) on the same GPU, and an all-gather made of
+    device copies and a barrier: drives the C code of the sharded group-by end to end where only one GPU is there (RCCL refuses two
+    ranks on one device).  run(fn) calls fn(rank, dev, comm) on every rank and returns the results in rank order."""
+
+    def __init__(self, world, device=0):
+        import threading
+        self.world = world
+        self.devs = [Device(device) for _ in range(world)]
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.comms = [Comm(self.devs[r], r, world, allgather=self._make(r)) for r in range(world)]
+
+    def _make(self, rank):
+        def gather(send, recv, nbytes, stream):
+            dev = self.devs[rank]
+            dev.sync()                                   # the pack kernel behind `send` has run
+            self.slots[rank] = send
+            self.barrier.wait()
+            for r in range(self.world):
+                dev._chk(dev.lib.aqg_d2d(dev.ctx, C.c_void_p(recv + r * nbytes), C.c_void_p(self.slots[r]), C.c_size_t(nbytes)), "aqg_d2d")
+            dev.sync()
+            self.barrier.wait()                          # nobody reuses its send buffer before everybody has copied it
+            return 0
+        return gather
+
+    def run(self, fn):
+        import threading
+        out, err = [None] * self.world, [None] * self.world
+        def body(r):
+            try:
+                out[r] = fn(r, self.devs[r], self.comms[r])
+            except BaseException as e:                   # noqa: BLE001 -- reported to the caller below
+                err[r] = e
+                self.barrier.abort()
+        th = [threading.Thread(target=body, args=(r,)) for r in range(self.world)]
+        for t in th: t.start()
+        for t in th: t.join()
+        for e in err:
+            if e is not None and not isinstance(e, __import__("threading").BrokenBarrierError):
+                raise e
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+    def close(self):
+        for c in self.comms: c.destroy()
+        for d in self.devs: d.close()
 
 
 class Device:

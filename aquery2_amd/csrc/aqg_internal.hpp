@@ -32,6 +32,7 @@ struct aqg_ctx {
     hipEvent_t up_ev[2] = {nullptr, nullptr};
     bool tail_in_flight = false;                 // the last group-by returned with its tail kernels still queued (stream-ordered)
     bool evk_valid = false;
+    bool evk_frozen = false;                     // the exchange's re-aggregation must not replace the row pass as "the dominant kernel"
     std::unordered_map<const void*, aqg_pin> pins;
     std::unordered_map<const void*, int> max_lds;   // largest dynamic LDS size already granted per kernel (aqg_allow_lds)
     // pinned host staging for small results
@@ -79,8 +80,8 @@ int aqg_host_stage(aqg_ctx* ctx, size_t bytes, void** out);
 int aqg_exclusive_scan_u32(aqg_ctx* ctx, uint32_t* d, uint64_t count, uint32_t* bsum);
 
 // HIP events around the dominant kernel of a call (read back by aqg_last_kernel_ms)
-static inline void aqg_kernel_timer_begin(aqg_ctx* ctx) { (void)hipEventRecord(ctx->evk0, ctx->stream); }
-static inline void aqg_kernel_timer_end(aqg_ctx* ctx) { (void)hipEventRecord(ctx->evk1, ctx->stream); ctx->evk_valid = true; }
+static inline void aqg_kernel_timer_begin(aqg_ctx* ctx) { if (!ctx->evk_frozen) (void)hipEventRecord(ctx->evk0, ctx->stream); }
+static inline void aqg_kernel_timer_end(aqg_ctx* ctx) { if (!ctx->evk_frozen) { (void)hipEventRecord(ctx->evk1, ctx->stream); ctx->evk_valid = true; } }
 
 // launch check
 static inline int aqg_check_launch(aqg_ctx* ctx, const char* what) {

@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) xfinal_kernel(FinalSpec fs, uint32_t G) {
             const bool fp = fs.dt[j] == AQG_FLOAT || fs.dt[j] == AQG_DOUBLE;
             const bool uns = fs.dt[j] == AQG_UINT8 || fs.dt[j] == AQG_UINT16 || fs.dt[j] == AQG_UINT32 || fs.dt[j] == AQG_UINT64 || fs.dt[j] == AQG_BOOL;
             switch (fs.op[j]) {
-            case AQG_RED_COUNT: static_cast<uint64_t*>(fs.out[j])[g] = static_cast<const aqg_i128*>(fs.a[j])[g].lo; break;
+            case AQG_RED_COUNT: static_cast<uint64_t*>(fs.out[j])[g] = static_cast<const aqg_i128*>(fs.a[j])[g].lo; break;   // sum of uint32 counts: unsigned 128-bit
             case AQG_RED_AVG: {                                               // sum / (double)size (aggregations.h:28-32)
                 const aqg_i128 cn = static_cast<const aqg_i128*>(fs.b[j])[g];
                 double s;
@@ -180,6 +180,86 @@ __global__ void __launch_bounds__(256) xfinal_kernel(FinalSpec fs, uint32_t G) {
             }
         }
     }
+}
+
+// steps 2-4 of the sharded group-by over an existing shard table L (keys, 32-bit first rows, one result column per partial):
+// sizes the payload, packs, ONE all-gather, concatenates, re-aggregates into comm->merged (aggregate 0 = MIN of the global first rows)
+int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtypes, int nparts, const int* part_dt, const int* merge_op,
+                  uint64_t row_base, uint32_t max_groups_hint, uint32_t gmax) {
+    aqg_ctx* ctx = comm->ctx;
+    const uint32_t G = L->ngroups;
+    // ---- 2. capacity of the exchange: the caller's bound, or the largest shard table (one 8-byte all-gather and a host read) -------
+    const uint32_t world = (uint32_t)comm->world;
+    uint32_t gcap = gmax;
+    if (gmax) { if (G > gmax) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: a shard has more groups than gmax"); }
+    else {
+        AQG_TRY(grow(ctx, &comm->hdr, &comm->hdr_cap, 8 * ((size_t)world + 1)));
+        uint64_t* h = static_cast<uint64_t*>(comm->hdr);
+        const uint64_t mine = G;
+        AQG_HIP(ctx, hipMemcpyAsync(h + world, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
+        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));                    // (`mine` is a stack variable)
+        AQG_TRY(allgather(comm, h + world, h, 8));
+        uint64_t all[64];
+        AQG_HIP(ctx, hipMemcpyAsync(all, h, 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        uint64_t mx = 1;
+        for (uint32_t r = 0; r < world; ++r) mx = all[r] > mx ? all[r] : mx;
+        gcap = (uint32_t)mx;
+    }
+    const int ncols = nkeys + 1 + nparts;
+    const size_t words = 2 + (size_t)ncols * gcap, bytes = words * 8;
+    if ((uint64_t)gcap * world > AQG_MAX_ROWS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: world x group capacity exceeds AQG_MAX_ROWS");
+    AQG_TRY(grow(ctx, &comm->send, &comm->send_cap, bytes));
+    AQG_TRY(grow(ctx, &comm->recv, &comm->recv_cap, bytes * world));
+    // ---- 3. pack, ONE all-gather, concatenate ----------------------------------------------------------------------------------------
+    PackSpec ps;
+    memset(&ps, 0, sizeof ps);
+    ps.ncols = ncols; ps.nkeys = nkeys; ps.row_base = row_base;
+    for (int k = 0; k < nkeys; ++k) { ps.src[k] = L->keys_out[k]; ps.src_dt[k] = key_dtypes[k]; }
+    ps.src[nkeys] = L->first_rows; ps.src_dt[nkeys] = AQG_UINT32;
+    for (int p = 0; p < nparts; ++p) { ps.src[nkeys + 1 + p] = L->results[p]; ps.src_dt[nkeys + 1 + p] = L->res_dt[p]; }
+    hipLaunchKernelGGL(xpack_kernel, dim3(aqg_grid(ctx, (uint64_t)ncols * G + 1, 256, 2, 4)), dim3(256), 0, ctx->stream, ps, G, gcap, static_cast<uint64_t*>(comm->send));
+    AQG_TRY(aqg_check_launch(ctx, "xpack_kernel"));
+    AQG_TRY(allgather(comm, comm->send, comm->recv, bytes));
+    // concatenated columns: keys in their own dtypes, first rows and partials
+    const size_t cat_rows = (size_t)gcap * world;
+    size_t col_off[MAXKEYS + 1 + MAXPART], cat_bytes = 0;
+    int col_dt[MAXKEYS + 1 + MAXPART];
+    for (int c = 0; c < ncols; ++c) {
+        col_dt[c] = c < nkeys ? key_dtypes[c] : c == nkeys ? AQG_INT64 : part_dt[c - nkeys - 1];
+        col_off[c] = cat_bytes;
+        cat_bytes += (cat_rows * aqg_dtype_size(col_dt[c]) + 255) & ~(size_t)255;
+    }
+    AQG_TRY(grow(ctx, &comm->cat, &comm->cat_cap, cat_bytes + 256));
+    UnpackSpec us;
+    memset(&us, 0, sizeof us);
+    us.ncols = ncols;
+    for (int c = 0; c < ncols; ++c) { us.dst[c] = static_cast<char*>(comm->cat) + col_off[c]; us.dst_dt[c] = col_dt[c]; }
+    hipLaunchKernelGGL(xunpack_kernel, dim3(aqg_grid(ctx, (uint64_t)ncols * gcap + 1, 256, 2, 4)), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(comm->recv), world, gcap, words, us);
+    AQG_TRY(aqg_check_launch(ctx, "xunpack_kernel"));
+    // the number of concatenated rows: sum of the headers (one small copy)
+    uint64_t total = 0;
+    {
+        uint64_t hd[64];
+        for (uint32_t r = 0; r < world; ++r) AQG_HIP(ctx, hipMemcpyAsync(&hd[r], static_cast<const uint64_t*>(comm->recv) + (size_t)r * words, 8, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (uint32_t r = 0; r < world; ++r) total += hd[r];
+    }
+    if (total > AQG_MAX_ROWS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: more shard groups than AQG_MAX_ROWS");
+    // ---- 4. re-aggregate the concatenation (first occurrence in it = global first occurrence) ------------------------------------------
+    int mops[MAXAGG], mdts[MAXAGG];
+    const void* mvals[MAXAGG];
+    const void* mkeys[MAXKEYS];
+    for (int k = 0; k < nkeys; ++k) mkeys[k] = us.dst[k];
+    mops[0] = AQG_RED_MIN; mdts[0] = AQG_INT64; mvals[0] = us.dst[nkeys];
+    for (int p = 0; p < nparts; ++p) { mops[1 + p] = merge_op[p]; mdts[1 + p] = part_dt[p]; mvals[1 + p] = us.dst[nkeys + 1 + p]; }
+    uint64_t mhint = total < 64 ? 64 : total;
+    if (max_groups_hint && (uint64_t)max_groups_hint * world < mhint) mhint = (uint64_t)max_groups_hint * world;
+    ctx->evk_frozen = true;                  // aqg_last_kernel_ms keeps naming the pass over the shard's rows
+    const int mrc = aqg_groupby_agg(ctx, nkeys, key_dtypes, mkeys, nparts + 1, mops, mdts, mvals, (uint32_t)total, (uint32_t)mhint, &comm->merged);
+    ctx->evk_frozen = false;
+    AQG_TRY(mrc);
+    return AQG_OK;
 }
 
 bool small_int(int dt) { return dt == AQG_INT8 || dt == AQG_INT16 || dt == AQG_INT32 || dt == AQG_UINT8 || dt == AQG_UINT16 || dt == AQG_UINT32 || dt == AQG_BOOL; }
@@ -238,6 +318,42 @@ int aqg_comm_world(const aqg_comm* c) { return c ? c->world : 0; }
 
 const int64_t* aqg_groupby_first_rows64(const aqg_groupby* g) { return g ? g->first_rows64 : nullptr; }
 
+int aqg_groupby_exchange(aqg_comm* comm, aqg_groupby* local, int nparts, const int* merge_ops, uint64_t row_base, uint32_t gmax, aqg_groupby** out) {
+    if (!comm || !local || !out || nparts < 0 || nparts + 1 > MAXAGG || nparts > local->nagg) return aqg_fail(comm ? comm->ctx : nullptr, AQG_ERR_ARG, "aqg_groupby_exchange: bad argument (at most 7 partial columns)");
+    aqg_ctx* ctx = comm->ctx;
+    int pdt[MAXPART];
+    for (int p = 0; p < nparts; ++p) {
+        const int rdt = local->res_dt[p], op = merge_ops[p];
+        if (!(op == AQG_RED_SUM || op == AQG_RED_MIN || op == AQG_RED_MAX)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_exchange: partials combine with SUM / MIN / MAX");
+        if (op == AQG_RED_SUM) pdt[p] = (rdt == AQG_DOUBLE || rdt == AQG_FLOAT) ? AQG_DOUBLE : rdt == AQG_UINT64 ? AQG_UINT32 : AQG_INT64;   // 128-bit sums travel as their low 64 bits, counts as 32
+        else pdt[p] = rdt;
+        if (op == AQG_RED_SUM && rdt == AQG_FLOAT) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_exchange: a float column is not a partial sum");
+    }
+    AQG_TRY(exchange_core(comm, local, local->nkeys, local->key_dt, nparts, pdt, merge_ops, row_base, 0, gmax));
+    aqg_groupby* M = comm->merged;
+    aqg_groupby* H = *out ? *out : new aqg_groupby();
+    H->ctx = ctx; H->n = local->n; H->ngroups = M->ngroups; H->nkeys = local->nkeys; H->nagg = nparts;
+    H->has_counts = false; H->has_reversemap = false; H->sharded = true;
+    const size_t GG = M->ngroups ? M->ngroups : 1;
+    int rc = AQG_OK;
+    auto d2d = [&](void* dst, const void* src, size_t bytes) { return !bytes || hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? AQG_OK : AQG_ERR_HIP; };
+    for (int k = 0; k < local->nkeys && rc == AQG_OK; ++k) {
+        H->key_dt[k] = local->key_dt[k];
+        rc = grow(ctx, &H->keys_out[k], &H->cap_keys[k], GG * 8);
+        if (rc == AQG_OK) rc = d2d(H->keys_out[k], M->keys_out[k], (size_t)M->ngroups * aqg_dtype_size(local->key_dt[k]));
+    }
+    if (rc == AQG_OK) rc = grow(ctx, reinterpret_cast<void**>(&H->first_rows64), &H->cap_first64, GG * 8);
+    if (rc == AQG_OK) rc = d2d(H->first_rows64, M->results[0], (size_t)M->ngroups * 8);
+    for (int p = 0; p < nparts && rc == AQG_OK; ++p) {
+        H->res_dt[p] = M->res_dt[1 + p];
+        rc = grow(ctx, &H->results[p], &H->cap_results[p], GG * 16);
+        if (rc == AQG_OK) rc = d2d(H->results[p], M->results[1 + p], (size_t)M->ngroups * aqg_dtype_size(M->res_dt[1 + p]));
+    }
+    if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(H); return rc == AQG_ERR_HIP ? aqg_fail(ctx, rc, "aqg_groupby_exchange: device copy failed") : rc; }
+    *out = H;
+    return AQG_OK;
+}
+
 int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, const void* const* keys, int naggs, const int* ops, const int* val_dtypes,
                             const void* const* vals, uint32_t n, uint64_t row_base, uint32_t max_groups_hint, uint32_t gmax, aqg_groupby** out) {
     if (!comm || !out) return AQG_ERR_ARG;
@@ -252,7 +368,7 @@ int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, co
         Partial& P = parts[nparts];
         P.local_op = lop; P.val_dt = dt; P.val_index = j;
         if (lop == AQG_RED_SUM) { P.part_dt = is_fp(dt) ? AQG_DOUBLE : AQG_INT64; P.merge_op = AQG_RED_SUM; }
-        else if (lop == AQG_RED_COUNT) { P.part_dt = AQG_INT64; P.merge_op = AQG_RED_SUM; }
+        else if (lop == AQG_RED_COUNT) { P.part_dt = AQG_UINT32; P.merge_op = AQG_RED_SUM; }   // a shard has < 2^32 rows: one accumulator in the merge
         else { P.part_dt = dt; P.merge_op = lop; }
         return nparts++;
     };
@@ -275,74 +391,9 @@ int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, co
     AQG_TRY(aqg_groupby_agg(ctx, nkeys, key_dtypes, keys, nparts, lops, ldts, lvals, n, max_groups_hint, &comm->local));
     aqg_groupby* L = comm->local;
     const uint32_t G = L->ngroups;
-    // ---- 2. capacity of the exchange: the caller's bound, or the largest shard table (one 8-byte all-gather and a host read) -------
-    const uint32_t world = (uint32_t)comm->world;
-    uint32_t gcap = gmax;
-    if (gmax) { if (G > gmax) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: a shard has more groups than gmax"); }
-    else {
-        AQG_TRY(grow(ctx, &comm->hdr, &comm->hdr_cap, 8 * ((size_t)world + 1)));
-        uint64_t* h = static_cast<uint64_t*>(comm->hdr);
-        const uint64_t mine = G;
-        AQG_HIP(ctx, hipMemcpyAsync(h + world, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
-        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));                    // (`mine` is a stack variable)
-        AQG_TRY(allgather(comm, h + world, h, 8));
-        uint64_t all[64];
-        AQG_HIP(ctx, hipMemcpyAsync(all, h, 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
-        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        uint64_t mx = 1;
-        for (uint32_t r = 0; r < world; ++r) mx = all[r] > mx ? all[r] : mx;
-        gcap = (uint32_t)mx;
-    }
-    const int ncols = nkeys + 1 + nparts;
-    const size_t words = 2 + (size_t)ncols * gcap, bytes = words * 8;
-    if ((uint64_t)gcap * world > AQG_MAX_ROWS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: world x group capacity exceeds AQG_MAX_ROWS");
-    AQG_TRY(grow(ctx, &comm->send, &comm->send_cap, bytes));
-    AQG_TRY(grow(ctx, &comm->recv, &comm->recv_cap, bytes * world));
-    // ---- 3. pack, ONE all-gather, concatenate ----------------------------------------------------------------------------------------
-    PackSpec ps;
-    memset(&ps, 0, sizeof ps);
-    ps.ncols = ncols; ps.nkeys = nkeys; ps.row_base = row_base;
-    for (int k = 0; k < nkeys; ++k) { ps.src[k] = L->keys_out[k]; ps.src_dt[k] = key_dtypes[k]; }
-    ps.src[nkeys] = L->first_rows; ps.src_dt[nkeys] = AQG_UINT32;
-    for (int p = 0; p < nparts; ++p) { ps.src[nkeys + 1 + p] = L->results[p]; ps.src_dt[nkeys + 1 + p] = L->res_dt[p]; }
-    hipLaunchKernelGGL(xpack_kernel, dim3(aqg_grid(ctx, (uint64_t)ncols * G + 1, 256, 2, 4)), dim3(256), 0, ctx->stream, ps, G, gcap, static_cast<uint64_t*>(comm->send));
-    AQG_TRY(aqg_check_launch(ctx, "xpack_kernel"));
-    AQG_TRY(allgather(comm, comm->send, comm->recv, bytes));
-    // concatenated columns: keys in their own dtypes, first rows and partials
-    const size_t cat_rows = (size_t)gcap * world;
-    size_t col_off[MAXKEYS + 1 + MAXPART], cat_bytes = 0;
-    int col_dt[MAXKEYS + 1 + MAXPART];
-    for (int c = 0; c < ncols; ++c) {
-        col_dt[c] = c < nkeys ? key_dtypes[c] : c == nkeys ? AQG_INT64 : parts[c - nkeys - 1].part_dt;
-        col_off[c] = cat_bytes;
-        cat_bytes += (cat_rows * aqg_dtype_size(col_dt[c]) + 255) & ~(size_t)255;
-    }
-    AQG_TRY(grow(ctx, &comm->cat, &comm->cat_cap, cat_bytes + 256));
-    UnpackSpec us;
-    memset(&us, 0, sizeof us);
-    us.ncols = ncols;
-    for (int c = 0; c < ncols; ++c) { us.dst[c] = static_cast<char*>(comm->cat) + col_off[c]; us.dst_dt[c] = col_dt[c]; }
-    hipLaunchKernelGGL(xunpack_kernel, dim3(aqg_grid(ctx, (uint64_t)ncols * gcap + 1, 256, 2, 4)), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(comm->recv), world, gcap, words, us);
-    AQG_TRY(aqg_check_launch(ctx, "xunpack_kernel"));
-    // the number of concatenated rows: sum of the headers (one small copy)
-    uint64_t total = 0;
-    {
-        uint64_t hd[64];
-        for (uint32_t r = 0; r < world; ++r) AQG_HIP(ctx, hipMemcpyAsync(&hd[r], static_cast<const uint64_t*>(comm->recv) + (size_t)r * words, 8, hipMemcpyDeviceToHost, ctx->stream));
-        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t r = 0; r < world; ++r) total += hd[r];
-    }
-    if (total > AQG_MAX_ROWS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: more shard groups than AQG_MAX_ROWS");
-    // ---- 4. re-aggregate the concatenation (first occurrence in it = global first occurrence) ------------------------------------------
-    int mops[MAXAGG], mdts[MAXAGG];
-    const void* mvals[MAXAGG];
-    const void* mkeys[MAXKEYS];
-    for (int k = 0; k < nkeys; ++k) mkeys[k] = us.dst[k];
-    mops[0] = AQG_RED_MIN; mdts[0] = AQG_INT64; mvals[0] = us.dst[nkeys];
-    for (int p = 0; p < nparts; ++p) { mops[1 + p] = parts[p].merge_op; mdts[1 + p] = parts[p].part_dt; mvals[1 + p] = us.dst[nkeys + 1 + p]; }
-    uint64_t mhint = total < 64 ? 64 : total;
-    if (max_groups_hint && (uint64_t)max_groups_hint * world < mhint) mhint = (uint64_t)max_groups_hint * world;
-    AQG_TRY(aqg_groupby_agg(ctx, nkeys, key_dtypes, mkeys, nparts + 1, mops, mdts, mvals, (uint32_t)total, (uint32_t)mhint, &comm->merged));
+    int pdt[MAXPART], mop[MAXPART];
+    for (int p = 0; p < nparts; ++p) { pdt[p] = parts[p].part_dt; mop[p] = parts[p].merge_op; }
+    AQG_TRY(exchange_core(comm, L, nkeys, key_dtypes, nparts, pdt, mop, row_base, max_groups_hint, gmax));
     aqg_groupby* M = comm->merged;
     // ---- 5. the result handle: keys and global first rows of the merged table, every aggregate in its own result dtype --------------
     aqg_groupby* H = *out ? *out : new aqg_groupby();

@@ -1377,6 +1377,7 @@ void aqg_groupby_destroy(aqg_groupby* g) {
     if (g->counts) hipFree(g->counts);
     if (g->reversemap) hipFree(g->reversemap);
     if (g->scratch) aqg_groupby_destroy(g->scratch);
+    if (g->first_rows64) hipFree(g->first_rows64);
     if (g->xkeys) hipFree(g->xkeys);
     if (g->xvals) hipFree(g->xvals);
     delete g;
@@ -1385,7 +1386,7 @@ uint32_t aqg_groupby_ngroups(const aqg_groupby* g) { return g ? g->ngroups : 0; 
 uint32_t aqg_groupby_nrows(const aqg_groupby* g) { return g ? g->n : 0; }
 const uint32_t* aqg_groupby_reversemap(const aqg_groupby* g) { return g && g->has_reversemap ? g->reversemap : nullptr; }
 const uint32_t* aqg_groupby_counts(const aqg_groupby* g) { return g && g->has_counts ? g->counts : nullptr; }
-const uint32_t* aqg_groupby_first_rows(const aqg_groupby* g) { return g ? g->first_rows : nullptr; }
+const uint32_t* aqg_groupby_first_rows(const aqg_groupby* g) { return g && !g->sharded ? g->first_rows : nullptr; }
 const void* aqg_groupby_agg_result(const aqg_groupby* g, int j) { return g && j >= 0 && j < g->nagg ? g->results[j] : nullptr; }
 
 int aqg_groupby_keys(aqg_groupby* g, int k, void* out_dev) {

@@ -24,6 +24,10 @@ struct aqg_groupby {
     // the small merge path, which keeps one) while others are already large
     size_t cap_keys[MAXKEYS] = {0}, cap_first = 0, cap_counts = 0, cap_rows = 0, cap_results[MAXAGG] = {0};
     uint32_t hint_used = 0;
+    // aqg_groupby_agg_sharded: rows of a sharded table are numbered globally (64 bits); the 32-bit first rows are not filled
+    int64_t* first_rows64 = nullptr;
+    size_t cap_first64 = 0;
+    bool sharded = false;
     bool dense_exact = false;         // a sampled key range missed values once: take exact ranges from now on
     aqg_groupby* scratch = nullptr;   // reusable handle for aqg_grouped_reduce
     // aqg_groupby_merge_packed: the concatenated shard tables (keys / values), owned by the merged handle

@@ -143,7 +143,6 @@ def main():
 
     import torch
     import aquery2_amd
-    from aquery2_amd import shard
     import checker as ck
 
     # AQG_BENCH_REHEARSAL=1: every rank on GPU 0 and the exchange over gloo -- a way to run the N>1 code path on a one-GPU
@@ -169,13 +168,27 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     assert stream, "expected a non-default stream handle"
     dev = aquery2_amd.Device(gpu, stream=stream)
-    if world > 1:
-        # communicator set-up (lazy in RCCL: seconds on the first collective) happens here, never inside the timed region
-        _probe = torch.zeros(world, dtype=torch.int64, device=xdev)
-        dist.all_gather_into_tensor(_probe, torch.full((1,), rank, dtype=torch.int64, device=xdev))
-        if xdev == "cuda":
-            torch.cuda.synchronize()
-        assert _probe.tolist() == list(range(world))
+    # The exchange lives in the library (include/aqg.h: aqg_comm_*, aqg_groupby_agg_sharded): one communicator per rank, RCCL's
+    # ncclAllGather on the library's stream.  torch.distributed only carries the 128-byte RCCL id from rank 0 to the others (and
+    # the barrier / max-over-ranks of the timing).  Rehearsal and self-merge runs plug a host-side all-gather into the same C code.
+    comm = None
+    if world > 1 and not rehearsal:
+        idt = torch.zeros(128, dtype=torch.uint8, device=xdev)
+        if rank == 0:
+            idt = torch.tensor(list(aquery2_amd.Comm.unique_id()), dtype=torch.uint8, device=xdev)
+        dist.broadcast(idt, 0)
+        torch.cuda.synchronize()
+        comm = aquery2_amd.Comm(dev, rank, world, nccl_id=bytes(idt.cpu().tolist()))
+    elif world > 1:
+        def gloo_allgather(send, recv, nbytes, stream):
+            hs = np.empty(nbytes, np.uint8)
+            dev._chk(dev.lib.aqg_d2h(dev.ctx, ctypes.c_void_p(hs.ctypes.data), ctypes.c_void_p(send), ctypes.c_size_t(nbytes)), "aqg_d2h")
+            outs = torch.empty(world * nbytes, dtype=torch.uint8)
+            dist.all_gather_into_tensor(outs, torch.from_numpy(hs))
+            ho = outs.numpy()
+            dev._chk(dev.lib.aqg_h2d(dev.ctx, ctypes.c_void_p(recv), ctypes.c_void_p(ho.ctypes.data), ctypes.c_size_t(world * nbytes)), "aqg_h2d")
+            return 0
+        comm = aquery2_amd.Comm(dev, rank, world, allgather=gloo_allgather)
     id1 = dev.gen_column(ck.GEN_ID1, 42, rank * n, n, n_total, 100)
     v1 = dev.gen_column(ck.GEN_V1, 42, rank * n, n, n_total, 100)
     join = args.workload == "join"
@@ -187,40 +200,43 @@ def main():
         dim_key, dim_w = dev.to_device(dim_key_h), dev.to_device(dim_w_h)
     dev.sync()
 
-    # AQG_BENCH_SELFMERGE=1 (N=1 only): run the exchange step against a one-rank stand-in for torch.distributed, to time
-    # what the merge adds on top of the row pass without a second GPU.  Never set by the driver.
+    # AQG_BENCH_SELFMERGE=1 (N=1 only): the whole sharded call with a world of one (pack, a device copy standing in for the
+    # all-gather, concatenate, re-aggregate, finalise) -- what the exchange adds on top of the row pass.  Never set by the driver.
     selfmerge = world == 1 and os.environ.get("AQG_BENCH_SELFMERGE") == "1"
     if selfmerge:
-        class _OneRank:
-            @staticmethod
-            def get_world_size(): return 1
-            @staticmethod
-            def all_gather_into_tensor(out, inp): out.copy_(inp)
-        dist = _OneRank()
+        def self_allgather(send, recv, nbytes, stream):
+            dev._chk(dev.lib.aqg_d2d(dev.ctx, ctypes.c_void_p(recv), ctypes.c_void_p(send), ctypes.c_size_t(nbytes)), "aqg_d2d")
+            return 0
+        comm = aquery2_amd.Comm(dev, 0, 1, allgather=self_allgather)
     state = {"gb": None, "merged": None}
-    GMAX = 128                     # the group-by hint: upper bound of a shard's group count (h2o K=100)
+    GMAX = 128                     # upper bound of a shard's group count (h2o K=100): fixed-size payload, ONE collective per step
     kernel_ms = []
 
-    # set-up outside any step: the argument arrays of the Q1 call are marshalled once (a prepared call: every step still runs the
-    # whole aqg_groupby_agg), the exchange buffers are allocated once
-    if not join:
+    # set-up outside any step: the argument arrays of the N=1 Q1 call are marshalled once (a prepared call: every step still runs the
+    # whole aqg_groupby_agg)
+    if not join and comm is None:
         state["q1"], state["gb"] = dev.prepare_groupby_agg([id1], [ck.RED_SUM], [v1], hint=128)
-    if world > 1 or selfmerge:
-        state["xchg"] = shard.GroupTableExchange(dev, dist, GMAX, ck.INT32, ck.RED_SUM, xdev)
+    if comm is not None:                       # communicator warm-up (RCCL sets its channels up on the first collective)
+        w = comm.groupby_agg_sharded([id1], [ck.RED_SUM], [v1], row_base=rank * n, hint=128, gmax=GMAX)
+        w.destroy()
 
     def step(record):
         if join:
             gb = dev.join_groupby_sum(dim_key, dim_w, id4, id1, v1, hint=128, handle=state["gb"])
+            state["gb"] = gb
+            if record:
+                kernel_ms.append(dev.last_kernel_ms())
+            if comm is not None:               # the shard tables of the fused join: one partial (the 128-bit sum) per group
+                state["merged"] = comm.groupby_exchange(gb, [ck.RED_SUM], row_base=rank * n, gmax=GMAX, handle=state["merged"])
+        elif comm is not None:
+            # ONE library call: this rank's group-by, pack, ONE all-gather of 129 x 3 words per rank, re-aggregation on every rank
+            state["merged"] = comm.groupby_agg_sharded([id1], [ck.RED_SUM], [v1], row_base=rank * n, hint=128, gmax=GMAX, handle=state["merged"])
+            if record:
+                kernel_ms.append(dev.last_kernel_ms())     # the pass over this shard's rows (the re-aggregation does not replace it)
         else:
-            gb = state["q1"]()
-        state["gb"] = gb
-        if record:
-            kernel_ms.append(dev.last_kernel_ms())
-        if world > 1 or selfmerge:
-            # one exchange: pack {key, partial sum} per group (one kernel), ONE all_gather of 129 int64 pairs per rank, one
-            # single-workgroup merge (aqg_groupby_merge_packed).  Shards are contiguous row ranges in rank order, so first
-            # occurrence in the concatenation is the global first occurrence.
-            state["merged"] = state["xchg"](gb, 0)
+            state["gb"] = state["q1"]()
+            if record:
+                kernel_ms.append(dev.last_kernel_ms())
 
     def fence():
         if world > 1:
@@ -242,8 +258,8 @@ def main():
         elapsed = float(t.item())
 
     # sanity: the merged / local result is the exact sum of v1 (checked against a second HIP reduction)
-    final = state["merged"] if world > 1 else state["gb"]
-    total = sum(ck.i128_to_int(final.result(0, ck.RED_SUM, ck.INT64 if (world > 1 or join) else ck.INT32)))
+    final = state["merged"] if comm is not None else state["gb"]
+    total = sum(ck.i128_to_int(final.result(0, ck.RED_SUM, ck.INT64 if join else ck.INT32)))
     if join:
         # independent check: sum(v1) by id4 (a plain group-by), dotted with w on the host
         by4 = dev.groupby_agg([id4], [ck.RED_SUM], [v1], hint=128)

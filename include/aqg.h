@@ -249,6 +249,44 @@ int aqg_groupby_pack(aqg_groupby* g, int agg_index, uint32_t gmax, int64_t* out_
 int aqg_groupby_merge_packed(aqg_ctx* ctx, const int64_t* gathered_dev, uint32_t world, uint32_t gmax, int key_dtype, int op,
                              aqg_groupby** out);
 
+/* ---- the exchange inside the library: communicators and the sharded group-by ----------------------------------------
+ * One communicator per (process, GPU).  aqg_comm_init_rccl: RCCL -- rank 0 makes an id with aqg_comm_unique_id (ncclGetUniqueId),
+ * the host ships its AQG_COMM_ID_BYTES bytes to the other ranks by any side channel (file, socket, torch.distributed, MPI) and
+ * every rank calls aqg_comm_init_rccl (ncclCommInitRank on the context's device); the all-gather is ncclAllGather on the
+ * context's stream, over xGMI inside a node.  librccl is opened on first use (dlopen), single-GPU users never load it.
+ * aqg_comm_init_custom: the caller supplies the all-gather (`bytes` bytes of every rank's device buffer `send_dev` into
+ * `recv_dev`, rank order, ordered on `hip_stream` or complete on return; 0 = success) -- hosts with a transport of their own,
+ * and the one-GPU rehearsals / tests of the sharded path.                                                                          */
+typedef struct aqg_comm aqg_comm;
+#define AQG_COMM_ID_BYTES 128
+typedef int (*aqg_allgather_fn)(void* user, const void* send_dev, void* recv_dev, size_t bytes, void* hip_stream);
+int aqg_comm_unique_id(void* id_out /* AQG_COMM_ID_BYTES, host */);
+int aqg_comm_init_rccl(aqg_ctx* ctx, int rank, int world, const void* id, aqg_comm** out);
+int aqg_comm_init_custom(aqg_ctx* ctx, int rank, int world, aqg_allgather_fn fn, void* user, aqg_comm** out);
+void aqg_comm_destroy(aqg_comm* comm);
+int aqg_comm_rank(const aqg_comm* comm);
+int aqg_comm_world(const aqg_comm* comm);
+/* aqg_groupby_agg over a table sharded by ROW RANGE: this rank holds rows [row_base, row_base + n) of every column.  Every rank
+ * groups its own rows, ONE all-gather moves the shards' group tables (k key columns, the global first row and one partial per
+ * aggregate: SUM -> sum, COUNT -> count, MIN / MAX -> itself, AVG -> sum and count), every rank re-aggregates the concatenation
+ * and gets the same merged result: keys / aggregates of all groups in GLOBAL first-occurrence order (shards are contiguous and
+ * gathered in rank order, so first occurrence in the concatenation is the global one: server/hasher.h:176-198 semantics).
+ * Integer sums are exact (128-bit results), AVG of integers is the exact sum over the count, as in the single-GPU call.
+ * gmax: upper bound of a shard's group count (fixed-size payload, nothing but the one all-gather crosses the wire: h2o Q1 / Q4 /
+ * config 4), or 0: the ranks first exchange their group counts (one 8-byte all-gather) and size the payload by the largest.
+ * ops: SUM / COUNT / MIN / MAX / AVG.  The result handle has no 32-bit first rows (aqg_groupby_first_rows returns NULL):
+ * aqg_groupby_first_rows64 gives the global row id of every group's first row.  `*out` is in/out like aqg_groupby_agg.             */
+int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, const void* const* keys,
+                            int naggs, const int* ops, const int* val_dtypes, const void* const* vals,
+                            uint32_t n, uint64_t row_base, uint32_t max_groups_hint, uint32_t gmax, aqg_groupby** out);
+const int64_t* aqg_groupby_first_rows64(const aqg_groupby* g);
+/* The exchange alone, over a shard table the caller already has (any aqg_groupby_agg / aqg_join_groupby_sum handle whose first
+ * `nparts` aggregates are decomposable partials): partial p combines with merge_ops[p] (SUM / MIN / MAX; counts and sums combine
+ * with SUM).  128-bit integer sums travel as their low 64 bits (exact while a SHARD's sum fits 64 bits) and come back as the exact
+ * 128-bit total; counts come back as 128-bit totals.  Result: keys, aqg_groupby_first_rows64 and aggregates 0 .. nparts-1 of the
+ * merged table in global first-occurrence order, as aqg_groupby_agg_sharded.                                                      */
+int aqg_groupby_exchange(aqg_comm* comm, aqg_groupby* local, int nparts, const int* merge_ops, uint64_t row_base, uint32_t gmax, aqg_groupby** out);
+
 /* Fused star join + grouped sum (BASELINE config 4: `fact JOIN small(key, w) ON fact.fk = small.key`, then
  * `sum(fact.val * small.w) BY fact.gkey`): one pass over fk, gkey and val (12 B/row) instead of lookup -> gather ->
  * multiply -> group-by (44 B/row).  The reference emits this as SQL for MonetDB (engine/ast.py:874-1085) followed by

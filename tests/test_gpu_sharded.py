@@ -1,0 +1,167 @@
+"""GPU parity of the library's own exchange (aqg_groupby_agg_sharded): a table cut into row-range shards, every shard
+grouped by its own rank, ONE all-gather of the shard tables, re-aggregation -- against the oracle's group-by of the WHOLE table:
+group order (global first occurrence), keys, global first rows, every aggregate.  Ranks are threads with their own contexts on the
+one GPU of the box and a copy-and-barrier all-gather (RCCL refuses two ranks on one device); the RCCL transport itself runs with a
+world of one.  The same C entry point is what bench.py --gpus N calls."""
+import numpy as np
+import pytest
+
+import checker as ck
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def shards_of(n, world, uneven=True):
+    cuts = [0] + sorted(np.random.default_rng(n + world).integers(0, n, world - 1).tolist()) + [n] if uneven else [n * r // world for r in range(world + 1)]
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def run_sharded(world, keys, ops, vals, hint=0, gmax=0, uneven=True, empty_rank=None):
+    import aquery2_amd
+    n = len(keys[0])
+    sh = shards_of(n, world, uneven)
+    if empty_rank is not None:
+        lo, hi = sh[empty_rank]
+        sh[empty_rank] = (hi, hi)
+        if empty_rank > 0: sh[empty_rank - 1] = (sh[empty_rank - 1][0], hi)
+        else: sh[1] = (lo, sh[1][1])
+    tr = aquery2_amd.ThreadRanks(world)
+    def body(rank, dev, comm):
+        lo, hi = sh[rank]
+        k = [np.ascontiguousarray(c[lo:hi]) for c in keys]
+        up = {}                                              # one device column per distinct host column (as a caller would hold them)
+        for c in vals:
+            if c is not None and id(c) not in up:
+                up[id(c)] = dev.to_device(np.ascontiguousarray(c[lo:hi]))
+        v = [up[id(c)] if c is not None else None for c in vals]
+        res = None
+        gb = None
+        for _ in range(2):                                   # the second call reuses every buffer of the first
+            gb = comm.groupby_agg_sharded(k, ops, v, row_base=lo, hint=hint, gmax=gmax, handle=gb)
+        res = {"G": gb.ngroups, "keys": [gb.keys(i, c.dtype) for i, c in enumerate(keys)], "first": gb.first_rows64(),
+               "res": [gb.result(j, op, ck.tag_of(vals[j]) if vals[j] is not None else ck.INT32) for j, op in enumerate(ops)]}
+        assert gb.first_rows() is None
+        gb.destroy()
+        return res
+    try:
+        return tr.run(body)
+    finally:
+        tr.close()
+
+
+def check(world, keys, ops, vals, oracle, **kw):
+    out = run_sharded(world, keys, ops, vals, **kw)
+    o = oracle.groupby(keys)
+    for r in out:
+        assert r["G"] == o["ngroups"]
+        assert np.array_equal(r["first"], o["first_rows"].astype(np.int64))
+        for i, c in enumerate(keys):
+            assert np.array_equal(r["keys"][i], c[o["first_rows"]])
+        for j, op in enumerate(ops):
+            x = vals[j] if vals[j] is not None else vals[0]
+            want = oracle.grouped_reduce(op, x, o)
+            got = r["res"][j]
+            if x.dtype.kind == "f" and op in (ck.RED_SUM, ck.RED_AVG):
+                w, g = want.astype(np.float64), got.astype(np.float64)
+                assert np.all(np.abs(g - w) <= np.maximum(1.0, np.abs(w)) * len(x) * 2.0 ** -50), op
+            else:
+                assert gu.same_bits(got, want), (op, x.dtype)
+
+
+def test_q1_q4_shapes_three_and_five_shards(oracle):
+    rng = np.random.default_rng(1)
+    n = 400_003
+    id1 = rng.integers(1, 101, n).astype(np.int32)
+    v1, v2 = rng.integers(1, 6, n).astype(np.int32), rng.integers(1, 16, n).astype(np.int32)
+    v3 = np.round(rng.uniform(0, 100, n), 6).astype(np.float32)
+    check(3, [id1], [ck.RED_SUM], [v1], oracle, hint=128, gmax=128)                              # h2o Q1: one collective
+    check(5, [id1], [ck.RED_AVG, ck.RED_AVG, ck.RED_AVG], [v1, v2, v3], oracle, hint=128, gmax=128)   # h2o Q4
+    check(2, [id1], [ck.RED_SUM, ck.RED_COUNT, ck.RED_MIN, ck.RED_MAX, ck.RED_AVG], [v1, v1, v3, v2, v1], oracle, empty_rank=0)
+
+
+def test_multi_key_high_cardinality_variable_payload(oracle):
+    """h2o Q5 / Q10 shapes: the shard tables have different sizes (gmax = 0: the group counts are exchanged first) and nearly
+    disjoint key sets; several key columns of different widths; negative keys and the key equal to the table's empty mark"""
+    rng = np.random.default_rng(2)
+    n = 250_000
+    id6 = rng.integers(1, 40_000, n).astype(np.int32)
+    v1, v2 = rng.integers(-5, 6, n).astype(np.int32), rng.integers(1, 16, n).astype(np.int16)
+    v3 = np.round(rng.uniform(0, 100, n), 6).astype(np.float32)
+    check(4, [id6], [ck.RED_SUM, ck.RED_SUM, ck.RED_SUM], [v1, v2, v3], oracle)                   # Q5
+    ids = [rng.integers(-3, 4, n).astype(np.int32), rng.integers(0, 50, n).astype(np.int16), rng.integers(0, 2, n).astype(np.uint8),
+           rng.integers(-2**40, 2**40, n).astype(np.int64) // 2**38]
+    ids[0][::1000] = -2**31
+    check(3, ids, [ck.RED_SUM, ck.RED_COUNT], [v3, v3], oracle)                                   # Q10 shape: wide tuple
+    d = rng.standard_normal(n)
+    check(2, [id6, ids[1]], [ck.RED_MAX, ck.RED_MIN, ck.RED_AVG, ck.RED_SUM], [d, v1, d, d], oracle)
+
+
+def test_group_order_is_global_first_occurrence(oracle):
+    """keys that first appear late in an early shard and early in a late one: the merged order must follow global row ids"""
+    n = 90_000
+    k = np.zeros(n, np.int32)
+    k[:30_000] = np.arange(30_000) % 7
+    k[29_990:30_000] = 100 + np.arange(10)            # new keys at the very end of where shard 0 may end
+    k[30_000:60_000] = 50 - (np.arange(30_000) % 13)
+    k[60_000:] = (np.arange(30_000) * 7919) % 211
+    v = np.arange(n, dtype=np.int32) % 1000
+    check(3, [k], [ck.RED_SUM], [v], oracle, uneven=False)
+    check(4, [k], [ck.RED_MAX, ck.RED_COUNT], [v, v], oracle)
+
+
+def test_rccl_transport_world_of_one(gpu_dev, oracle):
+    """the RCCL path itself (librccl opened with dlopen, ncclGetUniqueId / ncclCommInitRank / ncclAllGather on the context's stream)
+    with the only world a one-GPU box allows; the sharded call then equals the plain one"""
+    import aquery2_amd
+    rng = np.random.default_rng(3)
+    n = 300_000
+    id1, v1 = rng.integers(1, 101, n).astype(np.int32), rng.integers(1, 6, n).astype(np.int32)
+    comm = aquery2_amd.Comm(gpu_dev, 0, 1, nccl_id=aquery2_amd.Comm.unique_id())
+    gb = comm.groupby_agg_sharded([id1], [ck.RED_SUM, ck.RED_AVG], [v1, v1], row_base=5_000_000_000, hint=128, gmax=128)
+    o = oracle.groupby([id1])
+    assert gb.ngroups == o["ngroups"] == 100
+    assert np.array_equal(gb.keys(0, np.int32), id1[o["first_rows"]])
+    assert np.array_equal(gb.first_rows64(), o["first_rows"].astype(np.int64) + 5_000_000_000)
+    assert gu.same_bits(gb.result(0, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, v1, o))
+    assert gu.same_bits(gb.result(1, ck.RED_AVG, ck.INT32), oracle.grouped_reduce(ck.RED_AVG, v1, o))
+    gb.destroy()
+    comm.destroy()
+
+
+@pytest.fixture(scope="module")
+def gpu_dev():
+    import aquery2_amd
+    d = aquery2_amd.Device(0)
+    yield d
+    d.close()
+
+
+def _bench(args, env_extra, nproc=1):
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    if nproc > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", "29511",
+               os.path.join(root, "bench.py"), "--gpus", str(nproc)] + args
+    else:
+        cmd = [sys.executable, os.path.join(root, "bench.py")] + args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload", ["q1", "join"])
+def test_bench_multi_rank_path_rehearsed_on_one_gpu(workload):
+    """`bench.py --gpus 2` end to end with both ranks on GPU 0 and the all-gather over gloo (AQG_BENCH_REHEARSAL): the same
+    aqg_groupby_agg_sharded / aqg_groupby_exchange calls the RCCL run makes, its own sum check included"""
+    line = _bench(["--rows", "3e6", "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--workload", workload], {"AQG_BENCH_REHEARSAL": "1"}, nproc=2)
+    assert line["n_gpus"] == 2 and line["config"]["groups"] == 100 and line["scaling"] == "weak"
+    assert line["value"] > 0 and line["roofline"]["kernel_ms"] > 0
+
+
+def test_bench_self_merge_world_of_one():
+    line = _bench(["--rows", "3e6", "--steps", "3", "--warmup", "1", "--cpu-sample", "0"], {"AQG_BENCH_SELFMERGE": "1"})
+    assert line["n_gpus"] == 1 and line["config"]["groups"] == 100 and "secondary" not in line
