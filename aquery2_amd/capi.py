@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # dtype tags (reference server/aquery_types.h:1-5)
 INT32, FLOAT, STR, DOUBLE, LDOUBLE, INT64, INT128, INT16, DATE, TIME, INT8 = range(11)
 UINT32, UINT64, UINT128, UINT16, UINT8, BOOL = 11, 12, 13, 14, 15, 16
+TIMESTAMP = 18
 ERROR = 22
 I128 = np.dtype([("lo", "<u8"), ("hi", "<i8")])
 U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])
@@ -73,6 +74,8 @@ class DevBuf:
 
     @property
     def tag(self):
+        if getattr(self, "_tag", None) is not None:
+            return self._tag
         return NP2TAG[self.dtype] if self.dtype in NP2TAG else (INT128 if self.dtype == I128 else UINT128)
 
     @property
@@ -129,6 +132,13 @@ class GroupBy:
     def first_rows64(self):
         """global row id of every group's first row (handles of aqg_groupby_agg_sharded)"""
         return self._view("aqg_groupby_first_rows64", np.int64, self.ngroups)
+
+    def keys_raw(self, k, elem_bytes):
+        """key column k of every group as raw bytes, (ngroups, elem_bytes) uint8 (keys of any element type)"""
+        out = self.dev.empty(max(1, self.ngroups * elem_bytes), np.uint8)
+        self.dev._chk(self.dev.lib.aqg_groupby_keys(self.h, k, C.c_void_p(out.ptr)), "aqg_groupby_keys")
+        self.dev.sync()
+        return out.to_host()[:self.ngroups * elem_bytes].reshape(self.ngroups, elem_bytes)
 
     def keys(self, k, dtype):
         out = self.dev.empty(self.ngroups, dtype)
@@ -314,6 +324,24 @@ class Device:
     def _dev(self, a):
         return a if isinstance(a, DevBuf) else self.to_device(a)
 
+    def key_col(self, tag, data):
+        """a key column of a type that is not a numpy scalar type: DATE / TIME / TIMESTAMP as an (n, bytes) uint8 array, FLOAT /
+        DOUBLE / 128-bit columns as their arrays, STR as a list of bytes objects (encoded to uint32 codes by aqg_str_encode)"""
+        if tag == STR:
+            bufs = [C.create_string_buffer(b) for b in data]
+            arr = (C.c_char_p * max(1, len(bufs)))(*[C.cast(b, C.c_char_p) for b in bufs])
+            out = self.empty(max(1, len(bufs)), np.uint32)
+            nd = C.c_uint32()
+            self._chk(self.lib.aqg_str_encode(self.ctx, arr, C.c_uint32(len(bufs)), C.c_void_p(out.ptr), C.byref(nd)), "aqg_str_encode")
+            out.n = len(bufs)
+            out.ndistinct = nd.value
+            return out
+        a = np.ascontiguousarray(data)
+        raw = self.to_device(a.reshape(-1).view(np.uint8))
+        buf = DevBuf(self, raw.ptr, np.uint8, a.shape[0], owned=False)
+        buf._raw, buf._tag = raw, tag
+        return buf
+
     # -- generators
     def col_pin(self, a):
         """device mirror of a borrowed host column (aqg_col_pin: asynchronous, stream-ordered upload); `a` must stay alive"""
@@ -444,7 +472,9 @@ class Device:
         h = C.c_void_p()
         self._chk(self.lib.aqg_groupby_build(self.ctx, len(kd), dts, ptrs, C.c_uint32(kd[0].n), C.c_uint32(hint), C.byref(h)),
                   "aqg_groupby_build")
-        return GroupBy(self, h)
+        gb = GroupBy(self, h)
+        gb._keep = kd
+        return gb
 
     def groupby_agg(self, keys, ops, vals, hint=0, handle=None):
         kd, dts, ptrs = self._keyargs(keys)
@@ -456,6 +486,7 @@ class Device:
         self._chk(self.lib.aqg_groupby_agg(self.ctx, len(kd), dts, ptrs, len(ops), opa, vdt, vp, C.c_uint32(kd[0].n),
                                            C.c_uint32(hint), C.byref(h)), "aqg_groupby_agg")
         gb = handle if handle is not None else GroupBy(self, h)
+        gb._keep = (kd, vd)            # keys of non-integer columns are fetched from the caller's column: keep the uploads alive
         gb._val_tags = [v.tag if v is not None else INT32 for v in vd]
         gb._ops = list(ops)
         return gb

@@ -321,6 +321,7 @@ const int64_t* aqg_groupby_first_rows64(const aqg_groupby* g) { return g ? g->fi
 int aqg_groupby_exchange(aqg_comm* comm, aqg_groupby* local, int nparts, const int* merge_ops, uint64_t row_base, uint32_t gmax, aqg_groupby** out) {
     if (!comm || !local || !out || nparts < 0 || nparts + 1 > MAXAGG || nparts > local->nagg) return aqg_fail(comm ? comm->ctx : nullptr, AQG_ERR_ARG, "aqg_groupby_exchange: bad argument (at most 7 partial columns)");
     aqg_ctx* ctx = comm->ctx;
+    if (local->nuser) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_exchange: plain integer key columns only");
     int pdt[MAXPART];
     for (int p = 0; p < nparts; ++p) {
         const int rdt = local->res_dt[p], op = merge_ops[p];
@@ -390,7 +391,7 @@ int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, co
     for (int p = 0; p < nparts; ++p) { lops[p] = parts[p].local_op; ldts[p] = parts[p].val_dt; lvals[p] = vals[parts[p].val_index]; }
     AQG_TRY(aqg_groupby_agg(ctx, nkeys, key_dtypes, keys, nparts, lops, ldts, lvals, n, max_groups_hint, &comm->local));
     aqg_groupby* L = comm->local;
-    const uint32_t G = L->ngroups;
+    if (L->nuser) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: plain integer key columns only (dates / times / 128-bit / floating keys: single-GPU calls)");
     int pdt[MAXPART], mop[MAXPART];
     for (int p = 0; p < nparts; ++p) { pdt[p] = parts[p].part_dt; mop[p] = parts[p].merge_op; }
     AQG_TRY(exchange_core(comm, L, nkeys, key_dtypes, nparts, pdt, mop, row_base, max_groups_hint, gmax));

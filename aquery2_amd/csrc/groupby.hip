@@ -929,7 +929,7 @@ int make_keyspec(aqg_ctx* ctx, int nkeys, const int* dts, const void* const* key
     ks->nkeys = nkeys;
     for (int j = 0; j < nkeys; ++j) {
         if (!(dt_is_num(dts[j]) || dts[j] == AQG_BOOL)) return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: key dtype");
-        if (dt_is_fp(dts[j])) return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: floating key columns are not supported (tuple == on NaN / -0.0)");
+        if (dt_is_fp(dts[j])) return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: internal: floating key column reached the packed-key layer");
         if (!keys[j] && n) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: null key column");
         ks->dt[j] = dts[j]; ks->col[j] = keys[j]; ks->shift[j] = bits;
         bits += 8 * (int)aqg_dtype_size(dts[j]);
@@ -1366,6 +1366,128 @@ int run_with_retry(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n
 
 } // namespace
 
+// ---- key columns that are not plain integers ------------------------------------------------------------------------------------
+// The reference groups by tuple `==` (server/hasher.h:66-144 hashes, std::equal_to on the tuple).  Probed against the reference
+// itself (oracle/ref_harness.cpp, tests/golden): dates compare their 4 bytes; times their 7 bytes of fields (the 8th is padding);
+// timestamps date + time; 128-bit integers all 16 bytes; `const char*` keys are POINTERS (8-byte integers); floating keys compare
+// by value -- 0.0 and -0.0 are one group (libstdc++ hashes both to 0, == holds) and every NaN is a group of its own (same hash,
+// == never holds).  Here such columns are grouped through normalised integer columns: masked / split copies, canonical zero, and
+// for NaNs one more hidden key column holding row + 1.
+namespace {
+__global__ void __launch_bounds__(256) norm_time_kernel(const uint64_t* __restrict__ src, uint32_t n, uint64_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = src[i] & 0x00FFFFFFFFFFFFFFull;
+}
+__global__ void __launch_bounds__(256) norm_timestamp_kernel(const uint32_t* __restrict__ src, uint32_t n, uint32_t* __restrict__ date, uint64_t* __restrict__ time) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        date[i] = src[3 * i];
+        time[i] = ((uint64_t)src[3 * i + 1] | ((uint64_t)src[3 * i + 2] << 32)) & 0x00FFFFFFFFFFFFFFull;
+    }
+}
+__global__ void __launch_bounds__(256) norm_i128_kernel(const uint64_t* __restrict__ src, uint32_t n, uint64_t* __restrict__ lo, uint64_t* __restrict__ hi) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { lo[i] = src[2 * i]; hi[i] = src[2 * i + 1]; }
+}
+// flags[0] |= a NaN exists, flags[1] |= a negative zero exists
+template <class B> __global__ void __launch_bounds__(256) fp_scan_kernel(const B* __restrict__ bits, uint32_t n, uint32_t* __restrict__ flags) {
+    constexpr B SIGN = (B)1 << (sizeof(B) * 8 - 1), EXP = sizeof(B) == 4 ? (B)0x7F800000u : (B)0x7FF0000000000000ull;
+    bool nan = false, nz = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const B b = bits[i];
+        nan |= (b & ~SIGN) > EXP;
+        nz |= b == SIGN;
+    }
+    if (__any(nan) && lane_id() == 0) atomicOr(&flags[0], 1u);
+    if (__any(nz) && lane_id() == 0) atomicOr(&flags[1], 1u);
+}
+template <class B> __global__ void __launch_bounds__(256) fp_norm_kernel(const B* __restrict__ bits, uint32_t n, B* __restrict__ out, uint32_t* __restrict__ nanid) {
+    constexpr B SIGN = (B)1 << (sizeof(B) * 8 - 1), EXP = sizeof(B) == 4 ? (B)0x7F800000u : (B)0x7FF0000000000000ull;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const B b = bits[i];
+        out[i] = b == SIGN ? (B)0 : b;
+        if (nanid) nanid[i] = (b & ~SIGN) > EXP ? (uint32_t)i + 1u : 0u;
+    }
+}
+// out[g] = element first_rows[g] of a column of `esz`-byte elements
+__global__ void __launch_bounds__(256) key_fetch_kernel(const unsigned char* __restrict__ col, int esz, const uint32_t* __restrict__ first_rows, uint32_t G, unsigned char* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)G * esz; i += (size_t)gridDim.x * 256) {
+        const uint32_t g = (uint32_t)(i / esz), b = (uint32_t)(i - (size_t)g * esz);
+        out[i] = col[(size_t)first_rows[g] * esz + b];
+    }
+}
+
+size_t key_elem_size(int dt) {
+    switch (dt) {
+    case AQG_DATE: return 4;
+    case AQG_TIME: return 8;
+    case AQG_TIMESTAMP: return 12;
+    case AQG_INT128: case AQG_UINT128: return 16;
+    default: return aqg_dtype_size(dt);
+    }
+}
+bool key_is_plain(int dt) { return (dt_is_num(dt) && !dt_is_fp(dt)) || dt == AQG_BOOL; }
+
+// the integer columns (ndt / ncol, *nn of them) that stand for the caller's key columns; bookkeeping for aqg_groupby_keys in `h`
+int normalize_keys(aqg_ctx* ctx, aqg_groupby* h, int nkeys, const int* dts, const void* const* keys, uint32_t n, int* nn, int* ndt, const void** ncol) {
+    if (nkeys < 1 || nkeys > MAXKEYS) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: 1..8 key columns");
+    bool all_plain = true;
+    for (int k = 0; k < nkeys; ++k) all_plain = all_plain && key_is_plain(dts[k]);
+    if (all_plain) { h->nuser = 0; *nn = nkeys; for (int k = 0; k < nkeys; ++k) { ndt[k] = dts[k]; ncol[k] = keys[k]; } return AQG_OK; }
+    h->nuser = nkeys;
+    int m = 0, nb = 0;
+    auto buf = [&](size_t bytes, void** out) -> int { AQG_TRY(dev_realloc(ctx, &h->norm_buf[nb], &h->cap_norm[nb], bytes ? bytes : 16)); *out = h->norm_buf[nb++]; return AQG_OK; };
+    auto push = [&](int dt, const void* col) -> int { if (m >= MAXKEYS) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: the key columns normalise to more than 8 integer columns"); ndt[m] = dt; ncol[m] = col; ++m; return AQG_OK; };
+    const unsigned grid = aqg_grid(ctx, n, 256, 4, 16);
+    uint32_t* flags = nullptr;
+    for (int k = 0; k < nkeys; ++k) {
+        const int dt = dts[k];
+        h->user_dt[k] = dt; h->user_col[k] = keys[k]; h->user_norm[k] = -1;
+        if (!keys[k] && n) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: null key column");
+        if (key_is_plain(dt)) { h->user_norm[k] = m; AQG_TRY(push(dt, keys[k])); continue; }
+        void *a = nullptr, *b = nullptr;
+        switch (dt) {
+        case AQG_DATE: AQG_TRY(push(AQG_UINT32, keys[k])); break;
+        case AQG_TIME:
+            AQG_TRY(buf((size_t)n * 8, &a));
+            if (n) hipLaunchKernelGGL(norm_time_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(keys[k]), n, static_cast<uint64_t*>(a));
+            AQG_TRY(push(AQG_UINT64, a));
+            break;
+        case AQG_TIMESTAMP:
+            AQG_TRY(buf((size_t)n * 4, &a)); AQG_TRY(buf((size_t)n * 8, &b));
+            if (n) hipLaunchKernelGGL(norm_timestamp_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(keys[k]), n, static_cast<uint32_t*>(a), static_cast<uint64_t*>(b));
+            AQG_TRY(push(AQG_UINT32, a)); AQG_TRY(push(AQG_UINT64, b));
+            break;
+        case AQG_INT128: case AQG_UINT128:
+            AQG_TRY(buf((size_t)n * 8, &a)); AQG_TRY(buf((size_t)n * 8, &b));
+            if (n) hipLaunchKernelGGL(norm_i128_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(keys[k]), n, static_cast<uint64_t*>(a), static_cast<uint64_t*>(b));
+            AQG_TRY(push(AQG_UINT64, a)); AQG_TRY(push(AQG_UINT64, b));
+            break;
+        case AQG_FLOAT: case AQG_DOUBLE: {
+            const bool f32 = dt == AQG_FLOAT;
+            if (!flags) { AQG_TRY(aqg_ws_reset(ctx)); AQG_TRY(aqg_ws_ensure(ctx, 4096)); AQG_TRY(aqg_ws_get(ctx, 16, &flags)); }
+            uint32_t fl[2] = {0, 0};
+            AQG_HIP(ctx, hipMemsetAsync(flags, 0, 8, ctx->stream));
+            if (n) {
+                if (f32) hipLaunchKernelGGL(fp_scan_kernel<uint32_t>, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(keys[k]), n, flags);
+                else hipLaunchKernelGGL(fp_scan_kernel<uint64_t>, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(keys[k]), n, flags);
+            }
+            AQG_HIP(ctx, hipMemcpyAsync(fl, flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+            AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (!fl[0] && !fl[1]) { AQG_TRY(push(f32 ? AQG_UINT32 : AQG_UINT64, keys[k])); break; }      // the bit patterns are the values
+            AQG_TRY(buf((size_t)n * (f32 ? 4 : 8), &a));
+            if (fl[0]) AQG_TRY(buf((size_t)n * 4, &b));
+            if (f32) hipLaunchKernelGGL(fp_norm_kernel<uint32_t>, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(keys[k]), n, static_cast<uint32_t*>(a), static_cast<uint32_t*>(b));
+            else hipLaunchKernelGGL(fp_norm_kernel<uint64_t>, dim3(grid), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(keys[k]), n, static_cast<uint64_t*>(a), static_cast<uint32_t*>(b));
+            AQG_TRY(push(f32 ? AQG_UINT32 : AQG_UINT64, a));
+            if (fl[0]) AQG_TRY(push(AQG_UINT32, b));                         // every NaN row its own group
+        } break;
+        default: return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: key dtype (strings are grouped through aqg_str_encode codes)");
+        }
+    }
+    AQG_TRY(aqg_check_launch(ctx, "key normalisation"));
+    *nn = m;
+    return AQG_OK;
+}
+} // namespace
+
 extern "C" {
 
 void aqg_groupby_destroy(aqg_groupby* g) {
@@ -1378,6 +1500,7 @@ void aqg_groupby_destroy(aqg_groupby* g) {
     if (g->reversemap) hipFree(g->reversemap);
     if (g->scratch) aqg_groupby_destroy(g->scratch);
     if (g->first_rows64) hipFree(g->first_rows64);
+    for (int i = 0; i < 2 * MAXKEYS; ++i) if (g->norm_buf[i]) hipFree(g->norm_buf[i]);
     if (g->xkeys) hipFree(g->xkeys);
     if (g->xvals) hipFree(g->xvals);
     delete g;
@@ -1390,10 +1513,17 @@ const uint32_t* aqg_groupby_first_rows(const aqg_groupby* g) { return g && !g->s
 const void* aqg_groupby_agg_result(const aqg_groupby* g, int j) { return g && j >= 0 && j < g->nagg ? g->results[j] : nullptr; }
 
 int aqg_groupby_keys(aqg_groupby* g, int k, void* out_dev) {
-    if (!g || k < 0 || k >= g->nkeys || !out_dev) return AQG_ERR_ARG;
+    if (!g || k < 0 || k >= (g->nuser ? g->nuser : g->nkeys) || !out_dev) return AQG_ERR_ARG;
     aqg_ctx* ctx = g->ctx;
     if (!g->ngroups) return AQG_OK;
-    AQG_HIP(ctx, hipMemcpyAsync(out_dev, g->keys_out[k], (size_t)g->ngroups * aqg_dtype_size(g->key_dt[k]), hipMemcpyDeviceToDevice, ctx->stream));
+    if (g->nuser && g->user_norm[k] < 0) {        // not a plain integer column: the key of a group is the caller's element at its first row
+        const int esz = (int)key_elem_size(g->user_dt[k]);
+        hipLaunchKernelGGL(key_fetch_kernel, dim3(aqg_grid(ctx, (uint64_t)g->ngroups * esz, 256, 4, 8)), dim3(256), 0, ctx->stream,
+                           static_cast<const unsigned char*>(g->user_col[k]), esz, (const uint32_t*)g->first_rows, g->ngroups, static_cast<unsigned char*>(out_dev));
+        return aqg_check_launch(ctx, "key_fetch_kernel");
+    }
+    const int kk = g->nuser ? g->user_norm[k] : k;
+    AQG_HIP(ctx, hipMemcpyAsync(out_dev, g->keys_out[kk], (size_t)g->ngroups * aqg_dtype_size(g->key_dt[kk]), hipMemcpyDeviceToDevice, ctx->stream));
     return AQG_OK;
 }
 
@@ -1401,14 +1531,17 @@ int aqg_groupby_agg(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* 
                     const int* val_dtypes, const void* const* vals, uint32_t n, uint32_t max_groups_hint, aqg_groupby** out) {
     if (!ctx || !out || !key_dtypes || !keys) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_agg: bad argument");
     AQG_CHECK_ROWS(ctx, n, "aqg_groupby_agg");
-    KeySpec ks;
-    AQG_TRY(make_keyspec(ctx, nkeys, key_dtypes, keys, n, &ks));
     Plan plan;
     AQG_TRY(make_plan(ctx, naggs, ops, val_dtypes, vals, n, &plan));
     aqg_groupby* h = *out ? *out : new aqg_groupby();
-    h->ctx = ctx; h->n = n; h->has_reversemap = false;
+    h->ctx = ctx; h->n = n; h->has_reversemap = false; h->sharded = false;
     ctx->tail_in_flight = false;
-    int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, false, h, nullptr, nullptr);
+    KeySpec ks;
+    int nn = 0, ndt[MAXKEYS];
+    const void* ncol[MAXKEYS];
+    int rc = normalize_keys(ctx, h, nkeys, key_dtypes, keys, n, &nn, ndt, ncol);
+    if (rc == AQG_OK) rc = make_keyspec(ctx, nn, ndt, ncol, n, &ks);
+    if (rc == AQG_OK) rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, false, h, nullptr, nullptr);
     if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
     if (!ctx->tail_in_flight) AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (small tables: the group count is known, the tail is stream-ordered)
     *out = h;
@@ -1529,16 +1662,19 @@ int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void
                       uint32_t max_groups_hint, aqg_groupby** out) {
     if (!ctx || !out || !key_dtypes || !keys) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_build: bad argument");
     AQG_CHECK_ROWS(ctx, n, "aqg_groupby_build");
-    KeySpec ks;
-    AQG_TRY(make_keyspec(ctx, nkeys, key_dtypes, keys, n, &ks));
     Plan plan;
     memset(&plan, 0, sizeof plan);
     aqg_groupby* h = *out ? *out : new aqg_groupby();
-    h->ctx = ctx; h->n = n;
+    h->ctx = ctx; h->n = n; h->sharded = false;
     GTable gt; uint32_t* slot_gid = nullptr; uint32_t* occ_dev = nullptr;
     DenseOut dn;
     dn.used = false;
-    int rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, true, h, &gt, &slot_gid, &occ_dev, &dn);
+    KeySpec ks;
+    int nn = 0, ndt[MAXKEYS];
+    const void* ncol[MAXKEYS];
+    int rc = normalize_keys(ctx, h, nkeys, key_dtypes, keys, n, &nn, ndt, ncol);
+    if (rc == AQG_OK) rc = make_keyspec(ctx, nn, ndt, ncol, n, &ks);
+    if (rc == AQG_OK) rc = run_with_retry(ctx, ks, plan, n, max_groups_hint, true, h, &gt, &slot_gid, &occ_dev, &dn);
     if (rc == AQG_OK) {
         size_t c = h->reversemap ? h->cap_rows * 4 : 0;
         rc = dev_realloc(ctx, (void**)&h->reversemap, &c, ((size_t)n + 4) * 4);

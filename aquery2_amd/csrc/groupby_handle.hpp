@@ -28,6 +28,14 @@ struct aqg_groupby {
     int64_t* first_rows64 = nullptr;
     size_t cap_first64 = 0;
     bool sharded = false;
+    // key columns that are not plain integers (dates, times, 128-bit integers, floating columns): grouped through NORMALISED integer
+    // columns held here; their key values are fetched from the caller's column through the first rows (aqg_groupby_keys)
+    int nuser = 0;                              // 0: every key column is a plain integer column (keys_out[k] is key k)
+    int user_dt[MAXKEYS] = {0};
+    const void* user_col[MAXKEYS] = {nullptr};
+    int user_norm[MAXKEYS] = {0};               // index of the plain column among the normalised ones, or -1: fetch through first rows
+    void* norm_buf[2 * MAXKEYS] = {nullptr};
+    size_t cap_norm[2 * MAXKEYS] = {0};
     bool dense_exact = false;         // a sampled key range missed values once: take exact ranges from now on
     aqg_groupby* scratch = nullptr;   // reusable handle for aqg_grouped_reduce
     // aqg_groupby_merge_packed: the concatenated shard tables (keys / values), owned by the merged handle

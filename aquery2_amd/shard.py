@@ -1,6 +1,6 @@
-"""Row-range sharding of a table over the GPUs of one node, and the ONE exchange step that merges
-per-shard group tables.  torch.distributed is plumbing here: RCCL ("nccl") on GPUs,
-gloo in the CPU tests.  No data-path collective besides this merge: every shard scans its own rows.
+"""Row-range sharding of a table over the GPUs of one node: shard arithmetic, the halo / carry exchanges of scans and windows
+ and a torch-level form of the group-table merge for the CPU (gloo) tests.  The merge the product runs is in the
+library itself (aqg_groupby_agg_sharded: RCCL inside the C-ABI).  torch.distributed is plumbing here.
 
 Shards are contiguous row ranges in rank order, so concatenating the shards' group tables in rank
 order (each already in local first-occurrence order) and grouping the concatenation again yields the
@@ -42,38 +42,8 @@ def gather_group_tables(dist, cols, ngroups, gmax=None):
     return [rows[:, j].contiguous() for j in range(len(cols))]
 
 
-class GroupTableExchange:
-    """The lean form of the merge used by bench.py: the shard's table is packed by one kernel (aqg_groupby_pack), ONE
-    all_gather moves (gmax + 1) int64 pairs per rank, and aqg_groupby_merge_packed re-aggregates the concatenation --
-    three library / collective calls per step, buffers allocated once.  `xdev` = "cuda" (RCCL) or "cpu" (gloo rehearsal)."""
-
-    def __init__(self, dev, dist, gmax, key_tag, op, xdev="cuda"):
-        self.dev, self.dist, self.gmax, self.key_tag, self.op, self.xdev = dev, dist, gmax, key_tag, op, xdev
-        self.world = dist.get_world_size()
-        self.pack = torch.zeros((gmax + 1) * 2, dtype=torch.int64, device="cuda")
-        self.all = torch.zeros(self.world * (gmax + 1) * 2, dtype=torch.int64, device="cuda")
-        if xdev != "cuda":
-            self.all_x = torch.zeros_like(self.all, device=xdev)
-        self.merged = None
-
-    def __call__(self, gb, agg_index=0):
-        self.dev.groupby_pack(gb, agg_index, self.gmax, self.pack.data_ptr())
-        if self.xdev == "cuda":
-            # the collective orders itself with torch's current stream: free when the library runs on that stream,
-            # otherwise the two streams are joined on the host
-            shared = self.dev.stream and self.dev.stream == torch.cuda.current_stream().cuda_stream
-            if not shared:
-                self.dev.sync()
-            self.dist.all_gather_into_tensor(self.all, self.pack)
-            if not shared:
-                torch.cuda.current_stream().synchronize()
-        else:
-            self.dev.sync()
-            self.dist.all_gather_into_tensor(self.all_x, self.pack.to(self.xdev))
-            self.all.copy_(self.all_x)
-            torch.cuda.synchronize()
-        self.merged = self.dev.groupby_merge_packed(self.all.data_ptr(), self.world, self.gmax, self.key_tag, self.op, self.merged)
-        return self.merged
+# (The group-table merge of bench.py lives in the library since round 2: aqg_comm_* / aqg_groupby_agg_sharded, include/aqg.h.
+#  gather_group_tables above remains the torch-level form the gloo tests drive with the oracle's kernels.)
 
 
 # ---- scans and windows over row-range shards (SURVEY 8e: "windows need a fixed halo") ---------------------------------------

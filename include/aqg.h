@@ -176,7 +176,7 @@ int aqg_mask_to_index(aqg_ctx* ctx, const uint8_t* mask, uint32_t n, uint32_t* i
  * Contract (the only executable one in the reference):
  *   group ids are dense, numbered by FIRST OCCURRENCE of the key tuple;
  *   ht_postproc row-id lists are DESCENDING row id within each group.
- * Key tuples of up to 8 bytes in total (e.g. two int32 columns) are supported.   */
+ * Up to 8 key columns; tuples of up to 8 bytes are packed into one word, wider ones compare through a representative row.       */
 typedef struct aqg_groupby aqg_groupby;
 int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void* const* keys,
                       uint32_t n, uint32_t max_groups_hint, aqg_groupby** out);
@@ -192,6 +192,15 @@ int aqg_groupby_keys(aqg_groupby* g, int k, void* out_dev);
 /* ht_postproc (hasher.h:181-198): offsets[G+1] (exclusive scan of counts; the
  * reference's ht_base after postproc is offsets[0..G)), row_ids[n] descending   */
 int aqg_groupby_postproc(aqg_groupby* g, uint32_t* offsets_dev, uint32_t* row_ids_dev);
+
+/* Key columns need not be plain integers (the reference hashes astring_view, date_t, time_t, timestamp_t and 128-bit integers too,
+ * server/hasher.h:97-144, and groups by tuple ==): AQG_DATE (4-byte elements), AQG_TIME (8-byte elements, the 8th byte is padding
+ * and ignored), AQG_TIMESTAMP (12-byte elements), AQG_INT128 / AQG_UINT128, and AQG_FLOAT / AQG_DOUBLE -- by value like the
+ * reference's ==: 0.0 and -0.0 are one group, every NaN is a group of its own (probed against the reference headers,
+ * tests/golden).  aqg_groupby_keys returns, for such a column, the caller's element at every group's first row (the column
+ * must still be alive).  `const char*` keys are pointers in the reference (8-byte integers: pass AQG_UINT64); astring_view keys
+ * compare string contents: aqg_str_encode turns the host strings into a uint32 code column (dense ids in first-occurrence order).  */
+int aqg_str_encode(aqg_ctx* ctx, const char* const* strs_host, uint32_t n, uint32_t* codes_dev, uint32_t* ndistinct_host);
 
 /* one aggregate over all groups in ONE pass over the value column: the device
  * form of the generated per-group loop `out[g] = op(col[vecs[g]])`

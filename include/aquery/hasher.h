@@ -33,6 +33,41 @@ namespace aq {
 
 using GroupTable = dev::GroupCtx;   // host-side view of one device group-by (offsets/counts host valid, row_ids filled lazily)
 
+// dtype tag of a KEY column's element type (the reference hashes these, server/hasher.h:66-144): plain integers and bools,
+// floating columns (grouped by value), raw `const char*` (a POINTER in the reference's tuple ==: an 8-byte integer),
+// astring_view (string contents: dictionary codes made on the host, aqg_str_encode), dates / times / timestamps, 128-bit integers
+template <class T> struct key_tag { static constexpr int value = dev::tag_of<std::remove_cv_t<T>>::value; };
+template <class T> struct key_tag<T*> { static constexpr int value = AQG_UINT64; };
+template <> struct key_tag<astring_view> { static constexpr int value = AQG_STR; };
+template <> struct key_tag<types::date_t> { static constexpr int value = AQG_DATE; };
+template <> struct key_tag<types::time_t> { static constexpr int value = AQG_TIME; };
+template <> struct key_tag<types::timestamp_t> { static constexpr int value = AQG_TIMESTAMP; };
+
+// device view of one key column for the duration of a build: uploads (or finds the mirror of) the host column; string views are
+// encoded into a temporary code column
+struct KeyIn {
+    int dt = AQG_ERROR;
+    const void* d = nullptr;
+    void* temp = nullptr;       // upload owned by this view
+    void* codes = nullptr;      // astring_view: the code column
+    template <class T> KeyIn(const T* host, uint32_t n, bool borrowed) {
+        auto& rt = dev::Runtime::get();
+        if constexpr (std::is_same_v<std::remove_cv_t<T>, astring_view>) {
+            static_assert(sizeof(astring_view) == sizeof(const char*), "astring_view is one pointer");
+            dev::check(aqg_malloc(rt.ctx(), (size_t)(n ? n : 1) * 4, &codes), "aqg_malloc");
+            dev::check(aqg_str_encode(rt.ctx(), reinterpret_cast<const char* const*>(host), n, static_cast<uint32_t*>(codes), nullptr), "aqg_str_encode");
+            dt = AQG_UINT32; d = codes;
+        } else {
+            static_assert(key_tag<T>::value != AQG_ERROR, "element type cannot be a group-by key");
+            dt = key_tag<T>::value;
+            d = rt.input(host, (size_t)n * sizeof(T), borrowed, &temp);
+        }
+    }
+    ~KeyIn() { auto& rt = dev::Runtime::get(); rt.release(temp); if (codes) aqg_free(rt.ctx(), codes); }
+    KeyIn(const KeyIn&) = delete;
+    KeyIn& operator=(const KeyIn&) = delete;
+};
+
 inline GroupTable& build_groups(int nkeys, const int* dts, const void* const* dev_cols, uint32_t n, bool want_reversemap, uint32_t* reversemap_host,
                                 uint32_t max_groups_hint = 0) {
     auto& rt = dev::Runtime::get();
@@ -55,10 +90,16 @@ inline GroupTable& build_groups(int nkeys, const int* dts, const void* const* de
     return t;
 }
 
-template <class T> inline void fetch_key_column(const GroupTable& t, int k, std::vector<T>& out) {
+template <class T> inline void fetch_key_column(const GroupTable& t, int k, std::vector<T>& out, const T* host_col = nullptr) {
     auto& rt = dev::Runtime::get();
     out.resize(t.G);
     if (!t.G) return;
+    if constexpr (std::is_same_v<T, astring_view>) {       // the key of a group is the string view of its first row (the first one pushed)
+        std::vector<uint32_t> first(t.G);
+        dev::check(aqg_d2h(rt.ctx(), first.data(), aqg_groupby_first_rows(t.handle), (size_t)t.G * 4), "aqg_d2h");
+        for (uint32_t g = 0; g < t.G; ++g) out[g] = host_col[first[g]];
+        return;
+    }
     void* d = nullptr;
     dev::check(aqg_malloc(rt.ctx(), (size_t)t.G * sizeof(T), &d), "aqg_malloc");
     dev::check(aqg_groupby_keys(t.handle, k, d), "aqg_groupby_keys");
@@ -66,9 +107,9 @@ template <class T> inline void fetch_key_column(const GroupTable& t, int k, std:
     aqg_free(rt.ctx(), d);
 }
 
-template <class Tuple, size_t... Is> inline void fetch_keys(const GroupTable& t, std::vector<Tuple>& keys, std::index_sequence<Is...>) {
+template <class Tuple, size_t... Is> inline void fetch_keys(const GroupTable& t, std::vector<Tuple>& keys, std::index_sequence<Is...>, const void* const* host_cols = nullptr) {
     std::tuple<std::vector<std::tuple_element_t<Is, Tuple>>...> cols;
-    (fetch_key_column(t, (int)Is, std::get<Is>(cols)), ...);
+    (fetch_key_column(t, (int)Is, std::get<Is>(cols), host_cols ? static_cast<const std::tuple_element_t<Is, Tuple>*>(host_cols[Is]) : nullptr), ...);
     keys.resize(t.G);
     for (uint32_t g = 0; g < t.G; ++g) keys[g] = Tuple(std::get<Is>(cols)[g]...);
 }
@@ -130,22 +171,24 @@ private:
         std::tuple<std::vector<std::tuple_element_t<Is, Key>>...> cols;
         ((std::get<Is>(cols).resize(n)), ...);
         for (uint32_t i = 0; i < n; ++i) ((std::get<Is>(cols)[i] = std::get<Is>(staged_[i])), ...);
-        const int dts[] = {aq::dev::tag_of<std::tuple_element_t<Is, Key>>::value...};
-        aq::dev::In ins[] = {aq::dev::In(std::get<Is>(cols).data(), (size_t)n * sizeof(std::tuple_element_t<Is, Key>), false)...};
+        aq::KeyIn ins[] = {aq::KeyIn(std::get<Is>(cols).data(), n, false)...};
+        int dts[sizeof...(Is)];
         const void* ptrs[sizeof...(Is)];
-        for (size_t k = 0; k < sizeof...(Is); ++k) ptrs[k] = ins[k].d;
+        const void* hosts[] = {static_cast<const void*>(std::get<Is>(cols).data())...};
+        for (size_t k = 0; k < sizeof...(Is); ++k) { dts[k] = ins[k].dt; ptrs[k] = ins[k].d; }
         drop_table();
         tp_ = &aq::build_groups((int)sizeof...(Is), dts, ptrs, n, true, reversemap);
-        aq::fetch_keys(*tp_, keys_, std::index_sequence<Is...>{});
+        aq::fetch_keys(*tp_, keys_, std::index_sequence<Is...>{}, hosts);
     }
     template <class... Cols> void build_from_columns(uint32_t n, Cols&... cols) {
-        const int dts[] = {aq::dev::tag_of<std::remove_cv_t<std::remove_pointer_t<decltype(cols.container)>>>::value...};
-        aq::dev::In ins[] = {aq::dev::In(cols.container, (size_t)n * sizeof(*cols.container), cols.capacity == 0)...};
+        aq::KeyIn ins[] = {aq::KeyIn(cols.container, n, cols.capacity == 0)...};
+        int dts[sizeof...(Cols)];
         const void* ptrs[sizeof...(Cols)];
-        for (size_t k = 0; k < sizeof...(Cols); ++k) ptrs[k] = ins[k].d;
+        const void* hosts[] = {static_cast<const void*>(cols.container)...};
+        for (size_t k = 0; k < sizeof...(Cols); ++k) { dts[k] = ins[k].dt; ptrs[k] = ins[k].d; }
         drop_table();
         tp_ = &aq::build_groups((int)sizeof...(Cols), dts, ptrs, n, true, reversemap);
-        aq::fetch_keys(*tp_, keys_, std::make_index_sequence<std::tuple_size_v<Key>>{});
+        aq::fetch_keys(*tp_, keys_, std::make_index_sequence<std::tuple_size_v<Key>>{}, hosts);
         for (uint32_t g = 0; g < tp_->G; ++g) ht_base[g] = tp_->counts[g];
         done_ = true;
     }
@@ -181,10 +224,11 @@ public:
         using Tuple = std::tuple<value_type_r<std::decay_t<Cols>>...>;
         uint32_t n = 0;
         ((n = cols.size), ...);
-        const int dts[] = {aq::dev::tag_of<value_type_r<std::decay_t<Cols>>>::value...};
-        aq::dev::In ins[] = {aq::dev::In(cols.container, (size_t)n * sizeof(value_type_r<std::decay_t<Cols>>), cols.capacity == 0)...};
+        aq::KeyIn ins[] = {aq::KeyIn(cols.container, n, cols.capacity == 0)...};
+        int dts[sizeof...(Cols)];
         const void* ptrs[sizeof...(Cols)];
-        for (size_t k = 0; k < sizeof...(Cols); ++k) ptrs[k] = ins[k].d;
+        const void* hosts[] = {static_cast<const void*>(cols.container)...};
+        for (size_t k = 0; k < sizeof...(Cols); ++k) { dts[k] = ins[k].dt; ptrs[k] = ins[k].d; }
         // The reference's perfect-hash decision (hasher.h:334-343): integral keys whose TableStats widths add up to at most
         // PerfectHashingThreshold bits span a domain of 2^bits tuples.  Here that bound sizes the device plan (the direct-indexed
         // table of dense.hip is the device form of PerfectHashTable) instead of being discovered from a sample; group order stays
@@ -197,7 +241,7 @@ public:
         }
         aq::GroupTable& t = aq::build_groups((int)sizeof...(Cols), dts, ptrs, n, false, nullptr, hint);
         auto* keys = new std::vector<Tuple>();
-        aq::fetch_keys(t, *keys, std::index_sequence_for<Cols...>{});
+        aq::fetch_keys(t, *keys, std::index_sequence_for<Cols...>{}, hosts);
         auto* vecs = aq::make_vecs(t);
         HashTableComponents<value_type_r<std::decay_t<Cols>>...> c{t.G, keys, vecs, t.offsets};
         // the grouping (device handle, row ids, offsets, counts), `keys` and `vecs` live until the module's session ends

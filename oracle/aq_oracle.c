@@ -712,6 +712,85 @@ int AQCHK(groupby)(int nkeys, const int* key_dts, const void* const* keys, uint3
     return AQG_OK;
 }
 
+/* ------------------------------------------------------------------------- */
+/* Group-by over key columns that are not plain integers: dense ids in first-occurrence order under the reference's tuple ==
+ * (std::equal_to on std::tuple; element == as defined in server/types.h and server/libaquery.cpp), hashed by
+ * server/hasher.h:97-144.  Only EQUALITY decides the ids (the table mechanics do not), so this restates equality per type:
+ *   AQG_DATE      {uchar day, month; short year}: all 4 bytes (types.h:82-104, operator== compares the three fields)
+ *   AQG_TIME      {uint ms; uchar seconds, minutes, hours}: the 7 field bytes of the 8-byte struct (types.h:106-128)
+ *   AQG_TIMESTAMP {date_t; time_t}: 12-byte struct, date bytes 0-3, time fields at bytes 4-10 (types.h:129-146)
+ *   AQG_INT128 / AQG_UINT128: all 16 bytes (hash: int128_struct low ^ high, hasher.h:135-141)
+ *   AQG_FLOAT / AQG_DOUBLE: by value -- 0.0 == -0.0 (and libstdc++'s std::hash maps both to 0, so they meet in the table);
+ *                 NaN != NaN although the hashes agree, so every NaN row becomes a group of its own
+ *   AQG_STR       astring_view: the NUL-terminated contents (types.h:299-309; hash of the string view, hasher.h:99-106);
+ *                 the column holds `const char*` pointers
+ *   raw `const char*` keys are POINTERS under tuple == : pass them as AQG_UINT64
+ * Pinned against the reference itself: tests/golden/ref_golden_keys.json (oracle/gen_golden.py, ref_harness.cpp).             */
+static size_t typed_key_size(int t) {
+    switch (t) {
+    case AQG_DATE: return 4;
+    case AQG_TIME: return 8;
+    case AQG_TIMESTAMP: return 12;
+    case AQG_INT128: case AQG_UINT128: return 16;
+    case AQG_STR: return sizeof(char*);
+    default: return dt_size(t);
+    }
+}
+/* 1 if element i of column a equals element j (same column) */
+static int typed_equal(int t, const void* col, size_t i, size_t j) {
+    const unsigned char* b = (const unsigned char*)col;
+    switch (t) {
+    case AQG_DATE: return memcmp(b + 4 * i, b + 4 * j, 4) == 0;
+    case AQG_TIME: return memcmp(b + 8 * i, b + 8 * j, 7) == 0;
+    case AQG_TIMESTAMP: return memcmp(b + 12 * i, b + 12 * j, 11) == 0;
+    case AQG_INT128: case AQG_UINT128: return memcmp(b + 16 * i, b + 16 * j, 16) == 0;
+    case AQG_FLOAT: return ((const float*)col)[i] == ((const float*)col)[j];
+    case AQG_DOUBLE: return ((const double*)col)[i] == ((const double*)col)[j];
+    case AQG_STR: return strcmp(((const char* const*)col)[i], ((const char* const*)col)[j]) == 0;
+    default: { size_t z = dt_size(t); return z && memcmp(b + z * i, b + z * j, z) == 0; }
+    }
+}
+/* a bucket hash that is equal for equal elements (any such function yields the same ids) */
+static uint64_t typed_bucket(int t, const void* col, size_t i) {
+    const unsigned char* b = (const unsigned char*)col;
+    uint64_t h = UINT64_C(1469598103934665603);
+    size_t len = typed_key_size(t);
+    const unsigned char* p = b + len * i;
+    if (t == AQG_TIME) len = 7;
+    if (t == AQG_TIMESTAMP) len = 11;
+    if (t == AQG_FLOAT) { float f = ((const float*)col)[i]; if (f == 0.0f) return 7; }
+    if (t == AQG_DOUBLE) { double d = ((const double*)col)[i]; if (d == 0.0) return 7; }
+    if (t == AQG_STR) { p = (const unsigned char*)((const char* const*)col)[i]; len = strlen((const char*)p); }
+    for (size_t k = 0; k < len; ++k) h = (h ^ p[k]) * UINT64_C(1099511628211);
+    return h;
+}
+int AQCHK(groupby_typed)(int nkeys, const int* key_dts, const void* const* keys, uint32_t n,
+                         uint32_t* reversemap, uint32_t* ngroups, uint32_t* first_rows) {
+    if (nkeys < 1 || nkeys > 8) return AQG_ERR_ARG;
+    for (int k = 0; k < nkeys; ++k) if (!typed_key_size(key_dts[k])) return AQG_ERR_DTYPE;
+    uint64_t nb = 16; while (nb < (uint64_t)n * 2) nb <<= 1;
+    uint32_t* head = (uint32_t*)malloc(sizeof(uint32_t) * nb);      /* chained: bucket -> first group, groups chained by next */
+    uint32_t* next = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+    memset(head, 0xFF, sizeof(uint32_t) * nb);
+    uint32_t G = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t h = UINT64_C(534235245539);
+        for (int k = 0; k < nkeys; ++k) h = (h ^ typed_bucket(key_dts[k], keys[k], i)) * UINT64_C(0x9E3779B97F4A7C15);
+        uint64_t bk = (h ^ (h >> 29)) & (nb - 1);
+        uint32_t g = head[bk];
+        for (; g != 0xFFFFFFFFu; g = next[g]) {
+            int eq = 1;
+            for (int k = 0; k < nkeys && eq; ++k) eq = typed_equal(key_dts[k], keys[k], first_rows[g], i);
+            if (eq) break;
+        }
+        if (g == 0xFFFFFFFFu) { g = G++; first_rows[g] = i; next[g] = head[bk]; head[bk] = g; }
+        reversemap[i] = g;
+    }
+    *ngroups = G;
+    free(head); free(next);
+    return AQG_OK;
+}
+
 /* generated per-group loop: out[g] = op(col[vecs[g]]) (engine/ast.py:722-789) */
 int AQCHK(grouped_reduce)(int op, int t, const void* x, uint32_t G, const uint32_t* offsets,
                           const uint32_t* counts, const uint32_t* row_ids, void* out) {

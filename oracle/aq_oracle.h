@@ -74,6 +74,10 @@ int AQCHK(groupby)(int nkeys, const int* key_dts, const void* const* keys, uint3
 /* the generated per-group loop (engine/ast.py:722-789): out[g] = op(col[vecs[g]]),
  * i.e. gather (table.h:184-189) in row-id-descending order, then the reduction.
  * out has G elements of reduce_out_dtype(op, t).                                 */
+/* key columns of any type the reference hashes (dates, times, timestamps, 128-bit integers, floating columns, astring_view):
+ * dense first-occurrence ids under the reference's tuple ==; first_rows[g] = the row that introduced group g */
+int AQCHK(groupby_typed)(int nkeys, const int* key_dts, const void* const* keys, uint32_t n,
+                         uint32_t* reversemap, uint32_t* ngroups, uint32_t* first_rows);
 int AQCHK(grouped_reduce)(int op, int t, const void* x, uint32_t G, const uint32_t* offsets,
                           const uint32_t* counts, const uint32_t* row_ids, void* out);
 

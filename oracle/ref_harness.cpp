@@ -506,3 +506,51 @@ double aqr_time_groupby_sum(int nkeys, const int* key_dts, const void* const* ke
 }
 
 } // extern "C"
+
+/* key columns that are not plain integers, through the reference's own AQHashTable / hasher (server/hasher.h:66-199): the menu of
+ * tuple shapes the golden vectors cover (one column of each type; some paired with an int column: the multi-column hasher) */
+namespace {
+template <class Rec, class Push> int run_typed(uint32_t n, Push&& push, uint32_t* reversemap, uint32_t* ngroups, uint32_t* first_rows) {
+    AQHashTable<Rec, transTypes<Rec, hasher>> g{n ? n : 1u};
+    for (uint32_t i = 0; i < n; ++i) push(g, i);
+    const uint32_t G = (uint32_t)g.size();
+    *ngroups = G;
+    std::memcpy(reversemap, g.reversemap, sizeof(uint32_t) * (size_t)n);
+    std::vector<char> seen(G, 0);
+    for (uint32_t i = 0; i < n; ++i) if (!seen[reversemap[i]]) { seen[reversemap[i]] = 1; first_rows[reversemap[i]] = i; }
+    free(g.reversemap); free(g.ht_base);
+    return AQG_OK;
+}
+template <class T> int typed1(const void* col, uint32_t n, uint32_t* rm, uint32_t* ng, uint32_t* fr) {
+    auto k = static_cast<const T*>(col);
+    return run_typed<record<T>>(n, [&](auto& g, uint32_t i) { g.hashtable_push(std::forward_as_tuple(k[i]), i); }, rm, ng, fr);
+}
+template <class T> int typed2(const void* col, const void* icol, uint32_t n, uint32_t* rm, uint32_t* ng, uint32_t* fr) {
+    auto k = static_cast<const T*>(col);
+    auto j = static_cast<const int*>(icol);
+    return run_typed<record<T, int>>(n, [&](auto& g, uint32_t i) { g.hashtable_push(std::forward_as_tuple(k[i], j[i]), i); }, rm, ng, fr);
+}
+} // namespace
+extern "C" int aqr_groupby_typed(int nkeys, const int* dts, const void* const* keys, uint32_t n, uint32_t* rm, uint32_t* ng, uint32_t* fr) {
+    if (nkeys == 1) {
+        switch (dts[0]) {
+        case AQG_FLOAT: return typed1<float>(keys[0], n, rm, ng, fr);
+        case AQG_DOUBLE: return typed1<double>(keys[0], n, rm, ng, fr);
+        case AQG_DATE: return typed1<types::date_t>(keys[0], n, rm, ng, fr);
+        case AQG_TIME: return typed1<types::time_t>(keys[0], n, rm, ng, fr);
+        case AQG_TIMESTAMP: return typed1<types::timestamp_t>(keys[0], n, rm, ng, fr);
+        case AQG_STR: return typed1<astring_view>(keys[0], n, rm, ng, fr);
+        case AQG_UINT64: return typed1<const char*>(keys[0], n, rm, ng, fr);      /* raw string pointers: pointer equality */
+        }
+    } else if (nkeys == 2 && dts[1] == AQG_INT32) {
+        switch (dts[0]) {
+        case AQG_DOUBLE: return typed2<double>(keys[0], keys[1], n, rm, ng, fr);
+        case AQG_FLOAT: return typed2<float>(keys[0], keys[1], n, rm, ng, fr);
+        case AQG_DATE: return typed2<types::date_t>(keys[0], keys[1], n, rm, ng, fr);
+        case AQG_TIMESTAMP: return typed2<types::timestamp_t>(keys[0], keys[1], n, rm, ng, fr);
+        case AQG_INT128: return typed2<__int128>(keys[0], keys[1], n, rm, ng, fr);
+        case AQG_STR: return typed2<astring_view>(keys[0], keys[1], n, rm, ng, fr);
+        }
+    }
+    return AQG_ERR_DTYPE;
+}

@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # dtype tags: include/aqg.h (reference server/aquery_types.h:1-5)
 INT32, FLOAT, STR, DOUBLE, LDOUBLE, INT64, INT128, INT16, DATE, TIME, INT8 = range(11)
 UINT32, UINT64, UINT128, UINT16, UINT8, BOOL = 11, 12, 13, 14, 15, 16
+TIMESTAMP = 18
 ERROR = 22
+KEY_ELEM_BYTES = {DATE: 4, TIME: 8, TIMESTAMP: 12}          # key columns of these tags travel as (n, bytes) uint8 arrays
 
 I128 = np.dtype([("lo", "<u8"), ("hi", "<i8")])
 U128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])
@@ -198,6 +200,29 @@ class Checker:
         if postproc:
             res.update(offsets=offsets[:g].copy(), row_ids=row_ids[:n].copy())
         return res
+
+    def groupby_typed(self, cols):
+        """group ids in first-occurrence order for key columns of any type the reference hashes: cols = [(tag, data)] with
+        data = numpy array (FLOAT / DOUBLE / integers / I128), an (n, bytes) uint8 array (DATE / TIME / TIMESTAMP), or a list of
+        bytes objects (STR: astring_view, compared by content; every row gets its own buffer)"""
+        keep, ptrs, dts, n = [], [], [], None
+        for tag, data in cols:
+            if tag == STR:
+                bufs = [C.create_string_buffer(b) for b in data]
+                arr = (C.c_char_p * len(bufs))(*[C.cast(b, C.c_char_p) for b in bufs])
+                keep += [bufs, arr]
+                ptrs.append(C.cast(arr, C.c_void_p).value); m = len(bufs)
+            else:
+                a = np.ascontiguousarray(data)
+                keep.append(a)
+                ptrs.append(a.ctypes.data); m = a.shape[0]
+            dts.append(tag)
+            assert n is None or n == m
+            n = m
+        rev, first, G = np.empty(max(n, 1), np.uint32), np.zeros(max(n, 1), np.uint32), C.c_uint32()
+        self._chk(self._f("groupby_typed")(len(cols), (C.c_int * len(cols))(*dts), (C.c_void_p * len(cols))(*ptrs), C.c_uint32(n),
+                                           _p(rev), C.byref(G), _p(first)), "groupby_typed")
+        return dict(ngroups=G.value, reversemap=rev[:n].copy(), first_rows=first[:G.value].copy())
 
     def grouped_reduce(self, op, x, gb):
         x = np.ascontiguousarray(x)

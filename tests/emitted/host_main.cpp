@@ -53,17 +53,38 @@ static std::vector<std::vector<int>> dataset(const std::string& name) {
     return {};
 }
 
+// "strings": column 0 holds `const char*` (12 rows over 4 distinct months; equal strings share ONE pointer, as a string heap hands
+// them out), column 1 the same strings behind DISTINCT pointers (content equality only), column 2 sales
+static const char* kMonths[] = {"jan", "feb", "mar", "apr"};
+static const int kMonthOf[] = {2, 0, 2, 1, 3, 0, 0, 1, 2, 3, 3, 1};
+static std::vector<std::string> g_copies;
+
 int main(int argc, char** argv) {
     if (argc < 4) { std::fprintf(stderr, "usage: %s module.so dataset function...\n", argv[0]); return 2; }
     Context* cxt = new Context();
     Config cfg{};
     cfg.backend_type = BACKEND_AQuery;
     cxt->cfg = &cfg;
-    auto cols = dataset(argv[2]);
+    std::vector<std::vector<int>> cols;
+    std::vector<const char*> shared_ptrs, own_ptrs;
+    std::vector<void*> ptrs;
+    if (std::string(argv[2]) == "strings") {
+        const int n = (int)(sizeof kMonthOf / sizeof kMonthOf[0]);
+        g_copies.reserve(n);
+        cols.push_back(std::vector<int>(n));
+        for (int i = 0; i < n; ++i) {
+            shared_ptrs.push_back(kMonths[kMonthOf[i]]);
+            g_copies.emplace_back(kMonths[kMonthOf[i]]);
+            own_ptrs.push_back(g_copies.back().c_str());
+            cols[0][i] = 100 + 7 * i;
+        }
+        ptrs = {shared_ptrs.data(), own_ptrs.data(), cols[0].data()};
+    } else {
+        cols = dataset(argv[2]);
+        for (auto& c : cols) ptrs.push_back(c.data());
+    }
     if (cols.empty()) { std::fprintf(stderr, "unknown dataset %s\n", argv[2]); return 2; }
     ColumnDataSource ds;
-    std::vector<void*> ptrs;
-    for (auto& c : cols) ptrs.push_back(c.data());
     ds.set((long long)cols[0].size(), ptrs);
     ds.connect(cxt);
     cxt->curr_server = &ds;

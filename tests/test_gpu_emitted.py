@@ -25,7 +25,7 @@ def run(module, dataset, *funcs, cwd=None):
 def test_emitted_modules_compile():
     """CPU: the generated-shape translation units compile and link against the new library"""
     build()
-    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "distinct_orderby.so", "funcs_udf.so", "mutate_reuse.so", "stats_factory.so", "host_main"):
+    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "distinct_orderby.so", "funcs_udf.so", "mutate_reuse.so", "stats_factory.so", "string_keys.so", "host_main"):
         assert os.path.exists(os.path.join(EM, "build", m))
 
 
@@ -251,3 +251,26 @@ def test_populate_stats_and_the_perfect_hash_front_door():
             assert out[1] == "stats 1 a 0 10 b 7 0"         # a in 0..999: 10 bits; b constant: 0 bits
             assert out[2] == "groups 1000 1000 1000"
         assert out[3] == "same 1" and out[-1] == "done."
+
+
+@pytest.mark.gpu
+def test_string_keys_in_the_emitted_shape():
+    """mem_opt.cpp:22 shape: group by ColRef<const char*> (pointer keys, as the reference's tuple == has them) and by
+    astring_view (string contents) through HashTableFactory::get"""
+    build()
+    out = run("string_keys.so", "strings", "dll_strkeys").strip().splitlines()
+    months = ["jan", "feb", "mar", "apr"]
+    month_of = [2, 0, 2, 1, 3, 0, 0, 1, 2, 3, 3, 1]
+    sales = [100 + 7 * i for i in range(12)]
+    order = []
+    for m in month_of:
+        if m not in order:
+            order.append(m)
+    want = [f"{months[m]},{sum(s for s, mm in zip(sales, month_of) if mm == m)},{month_of.count(m)}" for m in order]
+    sep = out.index("--")
+    assert out[:sep] == want
+    assert out[sep + 1] == "pointer groups 12, string-view groups 4"
+    # string-view groups: same contents, first-occurrence order, vecs[g] descending (its first element is the group's LAST row)
+    last = {m: max(i for i, mm in enumerate(month_of) if mm == m) for m in order}
+    assert out[sep + 2:sep + 6] == [f"{w},{last[m]}" for w, m in zip(want, order)]
+    assert out[-1] == "done."
