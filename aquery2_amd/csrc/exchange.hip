@@ -100,7 +100,8 @@ __device__ inline uint64_t load_native(int dt, const void* col, size_t i) {
     default: return static_cast<const uint64_t*>(col)[i];
     }
 }
-__device__ inline void store_native(int dt, void* col, size_t i, uint64_t bits) {
+// (not inlined: see store_sized in groupby_dev.hpp and profiles/r2_hipcc_switch_miscompile.md)
+__device__ __noinline__ void store_native(int dt, void* col, size_t i, uint64_t bits) {
     switch (dt) {
     case AQG_INT8: case AQG_UINT8: case AQG_BOOL: static_cast<uint8_t*>(col)[i] = (uint8_t)bits; break;
     case AQG_INT16: case AQG_UINT16: static_cast<uint16_t*>(col)[i] = (uint16_t)bits; break;

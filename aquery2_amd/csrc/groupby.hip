@@ -601,7 +601,9 @@ struct AggOut { int op; int dt; int acc0; int acc1; int acc2; int acc3; void* ou
 struct EmitSpec { int nagg; AggOut agg[MAXAGG]; int nkeys; int key_dt[MAXKEYS]; int key_shift[MAXKEYS]; void* key_out[MAXKEYS]; int wide; const void* key_col[MAXKEYS];
                   uint32_t* first_out; uint32_t* count_out; };
 
-template <class T> __device__ inline void store_minmax(void* out, uint32_t g, uint64_t mapped, bool is_max) {
+// (not inlined: a size / dtype switch whose arms STORE, inlined into a loop with a 64-bit value live across it, is the shape hipcc
+// 7.2 miscompiled in unpack_kernel -- profiles/r2_hipcc_switch_miscompile.md)
+template <class T> __device__ __noinline__ void store_minmax(void* out, uint32_t g, uint64_t mapped, bool is_max) {
     T v;
     if constexpr (std::is_floating_point_v<T>) {
         double d = unmap_f(mapped);
