@@ -231,9 +231,19 @@ namespace aq {
 inline void append_value(std::string& s, const char* v) { s += v ? v : ""; }
 inline void append_value(std::string& s, astring_view v) { s += v.rstr ? v.rstr : ""; }
 inline void append_value(std::string& s, bool v) { s += v ? "true" : "false"; }
-inline void append_value(std::string& s, float v) { char b[64]; std::snprintf(b, sizeof b, "%f", v); s += b; }
-inline void append_value(std::string& s, double v) { char b[64]; std::snprintf(b, sizeof b, "%lf", v); s += b; }
-inline void append_value(std::string& s, long double v) { char b[96]; std::snprintf(b, sizeof b, "%Lf", v); s += b; }
+// %f of a large double runs to 300+ digits (1e300): size the buffer from the first call instead of cutting the text
+template <class V> inline void append_printf(std::string& s, const char* fmt, V v) {
+    char b[64];
+    const int len = std::snprintf(b, sizeof b, fmt, v);
+    if (len < (int)sizeof b) { s += b; return; }
+    std::string big((size_t)len + 1, '\0');
+    std::snprintf(big.data(), big.size(), fmt, v);
+    big.resize((size_t)len);
+    s += big;
+}
+inline void append_value(std::string& s, float v) { append_printf(s, "%f", (double)v); }
+inline void append_value(std::string& s, double v) { append_printf(s, "%lf", v); }
+inline void append_value(std::string& s, long double v) { append_printf(s, "%Lf", v); }
 #ifdef __AQ__HAS__INT128__
 inline void append_value(std::string& s, __int128 v) {
     if (v == 0) { s += '0'; return; }
@@ -335,9 +345,12 @@ struct TableInfo {
         return this;
     }
 
+    // every name followed by sep '|' sep, then strlen(sep) + 1 characters trimmed -- which leaves the LAST separator standing
+    // ("Mont | avgw3ysales " for sep " ", "Mont,|,avgw3ysales," for sep ","): the reference's text, byte for byte (table.h:484-493)
     std::string get_header_string(const char* __restrict sep, const char* __restrict end) const {
         std::string h;
         header_names(h, sep, std::index_sequence_for<Types...>{});
+        if (const size_t l_sep = std::strlen(sep) + 1; h.size() >= l_sep) h.resize(h.size() - l_sep);
         std::string line(h.size(), '=');
         return h + end + line + end;
     }
@@ -378,8 +391,7 @@ private:
     }
     template <size_t... Is> void init_names(const char** names, std::index_sequence<Is...>) { (std::get<Is>(cols).init(names ? names[Is] : ""), ...); }
     template <size_t... Is> void header_names(std::string& h, const char* sep, std::index_sequence<Is...>) const {
-        size_t k = 0;
-        ((h += std::string(std::get<Is>(cols).name) + (++k < sizeof...(Is) ? std::string(sep) + '|' + sep : std::string())), ...);
+        ((h += std::string(std::get<Is>(cols).name) + sep + '|' + sep), ...);
     }
     template <size_t... Is> void csv_names(std::string& h, const char* sep, std::index_sequence<Is...>) const {
         size_t k = 0;

@@ -554,3 +554,10 @@ extern "C" int aqr_groupby_typed(int nkeys, const int* dts, const void* const* k
     }
     return AQG_ERR_DTYPE;
 }
+
+/* result egress: the shapes of tests/emitted/print_shapes.inc printed by the REFERENCE's TableInfo::print / printall.  Built as a
+ * small executable of its own (oracle/Makefile: _ref/print_shapes_ref, -DAQR_PRINT_SHAPES_MAIN); its stdout is the golden text. */
+#ifdef AQR_PRINT_SHAPES_MAIN
+#include "../tests/emitted/print_shapes.inc"
+int main() { aq_print_shapes(); return 0; }
+#endif

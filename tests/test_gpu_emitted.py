@@ -34,7 +34,7 @@ def test_moving_avg(tmp_path):
     build()
     out = run("moving_avg.so", "moving_avg_asc", "dll_2Cxoox", cwd=str(tmp_path))
     lines = out.strip().splitlines()
-    assert lines[0] == "Mont | avgw3ysales"
+    assert lines[0] == "Mont | avgw3ysales "          # the reference leaves the last separator standing (tests/golden/print_shapes.txt)
     rows = [l.split() for l in lines[2:7]]
     assert [int(r[0]) for r in rows] == [1, 2, 3, 4, 5]
     assert [float(r[1]) for r in rows] == pytest.approx([100, 110, 120, 133.333, 136.667], abs=1e-3)
@@ -72,7 +72,7 @@ def test_groupby_q1_sql():
     build()
     out = run("groupby_q1.so", "test_csv", "dll_3kR9pQ")
     lines = out.strip().splitlines()
-    assert lines[0] == "sumc | b | d | cnt | avgc"
+    assert lines[0] == "sumc | b | d | cnt | avgc "
     rows = [l.split() for l in lines[2:-1]]
     assert len(rows) == 16, out
     # reference: 16 groups in first-occurrence order of (a,b,d); sum(c) per group
@@ -274,3 +274,23 @@ def test_string_keys_in_the_emitted_shape():
     last = {m: max(i for i, mm in enumerate(month_of) if mm == m) for m in order}
     assert out[sep + 2:sep + 6] == [f"{w},{last[m]}" for w, m in zip(want, order)]
     assert out[-1] == "done."
+
+
+@pytest.mark.gpu
+def test_config0_end_to_end_through_the_product_host(tmp_path):
+    """BASELINE config 0 (tests/moving_avg.a on data/moving_avg.csv): the product's host shim (aquery2_amd/aquery_host: message loop,
+    dlopen, __AQ_Init_GC__, stand-in SQL source loading the CSV and doing the ORDER BY) runs the recorded message list against the
+    generated-shape module; outputs = the KATs of SURVEY 8c"""
+    build()
+    root = os.path.dirname(HERE)
+    subprocess.check_call(["make", "-C", os.path.join(root, "aquery2_amd", "host")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(root, "aquery2_amd", "aquery_host"), os.path.join(EM, "build", "moving_avg.so"), os.path.join(EM, "moving_avg.msgs"), "--root", root],
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr
+    csv = open(tmp_path / "moving_avg_output.csv").read().strip().splitlines()
+    assert csv == ["Mont;avgw3ysales", "1;100.000000", "2;110.000000", "3;120.000000", "4;133.333333", "5;136.666667"]
+    flat = open(tmp_path / "flatten.csv").read().strip().splitlines()
+    assert flat == ["Mont,minw2ysales", "5,130", "4,140", "3,140", "2,120", "1,100"]
+    # the O message prints the data source's current result set (the DESC select), 4 rows
+    assert out.stdout.strip().splitlines()[-4:] == ["5 130", "4 140", "3 140", "2 120"]
+    assert "post-processing" in out.stderr
