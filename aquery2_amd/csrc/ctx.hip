@@ -313,10 +313,13 @@ int aqg_ws_ensure(aqg_ctx* ctx, size_t bytes) {
     AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     size_t cap = ctx->ws_cap ? ctx->ws_cap : (size_t)1 << 20;
     while (cap < bytes) cap *= 2;
+    // large arenas grow to what is asked for (rounded to 1 GiB), not to the next power of two: a 130 GB need must not take 256 GB
+    if (bytes > ((size_t)4 << 30)) cap = (bytes + (((size_t)1 << 30) - 1)) & ~(((size_t)1 << 30) - 1);
+    // the arena holds nothing across calls: release it first, so that a 100 GB arena can be replaced by a larger one
+    if (ctx->ws) { hipFree(ctx->ws); ctx->ws = nullptr; ctx->ws_cap = 0; }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, cap);
-    if (e != hipSuccess) { ctx->err = std::string("workspace hipMalloc: ") + hipGetErrorString(e); return AQG_ERR_NOMEM; }
-    if (ctx->ws) hipFree(ctx->ws);
+    if (e != hipSuccess) { ctx->err = std::string("workspace hipMalloc: ") + hipGetErrorString(e); (void)hipGetLastError(); return AQG_ERR_NOMEM; }
     ctx->ws = static_cast<char*>(p);
     ctx->ws_cap = cap;
     return AQG_OK;

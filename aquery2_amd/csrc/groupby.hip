@@ -1079,6 +1079,10 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     const uint32_t parts = use_part && !p1_off ? aqg_partition_parts(ks.total_bytes <= 4 ? 4 : 8, as, plan.need_count, hint) : 0;
     const uint32_t p1_bins = parts && parts <= p1_max && parts <= AQG_P1_MAXBINS ? parts : 0;
     const uint32_t p2_parts = parts && !p1_bins && parts <= AQG_P2_MAXPARTS ? parts : 0;
+    // tuples wider than 8 bytes with many groups (h2o Q10): hash-partitioned rows, every partition grouped inside LDS
+    const bool use_wpart = !part_off && !p1_off && !dense && !use_lds && ks.wide && !for_build && !plan.sj && n >= (1u << 20) && hint > (1u << 20) && as.nacc <= 4 &&
+                           !h->no_wide_part && aqg_partitionw_applies(ks, as, n);
+    if (use_wpart) gcap = (uint32_t)((uint64_t)hint + hint / 4 + 4096 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : (uint64_t)hint + hint / 4 + 4096);
 
     // ---- workspace ----------------------------------------------------------------------------
     size_t slots = (size_t)gcap + 1;
@@ -1088,7 +1092,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     if (!small_rank) need += (size_t)nwords * 8 + (size_t)ntiles * 4 + 4096;
     const bool ordered_emit = !small_rank && hint >= (1u << 20);
     if (ordered_emit) need += slots * 4 + 4096;
-    if (p1_bins) need += aqg_partition1_ws_bytes(ctx, ks, n, as, p1_bins) + 65536;
+    if (use_wpart) need += aqg_partitionw_ws_bytes(ctx, ks, n, as) + 65536;
+    else if (p1_bins) need += aqg_partition1_ws_bytes(ctx, ks, n, as, p1_bins) + 65536;
     else if (p2_parts) need += aqg_partition2_ws_bytes(ctx, ks, n, as, p2_parts) + 65536;
     else if (use_part) need += aqg_partition_ws_bytes(n, ks.total_bytes <= 4 ? 4 : 8, as, pbits) + 65536;
     AQG_TRY(aqg_ws_reset(ctx));
@@ -1101,7 +1106,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     {
         unsigned char* base = nullptr;
         AQG_TRY(aqg_ws_get(ctx, slots * stride, &base));
-        const bool records = use_part || hint > (1u << 17);
+        const bool records = use_part || use_wpart || hint > (1u << 17);
         if (records) {
             gt.kb = base; gt.fb = base + 8; gt.cb = base + 12; gt.ab = base + 16;
             gt.kst = gt.fst = gt.cst = gt.ast = stride; gt.astep = 8;
@@ -1119,7 +1124,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(aqg_ws_get(ctx, nwords, &word_prefix));
         AQG_TRY(aqg_ws_get(ctx, ntiles + 1, &tile_total));
     }
-    if (!use_part) hipLaunchKernelGGL(gt_init_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, gt, as);
+    if (!use_part && !use_wpart) hipLaunchKernelGGL(gt_init_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, gt, as);
     else AQG_HIP(ctx, hipMemsetAsync(gt.flags, 0, 64 * 4, ctx->stream));
     if (bitmap) AQG_HIP(ctx, hipMemsetAsync(bitmap, 0, (size_t)nwords * 4, ctx->stream));
 
@@ -1170,6 +1175,9 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(rc);
     } else if (n && dense) {
         AQG_TRY(aqg_dense_aggregate(ctx, ks, dspec, as, n, plan.need_count, gt));
+    } else if (n && use_wpart) {
+        AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap));
+        hipLaunchKernelGGL(occ_iota_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, occ, (uint32_t)slots);
     } else if (n && use_part) {
         if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap));
         else if (p2_parts) AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap));
@@ -1215,11 +1223,12 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     }
     // ---- dense ids ---------------------------------------------------------------------------------
     unsigned cgrid = aqg_grid(ctx, slots, 256, 1, 8);
-    if (!(n && use_part)) hipLaunchKernelGGL(collect_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, gt, occ);
+    if (!(n && (use_part || use_wpart))) hipLaunchKernelGGL(collect_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, gt, occ);
     uint32_t fl[4] = {0, 0, 0, 0};                    // [0] overflow, [1] occupied slots, [3] a row outside the sampled key ranges
     uint32_t G = 0;
     auto judge_flags = [&]() -> int {
         if (dense && fl[3]) { h->dense_exact = true; return AQG_ERR_RANGE_MISS; }
+        if (use_wpart && fl[0]) { h->no_wide_part = true; return AQG_ERR_RANGE_MISS; }        // a partition larger than LDS: the HBM table, same hint
         if (fl[0]) return AQG_ERR_OVERFLOW;
         G = fl[1];
         if (small_rank && G > 4096) return AQG_ERR_OVERFLOW;
@@ -1238,7 +1247,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     // still queued (stream-ordered, like every device result of this library), so the host's way to the next call overlaps them.
     // An overflow is noticed with the tail already queued on it: those kernels are bounded by the table and by `gmax`, their
     // results are discarded and the call re-plans as before.
-    const bool defer = n && (fast || plan.sj) && small_rank && !dense && !use_part;
+    const bool defer = n && (fast || plan.sj) && small_rank && !dense && !use_part && !use_wpart;
     const uint32_t gupper = (uint32_t)(slots + 1 < 4096 ? slots + 1 : 4096);
     uint32_t* pinned_flags = nullptr;
     if (defer) {

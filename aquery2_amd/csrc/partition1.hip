@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
     constexpr int HH = TR < 16 ? TR : 16;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);      // [TPT]
-    __shared__ uint32_t lb[65], gd[64];
+    __shared__ uint32_t lb[129], gd[128], wtot;                // up to 128 bins per level
     uint32_t seg, rb, nrows;
     if constexpr (FULL) {
         const uint32_t t = blockIdx.x;
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
         rb = lv.seg_start[seg + 1] - nrows;
     }
     const uint32_t NB = lv.nbins;
-    if (threadIdx.x <= 64) lb[threadIdx.x] = 0;
+    if (threadIdx.x <= 128) lb[threadIdx.x] = 0;
     __syncthreads();
     uint32_t pos[TR];                                         // (bin << 15) | rank, later the staged position
 #pragma unroll
@@ -546,12 +546,20 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
         }
     }
     __syncthreads();
-    if (threadIdx.x < 64) {   // first wavefront: exclusive scan of the bin counts; reserve this tile's run of every bin
-        const uint32_t c = threadIdx.x < NB ? lb[threadIdx.x] : 0;
-        const uint32_t excl = wave_scan_incl(c, OpAdd{}, lane_id()) - c;
-        const uint32_t base = c ? atomicAdd(&lv.cursor[(size_t)seg * lv.cursor_per_seg + threadIdx.x], c) : 0;
-        lb[threadIdx.x] = excl;
-        gd[threadIdx.x] = base - excl;
+    {   // first two wavefronts: exclusive scan of the bin counts; reserve this tile's run of every bin with one atomic per bin
+        uint32_t c = 0, incl = 0;
+        if (threadIdx.x < 128) {
+            c = threadIdx.x < NB ? lb[threadIdx.x] : 0;
+            incl = wave_scan_incl(c, OpAdd{}, lane_id());
+            if (threadIdx.x == 63) wtot = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const uint32_t excl = incl - c + (threadIdx.x >= 64 ? wtot : 0);
+            const uint32_t base = c ? atomicAdd(&lv.cursor[(size_t)seg * lv.cursor_per_seg + threadIdx.x], c) : 0;
+            lb[threadIdx.x] = excl;
+            gd[threadIdx.x] = base - excl;
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -595,6 +603,169 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
             const uint32_t j = i * TB + threadIdx.x;
             if (FULL || j < nrows) dst[(size_t)(j + dlt[i]) * dstride] = stage[j];
         }
+    }
+}
+
+
+// ==== tuples wider than 8 bytes (h2o Q10: six int32 keys, nearly every row its own group) ==============================================
+// Round 1 sent such rows straight to an HBM table with device-scope atomics (0.54 s per 1e9 rows).  Here the rows are partitioned on a
+// 32-bit HASH of the tuple (pw_hash: one pass over the key columns), through up to three levels of the same tile scatter (128 x 64 x 64
+// partitions; every level: a per-segment histogram pass over the hash plane, a scan, the scatter), until a partition has at most
+// ~2400 ROWS.  The key columns travel as ordinary dword planes.  pw_agg then loads a whole partition into LDS -- keys, row ids, values --
+// and groups it there: an open-addressing table of representative row indices, tuples compared LDS to LDS, accumulators indexed by
+// the representative.  The record's key word is the group's first row: emit fetches the key columns through it (the wide-tuple
+// convention of groupby.hip).  Sized by rows, not by groups: a tuple that dominates the input overflows its partition and the call
+// falls back to the HBM table.
+__global__ void __launch_bounds__(256) pw_hash_kernel(KeySpec ks, uint32_t n, uint32_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = hash_wide(ks, i);
+}
+__global__ void __launch_bounds__(256) pn_gather_strided_kernel(const uint32_t* __restrict__ src, uint32_t stride, uint32_t count, uint32_t* __restrict__ dst) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) dst[i] = src[(size_t)i * stride];
+}
+// tile_prefix[s] = number of tiles of the segments before s; segment s = rows [seg_start[s], seg_start[s + 1])
+__global__ void __launch_bounds__(1024) pn_tiles_kernel(const uint32_t* __restrict__ seg_start, uint32_t nseg, uint32_t tile_rows, uint32_t* __restrict__ tile_prefix) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base <= nseg; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < nseg ? (uint32_t)(((uint64_t)(seg_start[i + 1] - seg_start[i]) + tile_rows - 1) / tile_rows) : 0;
+        const uint32_t incl = wave_scan_incl(v, OpAdd{}, lane_id());
+        if (lane_id() == 63) wsum[wave_id()] = incl;
+        __syncthreads();
+        uint32_t wbase = carry;
+        for (int w = 0; w < wave_id(); ++w) wbase += wsum[w];
+        if (i <= nseg) tile_prefix[i] = wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = wbase + incl;
+        __syncthreads();
+    }
+}
+// bin counts of one level: a tile lies inside ONE segment, so its counts go to cnt[seg * nbins + bin] (LDS histogram, one atomic per bin)
+template <int TB, int TR>
+__global__ void __launch_bounds__(TB) pn_level_hist_kernel(const uint32_t* __restrict__ keys, P2Level lv, uint32_t* __restrict__ cnt) {
+    constexpr uint32_t TPT = TB * TR;
+    __shared__ uint32_t h[128];
+    const uint32_t t = blockIdx.x;
+    if (t >= lv.tile_prefix[lv.nseg]) return;
+    uint32_t lo = 0, hi = lv.nseg;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lv.tile_prefix[mid] <= t) lo = mid; else hi = mid; }
+    const uint32_t seg = lo;
+    const uint64_t b = (uint64_t)lv.seg_start[seg] + (uint64_t)(t - lv.tile_prefix[seg]) * TPT;
+    const uint32_t e = lv.seg_start[seg + 1];
+    const uint32_t nrows = b + TPT > e ? (uint32_t)(e - b) : TPT;
+    if (threadIdx.x < 128) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nrows; i += TB) atomicAdd(&h[(__umulhi(key_hash<false>(keys[b + i]), lv.P) >> lv.shift) & lv.mask], 1u);
+    __syncthreads();
+    if (threadIdx.x < lv.nbins && h[threadIdx.x]) atomicAdd(&cnt[(size_t)seg * lv.nbins + threadIdx.x], h[threadIdx.x]);
+}
+
+struct WideIn {
+    int nkd;                                  // key dwords per row
+    const uint32_t* kplane[2 * MAXKEYS];      // partitioned key planes
+    const uint32_t* rows;                     // partitioned global row ids
+    const void* vcol[MAXACC]; int vesz[MAXACC];   // partitioned value arrays per accumulator (null: the row id)
+};
+constexpr uint32_t WEMPTY = 0xFFFFu;
+// one workgroup per partition (grid-stride); R = row capacity.  LDS: keys u32[nkd][R] | rows u32[R] | first u32[R] | count u32[R] |
+// acc u64[NACC][R] | vals u64[NACC][R] | table u16[2R] | rep u16[R]
+template <int NACC>
+__global__ void __launch_bounds__(1024) pw_agg_kernel(WideIn in, AccSpec as, AggOps ops, const uint32_t* __restrict__ pstart, uint32_t nparts, uint32_t ntotal,
+                                                      uint32_t R, int need_count, GTable out, uint32_t out_cap) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint64_t* lacc = reinterpret_cast<uint64_t*>(smem_raw);                    // [NACC][R]
+    uint64_t* lval = lacc + (size_t)NACC * R;                                  // [NACC][R]
+    uint32_t* lkey = reinterpret_cast<uint32_t*>(lval + (size_t)NACC * R);     // [nkd][R]
+    uint32_t* lrow = lkey + (size_t)in.nkd * R;
+    uint32_t* lfirst = lrow + R;
+    uint32_t* lcount = lfirst + R;
+    uint16_t* table = reinterpret_cast<uint16_t*>(lcount + R);                 // [2R]
+    uint16_t* rep = table + 2 * R;                                             // [R]
+    __shared__ uint32_t lemit, gbase, ngrp;
+    const uint32_t T = 2 * R;
+    for (uint32_t part = blockIdx.x; part < nparts; part += gridDim.x) {
+        const uint32_t b = pstart[part], e = part + 1 < nparts ? pstart[part + 1] : ntotal;
+        const uint32_t m = e - b;
+        if (!m) continue;
+        if (m > R) { if (threadIdx.x == 0) out.flags[0] = 1; continue; }        // a partition larger than LDS holds: the host falls back
+        for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+            for (int k = 0; k < in.nkd; ++k) lkey[(size_t)k * R + i] = in.kplane[k][b + i];
+            lrow[i] = in.rows[b + i];
+            lfirst[i] = NOROW; lcount[i] = 0;
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                lacc[(size_t)a * R + i] = acc_init(as.kind[a]);
+                lval[(size_t)a * R + i] = !in.vcol[a] ? (uint64_t)in.rows[b + i] : in.vesz[a] == 4 ? (uint64_t)static_cast<const uint32_t*>(in.vcol[a])[b + i] : static_cast<const uint64_t*>(in.vcol[a])[b + i];
+            }
+        }
+        for (uint32_t s = threadIdx.x; s < T; s += 1024) table[s] = (uint16_t)WEMPTY;
+        if (threadIdx.x == 0) { lemit = 0; ngrp = 0; }
+        __syncthreads();
+        // representative of every row: the first row index that claimed the slot of an equal tuple
+        for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+            uint32_t h = 0x9E3779B1u;
+            for (int k = 0; k < in.nkd; ++k) h = (h ^ lkey[(size_t)k * R + i]) * 0x85EBCA6Bu;
+            uint32_t s = __umulhi(h ^ (h >> 15), T);
+            uint32_t r = WEMPTY;
+            for (uint32_t step = 0; step < T; ++step) {
+                uint32_t cur = *reinterpret_cast<volatile uint16_t*>(&table[s]);
+                if (cur == WEMPTY) {
+                    // claim through a 32-bit CAS on the aligned pair holding the slot
+                    uint32_t* w = reinterpret_cast<uint32_t*>(table) + (s >> 1);
+                    const uint32_t sh = (s & 1) * 16;
+                    uint32_t old = *reinterpret_cast<volatile uint32_t*>(w);
+                    while (((old >> sh) & 0xFFFFu) == WEMPTY) {
+                        const uint32_t want = (old & ~(0xFFFFu << sh)) | (i << sh);
+                        const uint32_t got = atomicCAS(w, old, want);
+                        if (got == old) break;
+                        old = got;
+                    }
+                    cur = (*reinterpret_cast<volatile uint32_t*>(w) >> sh) & 0xFFFFu;
+                }
+                bool eq = cur == i;
+                if (!eq) { eq = true; for (int k = 0; k < in.nkd && eq; ++k) eq = lkey[(size_t)k * R + cur] == lkey[(size_t)k * R + i]; }
+                if (eq) { r = cur; break; }
+                s = s + 1 == T ? 0 : s + 1;
+            }
+            rep[i] = (uint16_t)r;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+            const uint32_t r = rep[i];
+            atomicMin(&lfirst[r], lrow[i]);
+            if (need_count) atomicAdd(&lcount[r], 1u);
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                uint64_t* acc = lacc + (size_t)a * R + r;
+                const uint64_t x = lval[(size_t)a * R + i];
+                switch (ops.opc[a]) {
+                case OPC_ADDI_I32: atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)(int32_t)(uint32_t)x); break;
+                case OPC_ADDI_U32: atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(uint32_t)x); break;
+                case OPC_ADDF_F32: atomicAdd(reinterpret_cast<double*>(acc), (double)__uint_as_float((uint32_t)x)); break;
+                case OPC_ADDF_F64: atomicAdd(reinterpret_cast<double*>(acc), __builtin_bit_cast(double, x)); break;
+                default: acc_apply(acc, as.kind[a], val_operand_bits(as.dt[a] == AQG_NONE ? AQG_UINT32 : as.dt[a], x, as.kind[a], as.square[a], as.part[a])); break;
+                }
+            }
+        }
+        __syncthreads();
+        // groups = rows that represent themselves
+        uint32_t mine = 0;
+        for (uint32_t i = threadIdx.x; i < m; i += 1024) mine += rep[i] == i;
+        mine = wave_reduce(mine, OpAdd{});
+        if (lane_id() == 0 && mine) atomicAdd(&ngrp, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) gbase = atomicAdd(&out.flags[1], ngrp);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+            if (rep[i] != i) continue;
+            const uint32_t g = gbase + atomicAdd(&lemit, 1u);
+            if (g >= out_cap) { out.flags[0] = 1; continue; }
+            *out.key_p(g) = (uint64_t)lfirst[i];                               // wide tuples: the key word is a representative ROW
+            *out.first_p(g) = lfirst[i];
+            *out.count_p(g) = need_count ? lcount[i] : 0;
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) *out.acc_p(a, g) = lacc[(size_t)a * R + i];
+        }
+        __syncthreads();
     }
 }
 
@@ -896,4 +1067,184 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     };
     if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
     return p1_launch_agg(ctx, ksz, as, vc, keysB, rowsB, valsB, fstart, 1u, P, n, need_count, out, out_cap);
+}
+
+// ---- wide tuples: host ----------------------------------------------------------------------------------------------------------------
+struct WidePlan { uint32_t R, P, B1; int L, nkd; bool ok; };
+static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n) {
+    WidePlan w;
+    memset(&w, 0, sizeof w);
+    for (int k = 0; k < ks.nkeys; ++k) w.nkd += aqg_dtype_size(ks.dt[k]) <= 4 ? 1 : 2;
+    const size_t per_row = 4 * (size_t)w.nkd + 4 + 4 + 4 + 16 * (size_t)as.nacc + 4 + 2;
+    uint32_t R = (uint32_t)((AGG_LDS - 64) / per_row);
+    if (R > 60000) R = 60000;
+    R &= ~7u;
+    double mu = (double)R;
+    for (int it = 0; it < 8; ++it) mu = (double)R - 5.0 * sqrt(mu);
+    if (mu < 64 || w.nkd > 2 * MAXKEYS) return w;
+    const uint64_t P = (uint64_t)((double)n / mu) + 1;
+    w.R = R;
+    if (P <= 128) { w.L = 1; w.B1 = (uint32_t)P; }
+    else if (P <= 128 * 64) { w.L = 2; w.B1 = (uint32_t)((P + 63) / 64); }
+    else if (P <= 128 * 4096) { w.L = 3; w.B1 = (uint32_t)((P + 4095) / 4096); }
+    else return w;
+    w.P = w.B1 << (6 * (w.L - 1));
+    w.ok = true;
+    return w;
+}
+bool aqg_partitionw_applies(const KeySpec& ks, const AccSpec& as, uint32_t n) { return ks.wide && pw_plan(ks, as, n).ok; }
+
+size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as) {
+    const WidePlan w = pw_plan(ks, as, n);
+    ValCols vc;
+    p1_val_cols(as, &vc);
+    size_t per_row = 4 + 2 * (4 + 4 + 4 * (size_t)w.nkd);                    // the hash column; two sets of {hash, row, key dwords}
+    for (int k = 0; k < ks.nkeys; ++k) if (aqg_dtype_size(ks.dt[k]) < 4) per_row += 4;       // widened key columns
+    for (int u = 0; u < vc.n; ++u) per_row += 2 * part_val_bytes(vc.dt[u]) + (aqg_dtype_size(vc.dt[u]) < 4 ? 4 : 0);
+    return ((size_t)n + 64) * per_row + 256 * (16 + 8 * MAXACC + 8 * MAXKEYS) + ((size_t)w.P + 4096) * 24 + ((size_t)n / P2_PT + (size_t)w.P + 64) * 8 + 65536;
+}
+
+int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap) {
+    const WidePlan w = pw_plan(ks, as, n);
+    if (!w.ok) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "wide-tuple partitioned group-by: the input does not fit 128 x 64 x 64 partitions");
+    ValCols vc;
+    p1_val_cols(as, &vc);
+    const unsigned g4 = aqg_grid(ctx, n, 256, 4, 16);
+    // the partition key: a 32-bit hash of the tuple
+    uint32_t* h32;
+    AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &h32));
+    hipLaunchKernelGGL(pw_hash_kernel, dim3(g4), dim3(256), 0, ctx->stream, ks, n, h32);
+    // source planes: the key columns as dwords (1- / 2-byte ones widened, 8-byte ones as two planes), then the distinct value columns
+    struct Src { const void* p; int stride, off, bytes; };
+    std::vector<Src> ksrc, vsrc;
+    for (int k = 0; k < ks.nkeys; ++k) {
+        const int esz = (int)aqg_dtype_size(ks.dt[k]);
+        const void* col = ks.col[k];
+        if (esz < 4) {
+            void* wide;
+            AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * 4, &wide));
+            hipLaunchKernelGGL(p1_widen_kernel, dim3(g4), dim3(256), 0, ctx->stream, col, esz, n, static_cast<uint32_t*>(wide));
+            col = wide;
+        }
+        if (esz <= 4) ksrc.push_back({col, 1, 0, 4});
+        else { ksrc.push_back({col, 2, 0, 4}); ksrc.push_back({col, 2, 1, 4}); }
+    }
+    for (int u = 0; u < vc.n; ++u) {
+        const int esz = (int)aqg_dtype_size(vc.dt[u]);
+        const void* col = vc.col[u];
+        if (esz < 4) {
+            void* wide;
+            AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * 4, &wide));
+            hipLaunchKernelGGL(p1_widen_kernel, dim3(g4), dim3(256), 0, ctx->stream, col, esz, n, static_cast<uint32_t*>(wide));
+            col = wide;
+        }
+        vsrc.push_back({col, 1, 0, (int)part_val_bytes(vc.dt[u])});
+    }
+    // two buffer sets: hash | row | key dwords | values
+    struct Set { uint32_t* hash; uint32_t* rows; uint32_t* kd[2 * MAXKEYS]; void* val[MAXACC]; } set[2];
+    for (int i = 0; i < 2; ++i) {
+        AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &set[i].hash));
+        AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &set[i].rows));
+        for (int k = 0; k < w.nkd; ++k) AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &set[i].kd[k]));
+        for (int u = 0; u < vc.n; ++u) AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * vsrc[u].bytes, &set[i].val[u]));
+    }
+    auto planes = [&](int level, const Set* from, const Set& to) {
+        Planes pl;
+        memset(&pl, 0, sizeof pl);
+        auto add = [&](int kind, const void* s_, int sstride, int soff, void* d, int dstride, int doff) {
+            Plane& Q = pl.p[pl.n++];
+            Q.kind = kind; Q.src = static_cast<const uint32_t*>(s_); Q.src_stride_dw = sstride; Q.src_off_dw = soff;
+            Q.dst = static_cast<uint32_t*>(d); Q.dst_stride_dw = dstride; Q.dst_off_dw = doff;
+        };
+        add(PL_LOAD, level == 1 ? h32 : from->hash, 1, 0, to.hash, 1, 0);
+        if (level == 1) add(PL_ROWIDX, nullptr, 0, 0, to.rows, 1, 0); else add(PL_LOAD, from->rows, 1, 0, to.rows, 1, 0);
+        for (int k = 0; k < w.nkd; ++k) {
+            if (level == 1) add(PL_LOAD, ksrc[k].p, ksrc[k].stride, ksrc[k].off, to.kd[k], 1, 0);
+            else add(PL_LOAD, from->kd[k], 1, 0, to.kd[k], 1, 0);
+        }
+        for (int u = 0; u < vc.n; ++u) {
+            const void* src = level == 1 ? vsrc[u].p : from->val[u];
+            if (vsrc[u].bytes == 4) add(PL_LOAD, src, 1, 0, to.val[u], 1, 0);
+            else { add(PL_LOAD, src, 2, 0, to.val[u], 2, 0); add(PL_LOAD, src, 2, 1, to.val[u], 2, 1); }
+        }
+        return pl;
+    };
+    if (2 + w.nkd + 2 * vc.n > MAXPL) return aqg_fail(ctx, AQG_ERR_ARG, "wide-tuple partitioned group-by: too many planes");
+    // level bookkeeping: segments of level l = the bins of level l - 1
+    uint32_t *seg, *tp, *cnt, *cur, *bsum;
+    const size_t maxseg = (size_t)w.P + 2;
+    AQG_TRY(aqg_ws_get(ctx, maxseg, &seg));
+    AQG_TRY(aqg_ws_get(ctx, maxseg, &tp));
+    AQG_TRY(aqg_ws_get(ctx, maxseg, &cnt));
+    AQG_TRY(aqg_ws_get(ctx, maxseg, &cur));
+    AQG_TRY(aqg_ws_get(ctx, maxseg / 2048 + 64, &bsum));
+    const uint32_t h0[2] = {0u, n};
+    void* st = nullptr;
+    AQG_TRY(aqg_host_stage(ctx, 16, &st));
+    memcpy(st, h0, 8);
+    AQG_HIP(ctx, hipMemcpyAsync(seg, st, 8, hipMemcpyHostToDevice, ctx->stream));
+    const size_t scat_lds = (size_t)P2_PT * 4;
+    AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, true>), scat_lds));
+    AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, false>), scat_lds));
+    uint32_t nseg = 1;
+    const Set* from = nullptr;
+    int to = 0;
+    for (int l = 1; l <= w.L; ++l) {
+        const uint32_t nb = l == 1 ? w.B1 : 64u, shift = 6u * (uint32_t)(w.L - l), mask = l == 1 ? 0xFFFFFFFFu : 63u;
+        const uint32_t* keys = l == 1 ? h32 : from->hash;
+        const unsigned tiles = (unsigned)((uint64_t)n / P2_PT) + nseg + 1;
+        hipLaunchKernelGGL(pn_tiles_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)seg, nseg, (uint32_t)P2_PT, tp);
+        AQG_HIP(ctx, hipMemsetAsync(cnt, 0, ((size_t)nseg * nb + 1) * 4, ctx->stream));
+        P2Level lv{seg, tp, cur, nseg, w.P, shift, mask, nb, nb};
+        hipLaunchKernelGGL((pn_level_hist_kernel<P2_TB, P2_TR>), dim3(tiles), dim3(P2_TB), 0, ctx->stream, keys, lv, cnt);
+        AQG_TRY(aqg_exclusive_scan_u32(ctx, cnt, (uint64_t)nseg * nb + 1, bsum));        // cnt[i] = start of (segment, bin) i; the last word = n
+        AQG_HIP(ctx, hipMemcpyAsync(cur, cnt, (size_t)nseg * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        const Planes pl = planes(l, from, set[to]);
+        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, true>), dim3(tiles), dim3(P2_TB), scat_lds, ctx->stream, keys, pl, lv);
+        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, false>), dim3(nseg), dim3(P2_TB), scat_lds, ctx->stream, keys, pl, lv);
+        AQG_TRY(aqg_check_launch(ctx, "wide-tuple partition level"));
+        // the bins of this level are the segments of the next (and, after the last level, the partitions)
+        AQG_HIP(ctx, hipMemcpyAsync(seg, cnt, ((size_t)nseg * nb + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        nseg *= nb;
+        from = &set[to];
+        to ^= 1;
+    }
+    // ---- aggregate every partition inside LDS -----------------------------------------------------------------------------------------
+    WideIn in;
+    memset(&in, 0, sizeof in);
+    in.nkd = w.nkd;
+    for (int k = 0; k < w.nkd; ++k) in.kplane[k] = from->kd[k];
+    in.rows = from->rows;
+    AggOps ops;
+    memset(&ops, 0, sizeof ops);
+    for (int a = 0; a < as.nacc; ++a) {
+        if (vc.of_acc[a] >= 0) { in.vcol[a] = from->val[vc.of_acc[a]]; in.vesz[a] = vsrc[vc.of_acc[a]].bytes; }
+        else { in.vcol[a] = nullptr; in.vesz[a] = 4; }
+        const int dt = as.dt[a], kind = as.kind[a];
+        int opc = OPC_GENERIC;
+        if (!as.square[a] && !as.part[a]) {
+            if (dt == AQG_INT32 && kind == ACC_ADD_I) opc = OPC_ADDI_I32;
+            else if (dt == AQG_UINT32 && kind == ACC_ADD_I) opc = OPC_ADDI_U32;
+            else if (dt == AQG_FLOAT && kind == ACC_ADD_F) opc = OPC_ADDF_F32;
+            else if (dt == AQG_DOUBLE && kind == ACC_ADD_F) opc = OPC_ADDF_F64;
+        }
+        ops.opc[a] = opc;
+    }
+    const size_t lds = (size_t)w.R * (4 * (size_t)w.nkd + 12 + 16 * (size_t)as.nacc + 6) + 64;
+    const unsigned grid = nseg < (unsigned)ctx->num_cu ? nseg : (unsigned)ctx->num_cu;
+    auto launch = [&](auto kern) -> int {
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
+        aqg_kernel_timer_begin(ctx);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, ctx->stream, in, as, ops, (const uint32_t*)seg, nseg, n, w.R, need_count, out, out_cap);
+        aqg_kernel_timer_end(ctx);
+        return aqg_check_launch(ctx, "pw_agg_kernel");
+    };
+    switch (as.nacc) {
+    case 0: return launch(&pw_agg_kernel<0>);
+    case 1: return launch(&pw_agg_kernel<1>);
+    case 2: return launch(&pw_agg_kernel<2>);
+    case 3: return launch(&pw_agg_kernel<3>);
+    case 4: return launch(&pw_agg_kernel<4>);
+    default: return aqg_fail(ctx, AQG_ERR_OVERFLOW, "wide-tuple partitioned group-by: at most 4 accumulators");
+    }
 }

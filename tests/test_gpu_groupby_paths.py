@@ -287,3 +287,45 @@ def test_handle_reuse_gaining_a_key_column(gpu, oracle):
             assert np.array_equal(gb.keys(k, key.dtype), key[o["first_rows"]])
         assert gu.same_bits(gb.result(0, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, v, o))
     gb.destroy()
+
+
+def test_wide_tuples_through_the_hash_partition_pipeline(gpu, oracle):
+    """h2o Q10 shape at a size the wide-tuple partition plan takes (tuples wider than 8 bytes, more than 2^20 groups): six int32 key
+    columns, sum(v3) and count; three key columns of mixed widths with an int32 sum; then a tuple that dominates the input, whose
+    partition overflows LDS and sends the call back to the HBM table"""
+    rng = np.random.default_rng(10)
+    n = 2_400_007
+    ids = [rng.integers(1, 101, n).astype(np.int32), rng.integers(1, 101, n).astype(np.int32), rng.integers(1, n // 100, n).astype(np.int32),
+           rng.integers(1, 101, n).astype(np.int32), rng.integers(1, 101, n).astype(np.int32), rng.integers(1, n // 100, n).astype(np.int32)]
+    v3 = np.round(rng.uniform(0, 100, n), 6).astype(np.float32)
+    v1 = rng.integers(-5, 6, n).astype(np.int32)
+    o = oracle.groupby(ids)
+    assert o["ngroups"] > (1 << 20)
+    for hint in (0, n):
+        gb = gpu.groupby_agg(ids, [ck.RED_SUM, ck.RED_COUNT, ck.RED_SUM], [v3, v3, v1], hint=hint)
+        assert gb.ngroups == o["ngroups"]
+        assert np.array_equal(gb.first_rows(), o["first_rows"])
+        assert np.array_equal(gb.counts(), o["counts"])
+        for k in range(6):
+            assert np.array_equal(gb.keys(k, np.int32), ids[k][o["first_rows"]])
+        got, want = gb.result(0, ck.RED_SUM, ck.FLOAT), oracle.grouped_reduce(ck.RED_SUM, v3, o)
+        assert np.all(np.abs(got - want) <= np.maximum(1.0, np.abs(want)) * 64 * 2.0 ** -50)
+        assert gu.same_bits(gb.result(2, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, v1, o))
+        gb.destroy()
+    # mixed widths: int64 + int16 + uint8 + int32 (15 bytes)
+    mk = [rng.integers(-2**40, 2**40, n).astype(np.int64), rng.integers(-300, 300, n).astype(np.int16), rng.integers(0, 3, n).astype(np.uint8), ids[2]]
+    o2 = oracle.groupby(mk)
+    gb = gpu.groupby_agg(mk, [ck.RED_SUM, ck.RED_MIN], [v1, v3], hint=n)
+    assert gb.ngroups == o2["ngroups"] and np.array_equal(gb.first_rows(), o2["first_rows"])
+    assert gu.same_bits(gb.result(0, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, v1, o2))
+    assert gu.same_bits(gb.result(1, ck.RED_MIN, ck.FLOAT), oracle.grouped_reduce(ck.RED_MIN, v3, o2))
+    gb.destroy()
+    # one tuple on half of the rows: its partition cannot fit LDS; the call must still be right (HBM table)
+    dom = [c.copy() for c in ids]
+    half = rng.random(n) < 0.5
+    for c in dom:
+        c[half] = 7
+    o3 = oracle.groupby(dom)
+    gb = gpu.groupby_agg(dom, [ck.RED_COUNT], [v1], hint=n)
+    assert gb.ngroups == o3["ngroups"] and np.array_equal(gb.first_rows(), o3["first_rows"]) and np.array_equal(gb.counts(), o3["counts"])
+    gb.destroy()
