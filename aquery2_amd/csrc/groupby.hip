@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __
     if (gmax && G > gmax) return;
     for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < G; i0 += gridDim.x * blockDim.x) {
         const uint32_t i = order ? order[i0] : i0;
-        uint32_t s = occ[i], g = gid_of_occ[i];
+        uint32_t s = occ ? occ[i] : i, g = gid_of_occ ? gid_of_occ[i] : i;       // (null: an ORDERED record table, aqg_sorted_tail)
         uint64_t key = s == gt.cap ? EMPTY64 : (*gt.key_p(s));
         for (int k = 0; k < es.nkeys; ++k) {
             uint64_t bits = es.wide ? load_bits(es.key_dt[k], es.key_col[k], (size_t)(uint32_t)key) : key >> es.key_shift[k];
@@ -1084,18 +1084,27 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
                            !h->no_wide_part && aqg_partitionw_applies(ks, as, n);
     if (use_wpart) gcap = (uint32_t)((uint64_t)hint + hint / 4 + 4096 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : (uint64_t)hint + hint / 4 + 4096);
 
+    // more than ~1.6e7 groups expected out of a partition plan: the records are ORDERED (aqg_sorted_tail) instead of ranked through a
+    // bitmap over the rows and gathered (h2o Q10, 1e9 groups: that tail took 219 of 317 ms and fetched 900 GB)
+    static const uint32_t sorted_min = getenv("AQG_SORTED_TAIL_MIN") ? (uint32_t)atoi(getenv("AQG_SORTED_TAIL_MIN")) : (1u << 24);
+    const bool sorted_tail = (use_part || use_wpart) && hint >= sorted_min && n > 8192;
     // ---- workspace ----------------------------------------------------------------------------
     size_t slots = (size_t)gcap + 1;
     uint32_t stride = 16;
     while (stride < 16 + 8 * (uint32_t)as.nacc) stride <<= 1;
-    size_t need = slots * ((size_t)stride + 4 + 4 + 4) + 4096 + 256 * 16;
-    if (!small_rank) need += (size_t)nwords * 8 + (size_t)ntiles * 4 + 4096;
-    const bool ordered_emit = !small_rank && hint >= (1u << 20);
+    size_t need = slots * (size_t)stride + 4096 + 256 * 16;
+    if (!sorted_tail) need += slots * (4 + 4 + 4);
+    if (!small_rank && !sorted_tail) need += (size_t)nwords * 8 + (size_t)ntiles * 4 + 4096;
+    const bool ordered_emit = !small_rank && hint >= (1u << 20) && !sorted_tail;
     if (ordered_emit) need += slots * 4 + 4096;
-    if (use_wpart) need += aqg_partitionw_ws_bytes(ctx, ks, n, as) + 65536;
-    else if (p1_bins) need += aqg_partition1_ws_bytes(ctx, ks, n, as, p1_bins) + 65536;
-    else if (p2_parts) need += aqg_partition2_ws_bytes(ctx, ks, n, as, p2_parts) + 65536;
-    else if (use_part) need += aqg_partition_ws_bytes(n, ks.total_bytes <= 4 ? 4 : 8, as, pbits) + 65536;
+    size_t part_need = 0;
+    if (use_wpart) part_need = aqg_partitionw_ws_bytes(ctx, ks, n, as) + 65536;
+    else if (p1_bins) part_need = aqg_partition1_ws_bytes(ctx, ks, n, as, p1_bins) + 65536;
+    else if (p2_parts) part_need = aqg_partition2_ws_bytes(ctx, ks, n, as, p2_parts) + 65536;
+    else if (use_part) part_need = aqg_partition_ws_bytes(n, ks.total_bytes <= 4 ? 4 : 8, as, pbits) + 65536;
+    // (the partition buffers are dead once the record table is written: the ordering pass takes their place in the arena)
+    const size_t sort_need = sorted_tail ? aqg_sorted_tail_ws_bytes(gcap, stride, as.nacc, ks.wide != 0) : 0;
+    need += part_need > sort_need ? part_need : sort_need;
     AQG_TRY(aqg_ws_reset(ctx));
     AQG_TRY(aqg_ws_ensure(ctx, need));
     GTable gt;
@@ -1116,10 +1125,13 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         }
     }
     AQG_TRY(aqg_ws_get(ctx, 64, &gt.flags));
-    AQG_TRY(aqg_ws_get(ctx, slots, &occ));
-    AQG_TRY(aqg_ws_get(ctx, slots, &gid_of_occ));
-    AQG_TRY(aqg_ws_get(ctx, slots, &slot_gid));
-    if (!small_rank) {
+    occ = gid_of_occ = slot_gid = nullptr;
+    if (!sorted_tail) {
+        AQG_TRY(aqg_ws_get(ctx, slots, &occ));
+        AQG_TRY(aqg_ws_get(ctx, slots, &gid_of_occ));
+        AQG_TRY(aqg_ws_get(ctx, slots, &slot_gid));
+    }
+    if (!small_rank && !sorted_tail) {
         AQG_TRY(aqg_ws_get(ctx, nwords, &bitmap));
         AQG_TRY(aqg_ws_get(ctx, nwords, &word_prefix));
         AQG_TRY(aqg_ws_get(ctx, ntiles + 1, &tile_total));
@@ -1175,14 +1187,14 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(rc);
     } else if (n && dense) {
         AQG_TRY(aqg_dense_aggregate(ctx, ks, dspec, as, n, plan.need_count, gt));
-    } else if (n && use_wpart) {
-        AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap));
-        hipLaunchKernelGGL(occ_iota_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, occ, (uint32_t)slots);
-    } else if (n && use_part) {
-        if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap));
+    } else if (n && (use_wpart || use_part)) {
+        const size_t mark = ctx->ws_off;
+        if (use_wpart) AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap));
+        else if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap));
         else if (p2_parts) AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap));
         else AQG_TRY(aqg_partition_aggregate(ctx, ks, as, n, pbits, part_lcap, plan.need_count, gt, gcap));
-        hipLaunchKernelGGL(occ_iota_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, occ, (uint32_t)slots);
+        if (sorted_tail) ctx->ws_off = mark;       // stream order: whatever is allocated there next is written after these kernels
+        else hipLaunchKernelGGL(occ_iota_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, occ, (uint32_t)slots);
     } else if (n) {
         uint32_t lrep = 1;
         if (use_lds) {   // replicate small tables: conflicts fall, LDS stays under ~32 KB per workgroup
@@ -1270,7 +1282,11 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         }
         AQG_TRY(aqg_check_launch(ctx, "first_rows_kernel"));
     }
-    if (defer || G) {
+    GTable gt_emit = gt;
+    if (sorted_tail && G) {
+        AQG_TRY(aqg_sorted_tail(ctx, gt, G, n, as.nacc, ks.wide != 0, &gt_emit));
+        gt_emit.flags = gt.flags;
+    } else if (defer || G) {
         if (small_rank) {
             hipLaunchKernelGGL(rank_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, gt, occ, gid_of_occ, slot_gid);
         } else {
@@ -1313,7 +1329,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
             AQG_TRY(aqg_ws_get(ctx, slots, &order));
             hipLaunchKernelGGL(emit_order_kernel, dim3(eg), dim3(256), 0, ctx->stream, (const uint32_t*)gid_of_occ, G, order);
         }
-        hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt, occ, gid_of_occ, es, (const uint32_t*)order, defer ? 4096u : 0u);
+        hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt_emit, (const uint32_t*)occ, (const uint32_t*)gid_of_occ, es, (const uint32_t*)order, defer ? 4096u : 0u);
         AQG_TRY(aqg_check_launch(ctx, "emit_kernel"));
     }
     if (defer) {

@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(1024) p2_setup_kernel(const uint32_t* __restri
 }
 
 // FULL: grid over all tiles of all segments, whole tiles only.  !FULL: one workgroup per segment takes its last, partial tile.
-template <int TB, int TR, bool K64, bool FULL>
+template <int TB, int TR, bool K64, bool FULL, bool HASHED = true>
 __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 64 / 4 : 1) p2_scatter_kernel(const key_t_<K64>* __restrict__ keys, Planes pl, P2Level lv) {
     constexpr int TPT = TB * TR;
     constexpr int HH = TR < 16 ? TR : 16;
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < HH; ++r) {
-            const uint32_t d = (__umulhi(key_hash<K64>(key[r]), lv.P) >> lv.shift) & lv.mask;
+            const uint32_t d = (__umulhi(HASHED ? key_hash<K64>(key[r]) : (uint32_t)key[r], lv.P) >> lv.shift) & lv.mask;
             pos[h + r] = FULL || trow<TB>(h + r) < nrows ? (d << 15) | atomicAdd(&lb[d], 1u) : 0xFFFFFFFFu;
         }
     }
@@ -586,10 +586,10 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
                 for (int r = 0; r < HH; ++r) v[r] = rb + trow<TB>(h + r);
             } else if (Q.src_stride_dw == 1) {
                 load_rows_t<TB, FULL>(Q.src, rb, nrows, h, v);
-            } else {                                   // one half of every element of an 8-byte column
-                const uint32_t* tp = Q.src + 2 * (size_t)rb + Q.src_off_dw;
+            } else {                                   // one dword of every element of a wider record (halves of 8-byte columns, fields of AoS records)
+                const uint32_t* tp = Q.src + (size_t)Q.src_stride_dw * rb + Q.src_off_dw;
 #pragma unroll
-                for (int r = 0; r < HH; ++r) { const uint32_t o = trow<TB>(h + r); v[r] = tp[2 * (size_t)(FULL || o < nrows ? o : nrows - 1)]; }
+                for (int r = 0; r < HH; ++r) { const uint32_t o = trow<TB>(h + r); v[r] = tp[(size_t)Q.src_stride_dw * (FULL || o < nrows ? o : nrows - 1)]; }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -643,7 +643,8 @@ __global__ void __launch_bounds__(1024) pn_tiles_kernel(const uint32_t* __restri
     }
 }
 // bin counts of one level: a tile lies inside ONE segment, so its counts go to cnt[seg * nbins + bin] (LDS histogram, one atomic per bin)
-template <int TB, int TR>
+// HASHED = false: the key is a row id and the bin ORDER-PRESERVING, f = umulhi(row, lv.P) with lv.P = floor(partitions * 2^32 / rows)
+template <int TB, int TR, bool HASHED>
 __global__ void __launch_bounds__(TB) pn_level_hist_kernel(const uint32_t* __restrict__ keys, P2Level lv, uint32_t* __restrict__ cnt) {
     constexpr uint32_t TPT = TB * TR;
     __shared__ uint32_t h[128];
@@ -657,7 +658,7 @@ __global__ void __launch_bounds__(TB) pn_level_hist_kernel(const uint32_t* __res
     const uint32_t nrows = b + TPT > e ? (uint32_t)(e - b) : TPT;
     if (threadIdx.x < 128) h[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nrows; i += TB) atomicAdd(&h[(__umulhi(key_hash<false>(keys[b + i]), lv.P) >> lv.shift) & lv.mask], 1u);
+    for (uint32_t i = threadIdx.x; i < nrows; i += TB) atomicAdd(&h[(__umulhi(HASHED ? key_hash<false>(keys[b + i]) : keys[b + i], lv.P) >> lv.shift) & lv.mask], 1u);
     __syncthreads();
     if (threadIdx.x < lv.nbins && h[threadIdx.x]) atomicAdd(&cnt[(size_t)seg * lv.nbins + threadIdx.x], h[threadIdx.x]);
 }
@@ -764,6 +765,66 @@ __global__ void __launch_bounds__(1024) pw_agg_kernel(WideIn in, AccSpec as, Agg
             *out.first_p(g) = lfirst[i];
             *out.count_p(g) = need_count ? lcount[i] : 0;
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) *out.acc_p(a, g) = lacc[(size_t)a * R + i];
+        }
+        __syncthreads();
+    }
+}
+
+
+// ==== ordering a huge group table (G ~ N: h2o Q10) ========================================================================================
+// Group ids are ranks of first rows.  For <= 1e7 groups groupby.hip ranks through a bitmap over the rows and gathers the records in id
+// order; at 1e9 groups those gathers fetch 600 GB.  Here the RECORDS are ordered instead, with the same tile scatter keyed on the first
+// row through an ORDER-PRESERVING bin f = umulhi(first_row, M), M = floor(4096 * 2^32 / rows): two levels of 64 bins leave 4096
+// partitions, partition p holding exactly the groups whose first rows fall into its row interval -- so its start is the id of its first
+// group, and the rank inside it comes from a bitmap of the interval in LDS.  pn_rank_write writes the records, in id order, as a record
+// table emit_kernel then walks sequentially.
+struct SortedIn {
+    const uint32_t* first; const uint32_t* count; const uint64_t* key; const uint64_t* acc[MAXACC];
+    int nacc, has_count, wide;
+};
+__global__ void __launch_bounds__(1024) pn_rank_write_kernel(SortedIn in, const uint32_t* __restrict__ pstart, uint32_t nparts, uint32_t G, uint32_t M, uint32_t nrows_total,
+                                                             uint32_t maxwords, GTable out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint32_t* bm = reinterpret_cast<uint32_t*>(smem_raw);          // [maxwords] bitmap of the partition's row interval
+    uint32_t* bs = bm + maxwords;                                  // [maxwords / 8 + 1] set bits before every block of eight words
+    __shared__ uint32_t wsum[16];
+    for (uint32_t part = blockIdx.x; part < nparts; part += gridDim.x) {
+        const uint32_t b = pstart[part], e = part + 1 < nparts ? pstart[part + 1] : G;
+        if (b >= e) continue;
+        const uint64_t lo64 = (((uint64_t)part << 32) + M - 1) / M, hi64 = ((((uint64_t)part + 1) << 32) + M - 1) / M;
+        const uint32_t lo = (uint32_t)lo64, hi = hi64 < nrows_total ? (uint32_t)hi64 : nrows_total;
+        const uint32_t nw = (hi - lo + 31) / 32, nblk = (nw + 7) / 8;
+        if (nw > maxwords) { if (threadIdx.x == 0) out.flags[0] = 1; continue; }
+        for (uint32_t w = threadIdx.x; w < nblk * 8; w += 1024) bm[w] = 0;
+        __syncthreads();
+        for (uint32_t j = b + threadIdx.x; j < e; j += 1024) { const uint32_t r = in.first[j] - lo; atomicOr(&bm[r >> 5], 1u << (r & 31)); }
+        __syncthreads();
+        // exclusive prefix of the set bits per block of eight words (nblk <= 4096: four blocks per thread)
+        uint32_t c[4], s4 = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t blk = threadIdx.x * 4 + k;
+            uint32_t t = 0;
+            if (blk < nblk) for (int q = 0; q < 8; ++q) t += __popc(bm[blk * 8 + q]);
+            c[k] = t; s4 += t;
+        }
+        const uint32_t incl = wave_scan_incl(s4, OpAdd{}, lane_id());
+        if (lane_id() == 63) wsum[wave_id()] = incl;
+        __syncthreads();
+        uint32_t base = incl - s4;
+        for (int w = 0; w < wave_id(); ++w) base += wsum[w];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const uint32_t blk = threadIdx.x * 4 + k; if (blk < nblk) bs[blk] = base; base += c[k]; }
+        __syncthreads();
+        for (uint32_t j = b + threadIdx.x; j < e; j += 1024) {
+            const uint32_t fr = in.first[j], r = fr - lo, w = r >> 5;
+            uint32_t rank = bs[w >> 3] + __popc(bm[w] & ((1u << (r & 31)) - 1u));
+            for (uint32_t q = w & ~7u; q < w; ++q) rank += __popc(bm[q]);
+            const uint32_t g = b + rank;
+            *out.key_p(g) = in.wide ? (uint64_t)fr : in.key[j];
+            *out.first_p(g) = fr;
+            *out.count_p(g) = in.has_count ? in.count[j] : 0;
+            for (int a = 0; a < in.nacc; ++a) *out.acc_p(a, g) = in.acc[a][j];
         }
         __syncthreads();
     }
@@ -1196,7 +1257,7 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         hipLaunchKernelGGL(pn_tiles_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)seg, nseg, (uint32_t)P2_PT, tp);
         AQG_HIP(ctx, hipMemsetAsync(cnt, 0, ((size_t)nseg * nb + 1) * 4, ctx->stream));
         P2Level lv{seg, tp, cur, nseg, w.P, shift, mask, nb, nb};
-        hipLaunchKernelGGL((pn_level_hist_kernel<P2_TB, P2_TR>), dim3(tiles), dim3(P2_TB), 0, ctx->stream, keys, lv, cnt);
+        hipLaunchKernelGGL((pn_level_hist_kernel<P2_TB, P2_TR, true>), dim3(tiles), dim3(P2_TB), 0, ctx->stream, keys, lv, cnt);
         AQG_TRY(aqg_exclusive_scan_u32(ctx, cnt, (uint64_t)nseg * nb + 1, bsum));        // cnt[i] = start of (segment, bin) i; the last word = n
         AQG_HIP(ctx, hipMemcpyAsync(cur, cnt, (size_t)nseg * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
         const Planes pl = planes(l, from, set[to]);
@@ -1247,4 +1308,102 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     case 4: return launch(&pw_agg_kernel<4>);
     default: return aqg_fail(ctx, AQG_ERR_OVERFLOW, "wide-tuple partitioned group-by: at most 4 accumulators");
     }
+}
+
+// ---- ordering a huge group table: host ------------------------------------------------------------------------------------------------
+size_t aqg_sorted_tail_ws_bytes(uint32_t gcap, uint32_t stride, int nacc, bool wide) {
+    const size_t per = 4 + 2 * (4 + 4 + (wide ? 0 : 8) + 8 * (size_t)nacc) + stride;      // first rows; two plane sets; the ordered table
+    return ((size_t)gcap + 64) * per + 256 * (16 + 4 * MAXACC) + (size_t)5 * 4200 * 4 + 65536;
+}
+// records 0 .. G-1 of `gt` (AoS: key | first | count | acc...) -> `sorted` (same layout, ordered by first row = dense group id)
+int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows, int nacc, bool wide, GTable* sorted) {
+    if (G == 0) return AQG_OK;
+    if (n_rows <= 8192) return aqg_fail(ctx, AQG_ERR_ARG, "ordered group table: too few rows");
+    const uint32_t stride_dw = gt.kst / 4;
+    const uint32_t PP = 4096, M = (uint32_t)((((uint64_t)PP) << 32) / n_rows);
+    uint32_t* fr0;
+    AQG_TRY(aqg_ws_get(ctx, (size_t)G + 64, &fr0));
+    hipLaunchKernelGGL(pn_gather_strided_kernel, dim3(aqg_grid(ctx, G, 256, 4, 16)), dim3(256), 0, ctx->stream, reinterpret_cast<const uint32_t*>(gt.fb), stride_dw, G, fr0);
+    struct Set { uint32_t* first; uint32_t* count; uint64_t* key; uint64_t* acc[MAXACC]; } set[2];
+    for (int i = 0; i < 2; ++i) {
+        AQG_TRY(aqg_ws_get(ctx, (size_t)G + 64, &set[i].first));
+        AQG_TRY(aqg_ws_get(ctx, (size_t)G + 64, &set[i].count));
+        set[i].key = nullptr;
+        if (!wide) AQG_TRY(aqg_ws_get(ctx, (size_t)G + 64, &set[i].key));
+        for (int a = 0; a < nacc; ++a) AQG_TRY(aqg_ws_get(ctx, (size_t)G + 64, &set[i].acc[a]));
+    }
+    auto planes = [&](int level, const Set* from, const Set& to) {
+        Planes pl;
+        memset(&pl, 0, sizeof pl);
+        auto add = [&](const void* s_, int sstride, int soff, void* d, int dstride, int doff) {
+            Plane& Q = pl.p[pl.n++];
+            Q.kind = PL_LOAD; Q.src = static_cast<const uint32_t*>(s_); Q.src_stride_dw = sstride; Q.src_off_dw = soff;
+            Q.dst = static_cast<uint32_t*>(d); Q.dst_stride_dw = dstride; Q.dst_off_dw = doff;
+        };
+        if (level == 1) {                                                     // fields of the AoS records
+            add(fr0, 1, 0, to.first, 1, 0);
+            add(gt.cb, (int)stride_dw, 0, to.count, 1, 0);
+            if (!wide) { add(gt.kb, (int)stride_dw, 0, to.key, 2, 0); add(gt.kb, (int)stride_dw, 1, to.key, 2, 1); }
+            for (int a = 0; a < nacc; ++a) { add(gt.ab + (size_t)a * gt.astep, (int)stride_dw, 0, to.acc[a], 2, 0); add(gt.ab + (size_t)a * gt.astep, (int)stride_dw, 1, to.acc[a], 2, 1); }
+        } else {
+            add(from->first, 1, 0, to.first, 1, 0);
+            add(from->count, 1, 0, to.count, 1, 0);
+            if (!wide) { add(from->key, 2, 0, to.key, 2, 0); add(from->key, 2, 1, to.key, 2, 1); }
+            for (int a = 0; a < nacc; ++a) { add(from->acc[a], 2, 0, to.acc[a], 2, 0); add(from->acc[a], 2, 1, to.acc[a], 2, 1); }
+        }
+        return pl;
+    };
+    uint32_t *seg, *tp, *cnt, *cur, *bsum;
+    AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &seg));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &tp));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &cnt));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &cur));
+    AQG_TRY(aqg_ws_get(ctx, 64 + 8, &bsum));
+    const uint32_t h0[2] = {0u, G};
+    void* st = nullptr;
+    AQG_TRY(aqg_host_stage(ctx, 16, &st));
+    memcpy(st, h0, 8);
+    AQG_HIP(ctx, hipMemcpyAsync(seg, st, 8, hipMemcpyHostToDevice, ctx->stream));
+    const size_t scat_lds = (size_t)P2_PT * 4;
+    AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, true, false>), scat_lds));
+    AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, false, false>), scat_lds));
+    uint32_t nseg = 1;
+    const Set* from = nullptr;
+    for (int l = 1; l <= 2; ++l) {
+        const uint32_t nb = 64, shift = l == 1 ? 6u : 0u, mask = l == 1 ? 0xFFFFFFFFu : 63u;
+        const uint32_t* keys = l == 1 ? fr0 : from->first;
+        const unsigned tiles = (unsigned)((uint64_t)G / P2_PT) + nseg + 1;
+        hipLaunchKernelGGL(pn_tiles_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)seg, nseg, (uint32_t)P2_PT, tp);
+        AQG_HIP(ctx, hipMemsetAsync(cnt, 0, ((size_t)nseg * nb + 1) * 4, ctx->stream));
+        P2Level lv{seg, tp, cur, nseg, M, shift, mask, nb, nb};
+        hipLaunchKernelGGL((pn_level_hist_kernel<P2_TB, P2_TR, false>), dim3(tiles), dim3(P2_TB), 0, ctx->stream, keys, lv, cnt);
+        AQG_TRY(aqg_exclusive_scan_u32(ctx, cnt, (uint64_t)nseg * nb + 1, bsum));
+        AQG_HIP(ctx, hipMemcpyAsync(cur, cnt, (size_t)nseg * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        const Planes pl = planes(l, from, set[l - 1]);
+        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, true, false>), dim3(tiles), dim3(P2_TB), scat_lds, ctx->stream, keys, pl, lv);
+        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, false, false>), dim3(nseg), dim3(P2_TB), scat_lds, ctx->stream, keys, pl, lv);
+        AQG_TRY(aqg_check_launch(ctx, "ordered group table: level"));
+        AQG_HIP(ctx, hipMemcpyAsync(seg, cnt, ((size_t)nseg * nb + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        nseg *= nb;
+        from = &set[l - 1];
+    }
+    // the ordered record table
+    unsigned char* base = nullptr;
+    AQG_TRY(aqg_ws_get(ctx, ((size_t)G + 1) * gt.kst, &base));
+    GTable so = gt;
+    so.kb = base; so.fb = base + 8; so.cb = base + 12; so.ab = base + 16;
+    so.cap = 0xFFFFFFFFu;
+    SortedIn in;
+    memset(&in, 0, sizeof in);
+    in.first = from->first; in.count = from->count; in.key = from->key; in.nacc = nacc; in.has_count = gt.has_count; in.wide = wide;
+    for (int a = 0; a < nacc; ++a) in.acc[a] = from->acc[a];
+    const uint32_t interval = (uint32_t)(((uint64_t)1 << 32) / M) + 2;               // rows a partition's interval can span
+    const uint32_t maxwords = ((interval + 31) / 32 + 7) & ~7u;
+    if ((size_t)maxwords * 4 + ((size_t)maxwords / 8 + 1) * 4 > 150 * 1024 || maxwords / 8 > 4096) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "ordered group table: row interval of a partition exceeds LDS");
+    const size_t lds = (size_t)maxwords * 4 + ((size_t)maxwords / 8 + 1) * 4;
+    AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&pn_rank_write_kernel), lds));
+    hipLaunchKernelGGL(pn_rank_write_kernel, dim3(nseg < 4u * ctx->num_cu ? nseg : 4u * ctx->num_cu), dim3(1024), lds, ctx->stream, in, (const uint32_t*)seg, nseg, G, M, n_rows, maxwords, so);
+    AQG_TRY(aqg_check_launch(ctx, "pn_rank_write_kernel"));
+    *sorted = so;
+    return AQG_OK;
 }

@@ -14,3 +14,7 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
 bool aqg_partitionw_applies(const KeySpec& ks, const AccSpec& as, uint32_t n);
 size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as);
 int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap);
+// ordering a huge group table (more than ~1.6e7 groups): the records ordered by first row with the tile scatter, instead of ranked
+// through a bitmap and gathered
+size_t aqg_sorted_tail_ws_bytes(uint32_t gcap, uint32_t stride, int nacc, bool wide);
+int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows, int nacc, bool wide, GTable* sorted);
