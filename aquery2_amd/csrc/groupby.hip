@@ -619,75 +619,146 @@ template <class T> __device__ __noinline__ void store_minmax(void* out, uint32_t
 __global__ void __launch_bounds__(256) emit_order_kernel(const uint32_t* __restrict__ gid_of_occ, uint32_t G, uint32_t* __restrict__ order) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) order[gid_of_occ[i]] = i;
 }
+// one group: record `s` of `gt` -> row `g` of every output column.  `key`: the packed key, or (wide tuples) the group's first row
+template <bool KEYS = true>
+__device__ inline void emit_record(const GTable& gt, uint32_t s, uint32_t g, const EmitSpec& es, uint64_t key) {
+    if constexpr (KEYS) for (int k = 0; k < es.nkeys; ++k) {
+        uint64_t bits = es.wide ? load_bits(es.key_dt[k], es.key_col[k], (size_t)(uint32_t)key) : key >> es.key_shift[k];
+        store_sized(es.key_out[k], g, aqg_dtype_size_dev(es.key_dt[k]), bits);
+    }
+    es.first_out[g] = (*gt.first_p(s));
+    uint32_t cnt = gt.has_count ? (*gt.count_p(s)) : 0;
+    if (es.count_out) es.count_out[g] = cnt;
+    for (int j = 0; j < es.nagg; ++j) {
+        const AggOut& a = es.agg[j];
+        int vc = vclass(a.dt);
+        uint64_t v0 = a.acc0 >= 0 ? (*gt.acc_p(a.acc0, s)) : 0;
+        const bool wide = a.dt == AQG_INT64 || a.dt == AQG_UINT64;
+        // exact 128-bit sum (and sum of squares) of an integer column
+        auto sum128 = [&](int lo_acc, int hi_acc) -> aqg_i128 {
+            uint64_t lo = (*gt.acc_p(lo_acc, s));
+            if (!wide) return vc == VC_U ? i128_from_u64(lo) : i128_from_i64((int64_t)lo);
+            uint64_t hi = (*gt.acc_p(hi_acc, s));                       // sum of the high halves, to be shifted by 32
+            aqg_i128 h = vc == VC_U ? i128_from_u64(hi) : i128_from_i64((int64_t)hi);
+            aqg_i128 sh = {h.lo << 32, (h.hi << 32) | (h.lo >> 32)};
+            return i128_add(sh, i128_from_u64(lo));
+        };
+        auto to_double = [&](aqg_i128 v) -> double { return vc == VC_U ? u128_to_double(v.hi, v.lo) : i128_to_double(v); };
+        switch (a.op) {
+        case AQG_RED_SUM:                                               // -> GetLongType
+            if (vc == VC_F) static_cast<double*>(a.out)[g] = __builtin_bit_cast(double, v0);
+            else static_cast<aqg_i128*>(a.out)[g] = sum128(a.acc0, a.acc1);
+            break;
+        case AQG_RED_COUNT: static_cast<uint64_t*>(a.out)[g] = cnt; break;
+        case AQG_RED_AVG: {                                             // sum / (double)size
+            double sd = vc == VC_F ? __builtin_bit_cast(double, v0) : to_double(sum128(a.acc0, a.acc1));
+            static_cast<double*>(a.out)[g] = sd / (double)cnt;
+        } break;
+        case AQG_RED_VAR: case AQG_RED_STDDEV: {                        // (ssq - s*s/(double)(n+1)) / (double)(n+1)
+            double np1 = (double)(uint32_t)(cnt + 1), d;
+            if (vc == VC_F) {
+                double sd = __builtin_bit_cast(double, v0), q = __builtin_bit_cast(double, (*gt.acc_p(a.acc2, s)));
+                d = (q - sd * sd / np1) / np1;
+            } else {
+                aqg_i128 sm = sum128(a.acc0, a.acc1), q = sum128(a.acc2, a.acc3);
+                aqg_i128 ss = mul_128(sm, sm);                          // s * s in the 128-bit LongType (wraps like the reference)
+                d = (to_double(q) - to_double(ss) / np1) / np1;
+            }
+            static_cast<double*>(a.out)[g] = a.op == AQG_RED_STDDEV ? sqrt(d) : d;
+        } break;
+        case AQG_RED_MIN: case AQG_RED_MAX: {
+            bool mx = a.op == AQG_RED_MAX;
+            switch (a.dt) {
+            case AQG_INT8: store_minmax<int8_t>(a.out, g, v0, mx); break;
+            case AQG_INT16: store_minmax<int16_t>(a.out, g, v0, mx); break;
+            case AQG_INT32: store_minmax<int32_t>(a.out, g, v0, mx); break;
+            case AQG_INT64: store_minmax<int64_t>(a.out, g, v0, mx); break;
+            case AQG_UINT8: store_minmax<uint8_t>(a.out, g, v0, mx); break;
+            case AQG_UINT16: store_minmax<uint16_t>(a.out, g, v0, mx); break;
+            case AQG_UINT32: store_minmax<uint32_t>(a.out, g, v0, mx); break;
+            case AQG_UINT64: store_minmax<uint64_t>(a.out, g, v0, mx); break;
+            case AQG_FLOAT: store_minmax<float>(a.out, g, v0, mx); break;
+            default: store_minmax<double>(a.out, g, v0, mx); break;
+            }
+        } break;
+        }
+    }
+}
 __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __restrict__ occ, const uint32_t* __restrict__ gid_of_occ, EmitSpec es,
                                                    const uint32_t* __restrict__ order, uint32_t gmax /* 0: no bound; else give up beyond it (ranks were not computed) */) {
     uint32_t G = gt.flags[1];
     if (gmax && G > gmax) return;
     for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < G; i0 += gridDim.x * blockDim.x) {
         const uint32_t i = order ? order[i0] : i0;
-        uint32_t s = occ ? occ[i] : i, g = gid_of_occ ? gid_of_occ[i] : i;       // (null: an ORDERED record table, aqg_sorted_tail)
-        uint64_t key = s == gt.cap ? EMPTY64 : (*gt.key_p(s));
-        for (int k = 0; k < es.nkeys; ++k) {
-            uint64_t bits = es.wide ? load_bits(es.key_dt[k], es.key_col[k], (size_t)(uint32_t)key) : key >> es.key_shift[k];
-            store_sized(es.key_out[k], g, aqg_dtype_size_dev(es.key_dt[k]), bits);
+        const uint32_t s = occ[i], g = gid_of_occ[i];
+        emit_record(gt, s, g, es, s == gt.cap ? EMPTY64 : (*gt.key_p(s)));
+    }
+}
+
+// Huge group tables (aqg_sorted_tail): one workgroup per partition of the record planes.  The partition holds the groups whose first
+// rows lie in one interval of <= C rows, so its first group id is its start offset and a group's id is that plus the number of set
+// bits below its first row in a bitmap of the interval.  The records are permuted into id order inside LDS and emitted from there:
+// every output column is written front to back, the key columns (wide tuples) are read in ascending row order.
+__global__ void __launch_bounds__(512) sorted_emit_kernel(SortedParts sp, uint32_t G, uint32_t n_rows, int nacc, int has_count, int wide, EmitSpec es, uint32_t* __restrict__ flags) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const uint32_t C = sp.cap, W = C / 32 + 8;
+    uint64_t* sacc = reinterpret_cast<uint64_t*>(smem_raw);                 // [nacc][C]
+    uint64_t* skey = sacc + (size_t)nacc * C;                               // [C] (packed keys only)
+    uint32_t* sfirst = reinterpret_cast<uint32_t*>(skey + (wide ? 0 : C));  // [C]
+    uint32_t* scount = sfirst + C;                                          // [C]
+    uint32_t* bm = scount + C;                                              // [W] bitmap of the row interval
+    uint32_t* wp = bm + W;                                                  // [W] set bits before every word
+    __shared__ uint32_t wsum[8];
+    GTable lt;
+    lt.kb = reinterpret_cast<unsigned char*>(skey); lt.fb = reinterpret_cast<unsigned char*>(sfirst); lt.cb = reinterpret_cast<unsigned char*>(scount);
+    lt.ab = reinterpret_cast<unsigned char*>(sacc);
+    lt.kst = 8; lt.fst = 4; lt.cst = 4; lt.ast = 8; lt.astep = (uint64_t)C * 8; lt.cap = 0xFFFFFFFFu; lt.flags = nullptr; lt.has_count = has_count;
+    bool k32 = wide != 0;
+    for (int k = 0; k < es.nkeys; ++k) k32 = k32 && aqg_dtype_size_dev(es.key_dt[k]) == 4;
+    for (uint32_t part = blockIdx.x; part < sp.nparts; part += gridDim.x) {
+        const uint32_t b = sp.pstart[part], e = sp.pstart[part + 1];
+        if (b >= e) continue;
+        const uint64_t lo64 = (((uint64_t)part << 32) + sp.M - 1) / sp.M, hi64 = ((((uint64_t)part + 1) << 32) + sp.M - 1) / sp.M;
+        const uint32_t lo = (uint32_t)lo64, hi = hi64 < n_rows ? (uint32_t)hi64 : n_rows;
+        const uint32_t c = e - b, nw = (hi - lo + 31) / 32;
+        if (hi - lo > C || c > C || e > G) { if (threadIdx.x == 0) flags[0] = 1; continue; }       // (the plan rules it out)
+        for (uint32_t w = threadIdx.x; w < nw; w += 512) bm[w] = 0;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < c; j += 512) { const uint32_t r = sp.first[b + j] - lo; atomicOr(&bm[r >> 5], 1u << (r & 31)); }
+        __syncthreads();
+        {   // nw <= 512: one word per thread
+            const uint32_t t = threadIdx.x < nw ? __popc(bm[threadIdx.x]) : 0;
+            const uint32_t incl = wave_scan_incl(t, OpAdd{}, lane_id());
+            if (lane_id() == 63) wsum[wave_id()] = incl;
+            __syncthreads();
+            uint32_t base = incl - t;
+            for (int w = 0; w < wave_id(); ++w) base += wsum[w];
+            if (threadIdx.x < nw) wp[threadIdx.x] = base;
         }
-        es.first_out[g] = (*gt.first_p(s));
-        uint32_t cnt = gt.has_count ? (*gt.count_p(s)) : 0;
-        if (es.count_out) es.count_out[g] = cnt;
-        for (int j = 0; j < es.nagg; ++j) {
-            const AggOut& a = es.agg[j];
-            int vc = vclass(a.dt);
-            uint64_t v0 = a.acc0 >= 0 ? (*gt.acc_p(a.acc0, s)) : 0;
-            const bool wide = a.dt == AQG_INT64 || a.dt == AQG_UINT64;
-            // exact 128-bit sum (and sum of squares) of an integer column
-            auto sum128 = [&](int lo_acc, int hi_acc) -> aqg_i128 {
-                uint64_t lo = (*gt.acc_p(lo_acc, s));
-                if (!wide) return vc == VC_U ? i128_from_u64(lo) : i128_from_i64((int64_t)lo);
-                uint64_t hi = (*gt.acc_p(hi_acc, s));                       // sum of the high halves, to be shifted by 32
-                aqg_i128 h = vc == VC_U ? i128_from_u64(hi) : i128_from_i64((int64_t)hi);
-                aqg_i128 sh = {h.lo << 32, (h.hi << 32) | (h.lo >> 32)};
-                return i128_add(sh, i128_from_u64(lo));
-            };
-            auto to_double = [&](aqg_i128 v) -> double { return vc == VC_U ? u128_to_double(v.hi, v.lo) : i128_to_double(v); };
-            switch (a.op) {
-            case AQG_RED_SUM:                                               // -> GetLongType
-                if (vc == VC_F) static_cast<double*>(a.out)[g] = __builtin_bit_cast(double, v0);
-                else static_cast<aqg_i128*>(a.out)[g] = sum128(a.acc0, a.acc1);
-                break;
-            case AQG_RED_COUNT: static_cast<uint64_t*>(a.out)[g] = cnt; break;
-            case AQG_RED_AVG: {                                             // sum / (double)size
-                double sd = vc == VC_F ? __builtin_bit_cast(double, v0) : to_double(sum128(a.acc0, a.acc1));
-                static_cast<double*>(a.out)[g] = sd / (double)cnt;
-            } break;
-            case AQG_RED_VAR: case AQG_RED_STDDEV: {                        // (ssq - s*s/(double)(n+1)) / (double)(n+1)
-                double np1 = (double)(uint32_t)(cnt + 1), d;
-                if (vc == VC_F) {
-                    double sd = __builtin_bit_cast(double, v0), q = __builtin_bit_cast(double, (*gt.acc_p(a.acc2, s)));
-                    d = (q - sd * sd / np1) / np1;
-                } else {
-                    aqg_i128 sm = sum128(a.acc0, a.acc1), q = sum128(a.acc2, a.acc3);
-                    aqg_i128 ss = mul_128(sm, sm);                          // s * s in the 128-bit LongType (wraps like the reference)
-                    d = (to_double(q) - to_double(ss) / np1) / np1;
-                }
-                static_cast<double*>(a.out)[g] = a.op == AQG_RED_STDDEV ? sqrt(d) : d;
-            } break;
-            case AQG_RED_MIN: case AQG_RED_MAX: {
-                bool mx = a.op == AQG_RED_MAX;
-                switch (a.dt) {
-                case AQG_INT8: store_minmax<int8_t>(a.out, g, v0, mx); break;
-                case AQG_INT16: store_minmax<int16_t>(a.out, g, v0, mx); break;
-                case AQG_INT32: store_minmax<int32_t>(a.out, g, v0, mx); break;
-                case AQG_INT64: store_minmax<int64_t>(a.out, g, v0, mx); break;
-                case AQG_UINT8: store_minmax<uint8_t>(a.out, g, v0, mx); break;
-                case AQG_UINT16: store_minmax<uint16_t>(a.out, g, v0, mx); break;
-                case AQG_UINT32: store_minmax<uint32_t>(a.out, g, v0, mx); break;
-                case AQG_UINT64: store_minmax<uint64_t>(a.out, g, v0, mx); break;
-                case AQG_FLOAT: store_minmax<float>(a.out, g, v0, mx); break;
-                default: store_minmax<double>(a.out, g, v0, mx); break;
-                }
-            } break;
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < c; j += 512) {
+            const uint32_t fr = sp.first[b + j], r = fr - lo;
+            const uint32_t rank = wp[r >> 5] + __popc(bm[r >> 5] & ((1u << (r & 31)) - 1u));
+            sfirst[rank] = fr;
+            scount[rank] = has_count ? sp.count[b + j] : 0;
+            if (!wide) skey[rank] = sp.key[b + j];
+            for (int a = 0; a < nacc; ++a) sacc[(size_t)a * C + rank] = sp.acc[a][b + j];
+        }
+        __syncthreads();
+        if (k32) {      // wide tuples of 4-byte columns: the key loads of a record issued together (emit_record's run one after the other)
+            for (uint32_t i = threadIdx.x; i < c; i += 512) {
+                const uint32_t row = sfirst[i], g = b + i;
+                uint32_t kv[MAXKEYS];
+#pragma unroll
+                for (int k = 0; k < MAXKEYS; ++k) kv[k] = k < es.nkeys ? static_cast<const uint32_t*>(es.key_col[k])[row] : 0;
+#pragma unroll
+                for (int k = 0; k < MAXKEYS; ++k) if (k < es.nkeys) static_cast<uint32_t*>(es.key_out[k])[g] = kv[k];
+                emit_record<false>(lt, i, g, es, 0);
             }
+        } else {
+            for (uint32_t i = threadIdx.x; i < c; i += 512) emit_record(lt, i, b + i, es, wide ? (uint64_t)sfirst[i] : skey[i]);
         }
+        __syncthreads();
     }
 }
 
@@ -1087,7 +1158,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     // more than ~1.6e7 groups expected out of a partition plan: the records are ORDERED (aqg_sorted_tail) instead of ranked through a
     // bitmap over the rows and gathered (h2o Q10, 1e9 groups: that tail took 219 of 317 ms and fetched 900 GB)
     static const uint32_t sorted_min = getenv("AQG_SORTED_TAIL_MIN") ? (uint32_t)atoi(getenv("AQG_SORTED_TAIL_MIN")) : (1u << 24);
-    const bool sorted_tail = (use_part || use_wpart) && hint >= sorted_min && n > 8192;
+    const bool sorted_tail = (use_part || use_wpart) && hint >= sorted_min && aqg_sorted_tail_plan(n, as.nacc, ks.wide != 0, nullptr);
     // ---- workspace ----------------------------------------------------------------------------
     size_t slots = (size_t)gcap + 1;
     uint32_t stride = 16;
@@ -1103,7 +1174,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     else if (p2_parts) part_need = aqg_partition2_ws_bytes(ctx, ks, n, as, p2_parts) + 65536;
     else if (use_part) part_need = aqg_partition_ws_bytes(n, ks.total_bytes <= 4 ? 4 : 8, as, pbits) + 65536;
     // (the partition buffers are dead once the record table is written: the ordering pass takes their place in the arena)
-    const size_t sort_need = sorted_tail ? aqg_sorted_tail_ws_bytes(gcap, stride, as.nacc, ks.wide != 0) : 0;
+    const size_t sort_need = sorted_tail ? aqg_sorted_tail_ws_bytes(gcap, n, as.nacc, ks.wide != 0) : 0;
     need += part_need > sort_need ? part_need : sort_need;
     AQG_TRY(aqg_ws_reset(ctx));
     AQG_TRY(aqg_ws_ensure(ctx, need));
@@ -1115,7 +1186,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     {
         unsigned char* base = nullptr;
         AQG_TRY(aqg_ws_get(ctx, slots * stride, &base));
-        const bool records = use_part || use_wpart || hint > (1u << 17);
+        const bool records = (use_part || use_wpart || hint > (1u << 17)) && !sorted_tail;   // (the ordering pass moves column planes)
         if (records) {
             gt.kb = base; gt.fb = base + 8; gt.cb = base + 12; gt.ab = base + 16;
             gt.kst = gt.fst = gt.cst = gt.ast = stride; gt.astep = 8;
@@ -1282,10 +1353,9 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         }
         AQG_TRY(aqg_check_launch(ctx, "first_rows_kernel"));
     }
-    GTable gt_emit = gt;
+    SortedParts sparts;
     if (sorted_tail && G) {
-        AQG_TRY(aqg_sorted_tail(ctx, gt, G, n, as.nacc, ks.wide != 0, &gt_emit));
-        gt_emit.flags = gt.flags;
+        AQG_TRY(aqg_sorted_tail(ctx, gt, G, n, as.nacc, ks.wide != 0, &sparts));
     } else if (defer || G) {
         if (small_rank) {
             hipLaunchKernelGGL(rank_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, gt, occ, gid_of_occ, slot_gid);
@@ -1322,14 +1392,20 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(dev_realloc(ctx, &h->results[j], &h->cap_results[j], gcapn * 16));
         es.agg[j].out = h->results[j];
     }
-    if (defer || G) {
+    if (sorted_tail && G) {
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&sorted_emit_kernel), sparts.lds));
+        const unsigned per_cu = sparts.lds <= 80 * 1024 ? 2 : 1;
+        const unsigned sg = sparts.nparts < 4u * per_cu * ctx->num_cu ? sparts.nparts : 4u * per_cu * ctx->num_cu;
+        hipLaunchKernelGGL(sorted_emit_kernel, dim3(sg), dim3(512), sparts.lds, ctx->stream, sparts, G, n, as.nacc, (int)gt.has_count, (int)(ks.wide != 0), es, gt.flags);
+        AQG_TRY(aqg_check_launch(ctx, "sorted_emit_kernel"));
+    } else if (defer || G) {
         unsigned eg = aqg_grid(ctx, defer ? gupper : G, 256, 1, 8);
         uint32_t* order = nullptr;
         if (ordered_emit && G >= (1u << 20)) {
             AQG_TRY(aqg_ws_get(ctx, slots, &order));
             hipLaunchKernelGGL(emit_order_kernel, dim3(eg), dim3(256), 0, ctx->stream, (const uint32_t*)gid_of_occ, G, order);
         }
-        hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt_emit, (const uint32_t*)occ, (const uint32_t*)gid_of_occ, es, (const uint32_t*)order, defer ? 4096u : 0u);
+        hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt, (const uint32_t*)occ, (const uint32_t*)gid_of_occ, es, (const uint32_t*)order, defer ? 4096u : 0u);
         AQG_TRY(aqg_check_launch(ctx, "emit_kernel"));
     }
     if (defer) {

@@ -609,9 +609,9 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
 
 // ==== tuples wider than 8 bytes (h2o Q10: six int32 keys, nearly every row its own group) ==============================================
 // Round 1 sent such rows straight to an HBM table with device-scope atomics (0.54 s per 1e9 rows).  Here the rows are partitioned on a
-// 32-bit HASH of the tuple (pw_hash: one pass over the key columns), through up to three levels of the same tile scatter (128 x 64 x 64
-// partitions; every level: a per-segment histogram pass over the hash plane, a scan, the scatter), until a partition has at most
-// ~2400 ROWS.  The key columns travel as ordinary dword planes.  pw_agg then loads a whole partition into LDS -- keys, row ids, values --
+// 32-bit HASH of the tuple (pw_hash: one pass over the key columns), through up to three levels of the same tile scatter (a first level
+// of <= 128 bins, lower levels of 64 or 128; every level: a per-segment histogram pass over the hash plane, a scan, the scatter), until
+// a partition has ~1000 ROWS (pw_plan).  The key columns travel as ordinary dword planes.  pw_agg then loads a whole partition into LDS
 // and groups it there: an open-addressing table of representative row indices, tuples compared LDS to LDS, accumulators indexed by
 // the representative.  The record's key word is the group's first row: emit fetches the key columns through it (the wide-tuple
 // convention of groupby.hip).  Sized by rows, not by groups: a tuple that dominates the input overflows its partition and the call
@@ -670,17 +670,18 @@ struct WideIn {
     const void* vcol[MAXACC]; int vesz[MAXACC];   // partitioned value arrays per accumulator (null: the row id)
 };
 constexpr uint32_t WEMPTY = 0xFFFFu;
-// one workgroup per partition (grid-stride); R = row capacity.  LDS: keys u32[nkd][R] | rows u32[R] | first u32[R] | count u32[R] |
-// acc u64[NACC][R] | vals u64[NACC][R] | table u16[2R] | rep u16[R]
-template <int NACC>
-__global__ void __launch_bounds__(1024) pw_agg_kernel(WideIn in, AccSpec as, AggOps ops, const uint32_t* __restrict__ pstart, uint32_t nparts, uint32_t ntotal,
-                                                      uint32_t R, int need_count, GTable out, uint32_t out_cap) {
+// one workgroup of NT threads per partition (grid-stride); R <= 3 NT = row capacity.  LDS: acc u64[NACC][R] | keys u32[nkd][R] |
+// first u32[R] | count u32[R] | table u16[2R] | rep u16[R]; a row's id and values stay in the registers of the thread that loaded it.
+// The phases are separated by barriers and each is a chain of LDS round trips, so the kernel lives on workgroups per CU: the plan
+// sizes a partition for three workgroups of 512 threads where the level structure allows it (pw_plan).
+template <int NACC, int NT>
+__global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in, AccSpec as, AggOps ops, const uint32_t* __restrict__ pstart, uint32_t nparts, uint32_t ntotal,
+                                                                        uint32_t R, int need_count, GTable out, uint32_t out_cap) {
+    constexpr int RPT = 3;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint64_t* lacc = reinterpret_cast<uint64_t*>(smem_raw);                    // [NACC][R]
-    uint64_t* lval = lacc + (size_t)NACC * R;                                  // [NACC][R]
-    uint32_t* lkey = reinterpret_cast<uint32_t*>(lval + (size_t)NACC * R);     // [nkd][R]
-    uint32_t* lrow = lkey + (size_t)in.nkd * R;
-    uint32_t* lfirst = lrow + R;
+    uint32_t* lkey = reinterpret_cast<uint32_t*>(lacc + (size_t)NACC * R);     // [nkd][R]
+    uint32_t* lfirst = lkey + (size_t)in.nkd * R;
     uint32_t* lcount = lfirst + R;
     uint16_t* table = reinterpret_cast<uint16_t*>(lcount + R);                 // [2R]
     uint16_t* rep = table + 2 * R;                                             // [R]
@@ -691,20 +692,27 @@ __global__ void __launch_bounds__(1024) pw_agg_kernel(WideIn in, AccSpec as, Agg
         const uint32_t m = e - b;
         if (!m) continue;
         if (m > R) { if (threadIdx.x == 0) out.flags[0] = 1; continue; }        // a partition larger than LDS holds: the host falls back
-        for (uint32_t i = threadIdx.x; i < m; i += 1024) {
-            for (int k = 0; k < in.nkd; ++k) lkey[(size_t)k * R + i] = in.kplane[k][b + i];
-            lrow[i] = in.rows[b + i];
-            lfirst[i] = NOROW; lcount[i] = 0;
-            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
-                lacc[(size_t)a * R + i] = acc_init(as.kind[a]);
-                lval[(size_t)a * R + i] = !in.vcol[a] ? (uint64_t)in.rows[b + i] : in.vesz[a] == 4 ? (uint64_t)static_cast<const uint32_t*>(in.vcol[a])[b + i] : static_cast<const uint64_t*>(in.vcol[a])[b + i];
+        uint32_t myrow[RPT];
+        uint64_t myval[NACC > 0 ? NACC : 1][RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const uint32_t i = threadIdx.x + q * NT;
+            myrow[q] = 0;
+            if (i < m) {
+                for (int k = 0; k < in.nkd; ++k) lkey[(size_t)k * R + i] = in.kplane[k][b + i];
+                myrow[q] = in.rows[b + i];
+                lfirst[i] = NOROW; lcount[i] = 0;
+                _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                    lacc[(size_t)a * R + i] = acc_init(as.kind[a]);
+                    myval[a][q] = !in.vcol[a] ? (uint64_t)myrow[q] : in.vesz[a] == 4 ? (uint64_t)static_cast<const uint32_t*>(in.vcol[a])[b + i] : static_cast<const uint64_t*>(in.vcol[a])[b + i];
+                }
             }
         }
-        for (uint32_t s = threadIdx.x; s < T; s += 1024) table[s] = (uint16_t)WEMPTY;
+        for (uint32_t s = threadIdx.x; s < T; s += NT) table[s] = (uint16_t)WEMPTY;
         if (threadIdx.x == 0) { lemit = 0; ngrp = 0; }
         __syncthreads();
         // representative of every row: the first row index that claimed the slot of an equal tuple
-        for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+        for (uint32_t i = threadIdx.x; i < m; i += NT) {
             uint32_t h = 0x9E3779B1u;
             for (int k = 0; k < in.nkd; ++k) h = (h ^ lkey[(size_t)k * R + i]) * 0x85EBCA6Bu;
             uint32_t s = __umulhi(h ^ (h >> 15), T);
@@ -732,13 +740,18 @@ __global__ void __launch_bounds__(1024) pw_agg_kernel(WideIn in, AccSpec as, Agg
             rep[i] = (uint16_t)r;
         }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const uint32_t i = threadIdx.x + q * NT;
+            if (i >= m) continue;
             const uint32_t r = rep[i];
-            atomicMin(&lfirst[r], lrow[i]);
+            mine += r == i;                                                     // groups = rows that represent themselves
+            atomicMin(&lfirst[r], myrow[q]);
             if (need_count) atomicAdd(&lcount[r], 1u);
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
                 uint64_t* acc = lacc + (size_t)a * R + r;
-                const uint64_t x = lval[(size_t)a * R + i];
+                const uint64_t x = myval[a][q];
                 switch (ops.opc[a]) {
                 case OPC_ADDI_I32: atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(long long)(int32_t)(uint32_t)x); break;
                 case OPC_ADDI_U32: atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)(uint32_t)x); break;
@@ -748,16 +761,12 @@ __global__ void __launch_bounds__(1024) pw_agg_kernel(WideIn in, AccSpec as, Agg
                 }
             }
         }
-        __syncthreads();
-        // groups = rows that represent themselves
-        uint32_t mine = 0;
-        for (uint32_t i = threadIdx.x; i < m; i += 1024) mine += rep[i] == i;
         mine = wave_reduce(mine, OpAdd{});
         if (lane_id() == 0 && mine) atomicAdd(&ngrp, mine);
         __syncthreads();
         if (threadIdx.x == 0) gbase = atomicAdd(&out.flags[1], ngrp);
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < m; i += 1024) {
+        for (uint32_t i = threadIdx.x; i < m; i += NT) {
             if (rep[i] != i) continue;
             const uint32_t g = gbase + atomicAdd(&lemit, 1u);
             if (g >= out_cap) { out.flags[0] = 1; continue; }
@@ -774,62 +783,10 @@ __global__ void __launch_bounds__(1024) pw_agg_kernel(WideIn in, AccSpec as, Agg
 // ==== ordering a huge group table (G ~ N: h2o Q10) ========================================================================================
 // Group ids are ranks of first rows.  For <= 1e7 groups groupby.hip ranks through a bitmap over the rows and gathers the records in id
 // order; at 1e9 groups those gathers fetch 600 GB.  Here the RECORDS are ordered instead, with the same tile scatter keyed on the first
-// row through an ORDER-PRESERVING bin f = umulhi(first_row, M), M = floor(4096 * 2^32 / rows): two levels of 64 bins leave 4096
+// row through an ORDER-PRESERVING bin f = umulhi(first_row, M), M = floor(P * 2^32 / rows): up to three levels of <= 64 bins leave P
 // partitions, partition p holding exactly the groups whose first rows fall into its row interval -- so its start is the id of its first
-// group, and the rank inside it comes from a bitmap of the interval in LDS.  pn_rank_write writes the records, in id order, as a record
-// table emit_kernel then walks sequentially.
-struct SortedIn {
-    const uint32_t* first; const uint32_t* count; const uint64_t* key; const uint64_t* acc[MAXACC];
-    int nacc, has_count, wide;
-};
-__global__ void __launch_bounds__(1024) pn_rank_write_kernel(SortedIn in, const uint32_t* __restrict__ pstart, uint32_t nparts, uint32_t G, uint32_t M, uint32_t nrows_total,
-                                                             uint32_t maxwords, GTable out) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    uint32_t* bm = reinterpret_cast<uint32_t*>(smem_raw);          // [maxwords] bitmap of the partition's row interval
-    uint32_t* bs = bm + maxwords;                                  // [maxwords / 8 + 1] set bits before every block of eight words
-    __shared__ uint32_t wsum[16];
-    for (uint32_t part = blockIdx.x; part < nparts; part += gridDim.x) {
-        const uint32_t b = pstart[part], e = part + 1 < nparts ? pstart[part + 1] : G;
-        if (b >= e) continue;
-        const uint64_t lo64 = (((uint64_t)part << 32) + M - 1) / M, hi64 = ((((uint64_t)part + 1) << 32) + M - 1) / M;
-        const uint32_t lo = (uint32_t)lo64, hi = hi64 < nrows_total ? (uint32_t)hi64 : nrows_total;
-        const uint32_t nw = (hi - lo + 31) / 32, nblk = (nw + 7) / 8;
-        if (nw > maxwords) { if (threadIdx.x == 0) out.flags[0] = 1; continue; }
-        for (uint32_t w = threadIdx.x; w < nblk * 8; w += 1024) bm[w] = 0;
-        __syncthreads();
-        for (uint32_t j = b + threadIdx.x; j < e; j += 1024) { const uint32_t r = in.first[j] - lo; atomicOr(&bm[r >> 5], 1u << (r & 31)); }
-        __syncthreads();
-        // exclusive prefix of the set bits per block of eight words (nblk <= 4096: four blocks per thread)
-        uint32_t c[4], s4 = 0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t blk = threadIdx.x * 4 + k;
-            uint32_t t = 0;
-            if (blk < nblk) for (int q = 0; q < 8; ++q) t += __popc(bm[blk * 8 + q]);
-            c[k] = t; s4 += t;
-        }
-        const uint32_t incl = wave_scan_incl(s4, OpAdd{}, lane_id());
-        if (lane_id() == 63) wsum[wave_id()] = incl;
-        __syncthreads();
-        uint32_t base = incl - s4;
-        for (int w = 0; w < wave_id(); ++w) base += wsum[w];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const uint32_t blk = threadIdx.x * 4 + k; if (blk < nblk) bs[blk] = base; base += c[k]; }
-        __syncthreads();
-        for (uint32_t j = b + threadIdx.x; j < e; j += 1024) {
-            const uint32_t fr = in.first[j], r = fr - lo, w = r >> 5;
-            uint32_t rank = bs[w >> 3] + __popc(bm[w] & ((1u << (r & 31)) - 1u));
-            for (uint32_t q = w & ~7u; q < w; ++q) rank += __popc(bm[q]);
-            const uint32_t g = b + rank;
-            *out.key_p(g) = in.wide ? (uint64_t)fr : in.key[j];
-            *out.first_p(g) = fr;
-            *out.count_p(g) = in.has_count ? in.count[j] : 0;
-            for (int a = 0; a < in.nacc; ++a) *out.acc_p(a, g) = in.acc[a][j];
-        }
-        __syncthreads();
-    }
-}
-
+// group -- and few enough of them that groupby.hip's sorted_emit_kernel ranks a partition inside LDS (bitmap of the interval) and
+// emits the final columns from there.  (host side: aqg_sorted_tail below)
 size_t part_val_bytes(int dt) { return aqg_dtype_size(dt) <= 4 ? 4 : 8; }   // narrow values travel widened to one dword
 constexpr size_t AGG_LDS = 150 * 1024;
 constexpr uint32_t LF1000 = 500;    // load factor of the key table
@@ -1131,27 +1088,40 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
 }
 
 // ---- wide tuples: host ----------------------------------------------------------------------------------------------------------------
-struct WidePlan { uint32_t R, P, B1; int L, nkd; bool ok; };
+struct WidePlan { uint32_t R, P, B1; int L, nkd, low[3], nt; size_t lds; bool ok; };   // low[l]: bits of level l + 1 (the levels below the first)
+static size_t pw_row_lds(int nkd, int nacc) { return 4 * (size_t)nkd + 4 + 4 + 8 * (size_t)nacc + 4 + 2; }
 static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n) {
-    WidePlan w;
-    memset(&w, 0, sizeof w);
-    for (int k = 0; k < ks.nkeys; ++k) w.nkd += aqg_dtype_size(ks.dt[k]) <= 4 ? 1 : 2;
-    const size_t per_row = 4 * (size_t)w.nkd + 4 + 4 + 4 + 16 * (size_t)as.nacc + 4 + 2;
-    uint32_t R = (uint32_t)((AGG_LDS - 64) / per_row);
-    if (R > 60000) R = 60000;
-    R &= ~7u;
-    double mu = (double)R;
-    for (int it = 0; it < 8; ++it) mu = (double)R - 5.0 * sqrt(mu);
-    if (mu < 64 || w.nkd > 2 * MAXKEYS) return w;
-    const uint64_t P = (uint64_t)((double)n / mu) + 1;
-    w.R = R;
-    if (P <= 128) { w.L = 1; w.B1 = (uint32_t)P; }
-    else if (P <= 128 * 64) { w.L = 2; w.B1 = (uint32_t)((P + 63) / 64); }
-    else if (P <= 128 * 4096) { w.L = 3; w.B1 = (uint32_t)((P + 4095) / 4096); }
-    else return w;
-    w.P = w.B1 << (6 * (w.L - 1));
-    w.ok = true;
-    return w;
+    WidePlan best;
+    memset(&best, 0, sizeof best);
+    int nkd = 0;
+    for (int k = 0; k < ks.nkeys; ++k) nkd += aqg_dtype_size(ks.dt[k]) <= 4 ? 1 : 2;
+    if (nkd > 2 * MAXKEYS) return best;
+    // workgroups per CU: three of 512 threads, two of 1024, one of 1024 -- the first that needs no more levels than the last
+    const struct { size_t budget; int nt; } shapes[3] = {{52 * 1024, 512}, {78 * 1024, 1024}, {AGG_LDS, 1024}};
+    for (int si = 2; si >= 0; --si) {
+        WidePlan w;
+        memset(&w, 0, sizeof w);
+        w.nkd = nkd; w.nt = shapes[si].nt;
+        uint32_t R = (uint32_t)((shapes[si].budget - 64) / pw_row_lds(nkd, as.nacc));
+        if (R > 3u * (uint32_t)w.nt) R = 3u * (uint32_t)w.nt;
+        R &= ~7u;
+        double mu = (double)R;
+        for (int it = 0; it < 8; ++it) mu = (double)R - 5.0 * sqrt(mu);
+        if (mu < 64) continue;
+        const uint64_t P = (uint64_t)((double)n / mu) + 1;
+        w.R = R;
+        w.lds = (size_t)R * pw_row_lds(nkd, as.nacc) + 64;
+        int lowsum = 0;
+        if (P <= 128) w.L = 1;
+        else if (P <= 128 * 128) { w.L = 2; w.low[0] = P <= 128 * 64 ? 6 : 7; lowsum = w.low[0]; }
+        else if (P <= 128 * 128 * 128) { w.L = 3; w.low[0] = P <= 128 * 64 * 128 ? 6 : 7; w.low[1] = P <= 128 * 64 * 64 ? 6 : 7; lowsum = w.low[0] + w.low[1]; }
+        else continue;
+        w.B1 = (uint32_t)((P + ((uint64_t)1 << lowsum) - 1) >> lowsum);
+        w.P = w.B1 << lowsum;
+        w.ok = true;
+        if (!best.ok || w.L <= best.L) best = w;
+    }
+    return best;
 }
 bool aqg_partitionw_applies(const KeySpec& ks, const AccSpec& as, uint32_t n) { return ks.wide && pw_plan(ks, as, n).ok; }
 
@@ -1167,7 +1137,7 @@ size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
 
 int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap) {
     const WidePlan w = pw_plan(ks, as, n);
-    if (!w.ok) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "wide-tuple partitioned group-by: the input does not fit 128 x 64 x 64 partitions");
+    if (!w.ok) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "wide-tuple partitioned group-by: the input does not fit 128 x 128 x 128 partitions");
     ValCols vc;
     p1_val_cols(as, &vc);
     const unsigned g4 = aqg_grid(ctx, n, 256, 4, 16);
@@ -1251,7 +1221,9 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     const Set* from = nullptr;
     int to = 0;
     for (int l = 1; l <= w.L; ++l) {
-        const uint32_t nb = l == 1 ? w.B1 : 64u, shift = 6u * (uint32_t)(w.L - l), mask = l == 1 ? 0xFFFFFFFFu : 63u;
+        uint32_t shift = 0;
+        for (int j = l; j < w.L; ++j) shift += (uint32_t)w.low[j - 1];          // bits of the levels below this one
+        const uint32_t nb = l == 1 ? w.B1 : 1u << w.low[l - 2], mask = l == 1 ? 0xFFFFFFFFu : nb - 1;
         const uint32_t* keys = l == 1 ? h32 : from->hash;
         const unsigned tiles = (unsigned)((uint64_t)n / P2_PT) + nseg + 1;
         hipLaunchKernelGGL(pn_tiles_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)seg, nseg, (uint32_t)P2_PT, tp);
@@ -1291,48 +1263,78 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         }
         ops.opc[a] = opc;
     }
-    const size_t lds = (size_t)w.R * (4 * (size_t)w.nkd + 12 + 16 * (size_t)as.nacc + 6) + 64;
-    const unsigned grid = nseg < (unsigned)ctx->num_cu ? nseg : (unsigned)ctx->num_cu;
+    const size_t lds = w.lds;
+    const unsigned per_cu = w.nt == 512 ? 3u : lds <= 78 * 1024 ? 2u : 1u;
+    const unsigned grid = nseg < per_cu * (unsigned)ctx->num_cu ? nseg : per_cu * (unsigned)ctx->num_cu;
     auto launch = [&](auto kern) -> int {
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
         aqg_kernel_timer_begin(ctx);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, ctx->stream, in, as, ops, (const uint32_t*)seg, nseg, n, w.R, need_count, out, out_cap);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(w.nt), lds, ctx->stream, in, as, ops, (const uint32_t*)seg, nseg, n, w.R, need_count, out, out_cap);
         aqg_kernel_timer_end(ctx);
         return aqg_check_launch(ctx, "pw_agg_kernel");
     };
+    auto pick = [&](auto nacc) -> int {
+        constexpr int N = decltype(nacc)::value;
+        return w.nt == 512 ? launch(&pw_agg_kernel<N, 512>) : launch(&pw_agg_kernel<N, 1024>);
+    };
     switch (as.nacc) {
-    case 0: return launch(&pw_agg_kernel<0>);
-    case 1: return launch(&pw_agg_kernel<1>);
-    case 2: return launch(&pw_agg_kernel<2>);
-    case 3: return launch(&pw_agg_kernel<3>);
-    case 4: return launch(&pw_agg_kernel<4>);
+    case 0: return pick(std::integral_constant<int, 0>{});
+    case 1: return pick(std::integral_constant<int, 1>{});
+    case 2: return pick(std::integral_constant<int, 2>{});
+    case 3: return pick(std::integral_constant<int, 3>{});
+    case 4: return pick(std::integral_constant<int, 4>{});
     default: return aqg_fail(ctx, AQG_ERR_OVERFLOW, "wide-tuple partitioned group-by: at most 4 accumulators");
     }
 }
 
 // ---- ordering a huge group table: host ------------------------------------------------------------------------------------------------
-size_t aqg_sorted_tail_ws_bytes(uint32_t gcap, uint32_t stride, int nacc, bool wide) {
-    const size_t per = 4 + 2 * (4 + 4 + (wide ? 0 : 8) + 8 * (size_t)nacc) + stride;      // first rows; two plane sets; the ordered table
-    return ((size_t)gcap + 64) * per + 256 * (16 + 4 * MAXACC) + (size_t)5 * 4200 * 4 + 65536;
+// LDS of sorted_emit_kernel per record: key (packed keys only) | first | count | accumulators, plus two bits per row of the interval
+static size_t sorted_rec_bytes(int nacc, bool wide) { return (wide ? 0 : 8) + 8 + 8 * (size_t)nacc; }
+bool aqg_sorted_tail_plan(uint32_t n_rows, int nacc, bool wide, SortedPlan* out) {
+    if (n_rows <= 8192) return false;
+    SortedPlan best;
+    memset(&best, 0, sizeof best);
+    for (size_t budget : {(size_t)64 * 1024, (size_t)150 * 1024}) {
+        uint32_t iv = (uint32_t)((budget - 1024) / (sorted_rec_bytes(nacc, wide) + 1)) & ~31u;   // rows (= records at most) one partition may span
+        if (iv > 16384) iv = 16384;                                   // one thread per bitmap word, 512 threads
+        if (iv < 64) continue;
+        uint32_t bits = 1;
+        while (bits <= 18 && ((uint64_t)n_rows + ((uint64_t)1 << bits) - 1) / ((uint64_t)1 << bits) + 4 > iv) ++bits;
+        if (bits > 18) continue;
+        const uint32_t levels = (bits + 5) / 6;
+        while (bits < 6 * levels && ((uint64_t)1 << (bits + 1)) <= n_rows / 64) ++bits;   // the levels are paid for: use their bins
+        if (best.levels && best.levels <= levels) continue;
+        best.levels = levels; best.bits = bits; best.cap = iv;
+        best.M = (uint32_t)((((uint64_t)1 << bits) << 32) / n_rows);
+        best.lds = (size_t)iv * sorted_rec_bytes(nacc, wide) + 2 * ((size_t)iv / 32 + 8) * 4 + 64;
+    }
+    if (!best.levels) return false;
+    if (out) *out = best;
+    return true;
 }
-// records 0 .. G-1 of `gt` (AoS: key | first | count | acc...) -> `sorted` (same layout, ordered by first row = dense group id)
-int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows, int nacc, bool wide, GTable* sorted) {
-    if (G == 0) return AQG_OK;
-    if (n_rows <= 8192) return aqg_fail(ctx, AQG_ERR_ARG, "ordered group table: too few rows");
-    const uint32_t stride_dw = gt.kst / 4;
-    const uint32_t PP = 4096, M = (uint32_t)((((uint64_t)PP) << 32) / n_rows);
-    uint32_t* fr0;
-    AQG_TRY(aqg_ws_get(ctx, (size_t)G + 64, &fr0));
-    hipLaunchKernelGGL(pn_gather_strided_kernel, dim3(aqg_grid(ctx, G, 256, 4, 16)), dim3(256), 0, ctx->stream, reinterpret_cast<const uint32_t*>(gt.fb), stride_dw, G, fr0);
-    struct Set { uint32_t* first; uint32_t* count; uint64_t* key; uint64_t* acc[MAXACC]; } set[2];
+size_t aqg_sorted_tail_ws_bytes(uint32_t gcap, uint32_t n_rows, int nacc, bool wide) {
+    SortedPlan sp;
+    if (!aqg_sorted_tail_plan(n_rows, nacc, wide, &sp)) return 0;
+    const size_t per = 2 * (4 + 4 + (wide ? 0 : 8) + 8 * (size_t)nacc);                    // two plane sets
+    return ((size_t)gcap + 64) * per + 256 * (16 + 4 * MAXACC) + (size_t)5 * (((size_t)1 << sp.bits) + 64) * 4 + 65536;
+}
+// records 0 .. G-1 of `gt` (column layout: keys | first rows | counts | accumulators) -> the same planes partitioned by first row
+int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows, int nacc, bool wide, SortedParts* out) {
+    SortedPlan sp;
+    if (!aqg_sorted_tail_plan(n_rows, nacc, wide, &sp)) return aqg_fail(ctx, AQG_ERR_ARG, "ordered group table: no plan for this shape");
+    if (gt.fst != 4 || gt.cst != 4 || gt.kst != 8 || gt.ast != 8) return aqg_fail(ctx, AQG_ERR_ARG, "ordered group table: column layout expected");
+    const uint32_t PP = 1u << sp.bits, M = sp.M;
+    struct Set { uint32_t* first; uint32_t* count; uint64_t* key; uint64_t* acc[MAXACC]; } set[3];
+    memset(set, 0, sizeof set);
+    set[2].first = reinterpret_cast<uint32_t*>(gt.fb); set[2].count = reinterpret_cast<uint32_t*>(gt.cb); set[2].key = reinterpret_cast<uint64_t*>(gt.kb);
+    for (int a = 0; a < nacc; ++a) set[2].acc[a] = reinterpret_cast<uint64_t*>(gt.ab + (size_t)a * gt.astep);
     for (int i = 0; i < 2; ++i) {
         AQG_TRY(aqg_ws_get(ctx, (size_t)G + 64, &set[i].first));
         AQG_TRY(aqg_ws_get(ctx, (size_t)G + 64, &set[i].count));
-        set[i].key = nullptr;
         if (!wide) AQG_TRY(aqg_ws_get(ctx, (size_t)G + 64, &set[i].key));
         for (int a = 0; a < nacc; ++a) AQG_TRY(aqg_ws_get(ctx, (size_t)G + 64, &set[i].acc[a]));
     }
-    auto planes = [&](int level, const Set* from, const Set& to) {
+    auto planes = [&](const Set& from, const Set& to) {
         Planes pl;
         memset(&pl, 0, sizeof pl);
         auto add = [&](const void* s_, int sstride, int soff, void* d, int dstride, int doff) {
@@ -1340,17 +1342,10 @@ int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows,
             Q.kind = PL_LOAD; Q.src = static_cast<const uint32_t*>(s_); Q.src_stride_dw = sstride; Q.src_off_dw = soff;
             Q.dst = static_cast<uint32_t*>(d); Q.dst_stride_dw = dstride; Q.dst_off_dw = doff;
         };
-        if (level == 1) {                                                     // fields of the AoS records
-            add(fr0, 1, 0, to.first, 1, 0);
-            add(gt.cb, (int)stride_dw, 0, to.count, 1, 0);
-            if (!wide) { add(gt.kb, (int)stride_dw, 0, to.key, 2, 0); add(gt.kb, (int)stride_dw, 1, to.key, 2, 1); }
-            for (int a = 0; a < nacc; ++a) { add(gt.ab + (size_t)a * gt.astep, (int)stride_dw, 0, to.acc[a], 2, 0); add(gt.ab + (size_t)a * gt.astep, (int)stride_dw, 1, to.acc[a], 2, 1); }
-        } else {
-            add(from->first, 1, 0, to.first, 1, 0);
-            add(from->count, 1, 0, to.count, 1, 0);
-            if (!wide) { add(from->key, 2, 0, to.key, 2, 0); add(from->key, 2, 1, to.key, 2, 1); }
-            for (int a = 0; a < nacc; ++a) { add(from->acc[a], 2, 0, to.acc[a], 2, 0); add(from->acc[a], 2, 1, to.acc[a], 2, 1); }
-        }
+        add(from.first, 1, 0, to.first, 1, 0);
+        add(from.count, 1, 0, to.count, 1, 0);
+        if (!wide) { add(from.key, 2, 0, to.key, 2, 0); add(from.key, 2, 1, to.key, 2, 1); }
+        for (int a = 0; a < nacc; ++a) { add(from.acc[a], 2, 0, to.acc[a], 2, 0); add(from.acc[a], 2, 1, to.acc[a], 2, 1); }
         return pl;
     };
     uint32_t *seg, *tp, *cnt, *cur, *bsum;
@@ -1358,7 +1353,7 @@ int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows,
     AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &tp));
     AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &cnt));
     AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &cur));
-    AQG_TRY(aqg_ws_get(ctx, 64 + 8, &bsum));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)PP / 1024 + 64 + 8, &bsum));
     const uint32_t h0[2] = {0u, G};
     void* st = nullptr;
     AQG_TRY(aqg_host_stage(ctx, 16, &st));
@@ -1367,11 +1362,13 @@ int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows,
     const size_t scat_lds = (size_t)P2_PT * 4;
     AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, true, false>), scat_lds));
     AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, false, false>), scat_lds));
-    uint32_t nseg = 1;
-    const Set* from = nullptr;
-    for (int l = 1; l <= 2; ++l) {
-        const uint32_t nb = 64, shift = l == 1 ? 6u : 0u, mask = l == 1 ? 0xFFFFFFFFu : 63u;
-        const uint32_t* keys = l == 1 ? fr0 : from->first;
+    uint32_t nseg = 1, bits_left = sp.bits;
+    const Set* from = &set[2];
+    for (uint32_t l = 0; l < sp.levels; ++l) {
+        const uint32_t lb = (bits_left + (sp.levels - l) - 1) / (sp.levels - l);       // bits of this level (most significant first)
+        bits_left -= lb;
+        const uint32_t nb = 1u << lb, shift = bits_left, mask = nb - 1;
+        const uint32_t* keys = from->first;
         const unsigned tiles = (unsigned)((uint64_t)G / P2_PT) + nseg + 1;
         hipLaunchKernelGGL(pn_tiles_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)seg, nseg, (uint32_t)P2_PT, tp);
         AQG_HIP(ctx, hipMemsetAsync(cnt, 0, ((size_t)nseg * nb + 1) * 4, ctx->stream));
@@ -1379,31 +1376,18 @@ int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows,
         hipLaunchKernelGGL((pn_level_hist_kernel<P2_TB, P2_TR, false>), dim3(tiles), dim3(P2_TB), 0, ctx->stream, keys, lv, cnt);
         AQG_TRY(aqg_exclusive_scan_u32(ctx, cnt, (uint64_t)nseg * nb + 1, bsum));
         AQG_HIP(ctx, hipMemcpyAsync(cur, cnt, (size_t)nseg * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        const Planes pl = planes(l, from, set[l - 1]);
+        const Set& to = set[l & 1];
+        const Planes pl = planes(*from, to);
         hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, true, false>), dim3(tiles), dim3(P2_TB), scat_lds, ctx->stream, keys, pl, lv);
         hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, false, false>), dim3(nseg), dim3(P2_TB), scat_lds, ctx->stream, keys, pl, lv);
         AQG_TRY(aqg_check_launch(ctx, "ordered group table: level"));
         AQG_HIP(ctx, hipMemcpyAsync(seg, cnt, ((size_t)nseg * nb + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
         nseg *= nb;
-        from = &set[l - 1];
+        from = &to;
     }
-    // the ordered record table
-    unsigned char* base = nullptr;
-    AQG_TRY(aqg_ws_get(ctx, ((size_t)G + 1) * gt.kst, &base));
-    GTable so = gt;
-    so.kb = base; so.fb = base + 8; so.cb = base + 12; so.ab = base + 16;
-    so.cap = 0xFFFFFFFFu;
-    SortedIn in;
-    memset(&in, 0, sizeof in);
-    in.first = from->first; in.count = from->count; in.key = from->key; in.nacc = nacc; in.has_count = gt.has_count; in.wide = wide;
-    for (int a = 0; a < nacc; ++a) in.acc[a] = from->acc[a];
-    const uint32_t interval = (uint32_t)(((uint64_t)1 << 32) / M) + 2;               // rows a partition's interval can span
-    const uint32_t maxwords = ((interval + 31) / 32 + 7) & ~7u;
-    if ((size_t)maxwords * 4 + ((size_t)maxwords / 8 + 1) * 4 > 150 * 1024 || maxwords / 8 > 4096) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "ordered group table: row interval of a partition exceeds LDS");
-    const size_t lds = (size_t)maxwords * 4 + ((size_t)maxwords / 8 + 1) * 4;
-    AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&pn_rank_write_kernel), lds));
-    hipLaunchKernelGGL(pn_rank_write_kernel, dim3(nseg < 4u * ctx->num_cu ? nseg : 4u * ctx->num_cu), dim3(1024), lds, ctx->stream, in, (const uint32_t*)seg, nseg, G, M, n_rows, maxwords, so);
-    AQG_TRY(aqg_check_launch(ctx, "pn_rank_write_kernel"));
-    *sorted = so;
+    memset(out, 0, sizeof *out);
+    out->first = from->first; out->count = from->count; out->key = from->key;
+    for (int a = 0; a < nacc; ++a) out->acc[a] = from->acc[a];
+    out->pstart = seg; out->nparts = nseg; out->M = M; out->cap = sp.cap; out->lds = sp.lds;
     return AQG_OK;
 }

@@ -14,7 +14,14 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
 bool aqg_partitionw_applies(const KeySpec& ks, const AccSpec& as, uint32_t n);
 size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as);
 int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap);
-// ordering a huge group table (more than ~1.6e7 groups): the records ordered by first row with the tile scatter, instead of ranked
-// through a bitmap and gathered
-size_t aqg_sorted_tail_ws_bytes(uint32_t gcap, uint32_t stride, int nacc, bool wide);
-int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows, int nacc, bool wide, GTable* sorted);
+// ordering a huge group table (more than ~1.6e7 groups): the record planes partitioned by first row with the tile scatter (order-preserving
+// bins, up to three levels) until a partition's row interval fits LDS; sorted_emit_kernel (groupby.hip) ranks and emits from there
+struct SortedPlan { uint32_t levels, bits, M, cap; size_t lds; };    // cap: rows (so records at most) of one partition
+struct SortedParts {
+    const uint32_t* first; const uint32_t* count; const uint64_t* key; const uint64_t* acc[MAXACC];
+    const uint32_t* pstart;                                           // [nparts + 1] first group id of every partition
+    uint32_t nparts, M, cap; size_t lds;                              // partition p: first rows in [ceil(p 2^32 / M), ceil((p + 1) 2^32 / M))
+};
+bool aqg_sorted_tail_plan(uint32_t n_rows, int nacc, bool wide, SortedPlan* out);
+size_t aqg_sorted_tail_ws_bytes(uint32_t gcap, uint32_t n_rows, int nacc, bool wide);
+int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows, int nacc, bool wide, SortedParts* out);
