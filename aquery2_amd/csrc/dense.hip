@@ -121,17 +121,51 @@ __device__ inline uint64_t dense_key_word(const KeySpec& ks, const DenseSpec& ds
     return key;
 }
 
-template <int NACC, int BLOCK>
+// NK > 0: exactly NK key columns, all int32 / uint32.  The generic form (NK = 0) walks ks / ds with run-time indices, which keeps those
+// structs in kernel-argument memory: ~20 scalar loads per step INSIDE the loop, and every s_waitcnt lgkmcnt(0) behind one also waits
+// for the LDS atomics in flight, so the next step's global loads start only after the table traffic of this one has drained (h2o Q2:
+// 0.9 vector-memory instructions in flight per SQ where the hashed kernel keeps 4; 54 % of the HBM roofline).  With NK and NACC
+// compile-time, the columns, minima, weights and accumulator kinds are copied into registers before the loop.
+template <int NACC, int BLOCK, int NK = 0>
 __global__ void __launch_bounds__(BLOCK) dense_agg_kernel(KeySpec ks, DenseSpec ds, AccSpec as, GTable gt, uint32_t n, int need_count) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const uint32_t PP = ds.per_pass;
+    const uint32_t* kcol[NK ? NK : 1]; uint32_t kmin[NK ? NK : 1], kmult[NK ? NK : 1], krange[NK ? NK : 1];
+#pragma unroll
+    for (int c = 0; c < NK; ++c) { kcol[c] = static_cast<const uint32_t*>(ks.col[c]); kmin[c] = (uint32_t)ds.kmin[c]; kmult[c] = ds.mult[c]; krange[c] = ds.range[c]; }
+    int akind[NACC ? NACC : 1], adt[NACC ? NACC : 1], asq[NACC ? NACC : 1], apart[NACC ? NACC : 1]; const void* acol[NACC ? NACC : 1];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a) { akind[a] = as.kind[a]; adt[a] = as.dt[a]; asq[a] = as.square[a]; apart[a] = as.part[a]; acol[a] = as.col[a]; }
+    // dense index of four consecutive rows
+    auto idx4 = [&](size_t base, uint32_t (&idx)[4]) {
+        if constexpr (NK > 0) {
+            uint32_t bad[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) idx[j] = 0;
+#pragma unroll
+            for (int c = 0; c < NK; ++c) {
+                const pack<uint32_t, 4> v = *reinterpret_cast<const pack<uint32_t, 4>*>(kcol[c] + base);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const uint32_t d = v.v[j] - kmin[c]; bad[j] |= d >= krange[c]; idx[j] += d * kmult[c]; }   // (mod 2^32: exact for either signedness)
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (bad[j]) idx[j] = 0xFFFFFFFFu;
+        } else dense_idx4(ks, ds, base, idx);
+    };
     uint64_t* lacc = reinterpret_cast<uint64_t*>(smem_raw);                  // [NACC][PP]
     uint32_t* lfirst = reinterpret_cast<uint32_t*>(lacc + (size_t)NACC * PP);   // [PP]
     uint32_t* lcount = lfirst + PP;                                          // [PP] if need_count
+    // A domain whose every index occurs (h2o Q2: all 100 x 100 pairs) is complete after the first ~1e5 rows of a workgroup's span; from
+    // then on the first-row bookkeeping (an LDS read and a compare per row) can only matter for rows below the largest first row
+    // recorded so far.  lseen[0] counts the indices with a first row, lseen[1] bounds those first rows from above (never lowered: a
+    // stale bound is only conservative); rows beyond it skip the bookkeeping.  A domain with holes never gets there and runs as before.
+    __shared__ uint32_t lseen[2];
     const uint32_t nchunk = n >> 2;
     for (uint32_t pass = 0; pass < ds.npass; ++pass) {
         const uint32_t lo = pass * PP;
+        const uint32_t pass_groups = ds.D - lo < PP ? ds.D - lo : PP;
         if (pass) __syncthreads();
+        if (threadIdx.x == 0) { lseen[0] = 0; lseen[1] = 0; }
         for (uint32_t s = threadIdx.x; s < PP; s += BLOCK) {
             lfirst[s] = NOROW;
             if (need_count) lcount[s] = 0;
@@ -146,20 +180,31 @@ __global__ void __launch_bounds__(BLOCK) dense_agg_kernel(KeySpec ks, DenseSpec 
         auto rows = [&](const uint32_t (&idx)[4], const uint64_t (&vals)[NACC ? NACC : 1][4], size_t base) {
             uint32_t f[4], id[4];
             bool in[4];
+            const uint32_t seen = *reinterpret_cast<volatile uint32_t*>(&lseen[0]), bound = *reinterpret_cast<volatile uint32_t*>(&lseen[1]);
+            const bool settled = seen >= pass_groups && (uint32_t)base > bound;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (idx[j] == 0xFFFFFFFFu) gt.flags[3] = 1;           // a value outside the sampled ranges: the host redoes the call with exact ranges
-                id[j] = idx[j] - lo; in[j] = idx[j] != 0xFFFFFFFFu && id[j] < PP; f[j] = lfirst[in[j] ? id[j] : 0];   // four LDS reads in flight
+                id[j] = idx[j] - lo; in[j] = idx[j] != 0xFFFFFFFFu && id[j] < PP;
             }
+            if (!settled) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (in[j] && (uint32_t)base + j < f[j]) atomicMin(&lfirst[id[j]], (uint32_t)base + j);
+                for (int j = 0; j < 4; ++j) f[j] = lfirst[in[j] ? id[j] : 0];   // four LDS reads in flight
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (in[j] && (uint32_t)base + j < f[j]) {
+                        const uint32_t old = atomicMin(&lfirst[id[j]], (uint32_t)base + j);
+                        if (old == NOROW) { atomicMax(&lseen[1], (uint32_t)base + j); __threadfence_block(); atomicAdd(&lseen[0], 1u); }
+                    }
+                }
+            }
             if (need_count) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (in[j]) atomicAdd(&lcount[id[j]], 1u);
             }
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
                 uint64_t* la = lacc + (size_t)a * PP;
-                switch (as.kind[a]) {   // wave-uniform
+                switch (akind[a]) {   // wave-uniform
                 case ACC_ADD_I:
 #pragma unroll
                     for (int j = 0; j < 4; ++j) if (in[j]) atomicAdd(reinterpret_cast<unsigned long long*>(&la[id[j]]), (unsigned long long)vals[a][j]);
@@ -179,17 +224,22 @@ __global__ void __launch_bounds__(BLOCK) dense_agg_kernel(KeySpec ks, DenseSpec 
                 }
             }
         };
-        for (uint32_t st = c_lo + threadIdx.x; st < c_hi; st += BLOCK) {
+        // the H groups of a lane lie BLOCK chunks apart: every load instruction of a wavefront reads 1 KB of consecutive bytes
+        const uint32_t ch_lo = c_lo * H, ch_hi = c_hi * H;
+        for (uint32_t c0 = ch_lo; c0 < ch_hi; c0 += BLOCK * H) {     // (uniform over the workgroup)
             uint32_t idx[H][4];
             uint64_t vals[H][NACC ? NACC : 1][4];
+            bool ok[H];
 #pragma unroll
             for (int h = 0; h < H; ++h) {
-                const size_t base = ((size_t)st * H + h) * 4;
-                dense_idx4(ks, ds, base, idx[h]);
-                _Pragma("unroll") for (int a = 0; a < NACC; ++a) val_operand4(as.dt[a], as.col[a], base, as.kind[a], as.square[a], as.part[a], vals[h][a]);
+                const uint32_t chunk = c0 + h * BLOCK + threadIdx.x;
+                ok[h] = chunk < ch_hi;
+                const size_t base = (size_t)(ok[h] ? chunk : ch_lo) * 4;      // (a lane beyond the span re-reads its first chunk and drops it)
+                idx4(base, idx[h]);
+                _Pragma("unroll") for (int a = 0; a < NACC; ++a) val_operand4(adt[a], acol[a], base, akind[a], asq[a], apart[a], vals[h][a]);
             }
 #pragma unroll
-            for (int h = 0; h < H; ++h) rows(idx[h], vals[h], ((size_t)st * H + h) * 4);
+            for (int h = 0; h < H; ++h) if (ok[h]) rows(idx[h], vals[h], (size_t)(c0 + h * BLOCK + threadIdx.x) * 4);
         }
         if (blockIdx.x == 0) {                                       // chunks behind the last whole step (< H)
             const uint32_t c = nstep * H + threadIdx.x;
@@ -197,8 +247,8 @@ __global__ void __launch_bounds__(BLOCK) dense_agg_kernel(KeySpec ks, DenseSpec 
                 const size_t base = (size_t)c * 4;
                 uint32_t idx[4];
                 uint64_t vals[NACC ? NACC : 1][4];
-                dense_idx4(ks, ds, base, idx);
-                _Pragma("unroll") for (int a = 0; a < NACC; ++a) val_operand4(as.dt[a], as.col[a], base, as.kind[a], as.square[a], as.part[a], vals[a]);
+                idx4(base, idx);
+                _Pragma("unroll") for (int a = 0; a < NACC; ++a) val_operand4(adt[a], acol[a], base, akind[a], asq[a], apart[a], vals[a]);
                 rows(idx, vals, base);
             }
         }
@@ -329,12 +379,28 @@ int aqg_dense_aggregate(aqg_ctx* ctx, const KeySpec& ks, const DenseSpec& ds, co
         aqg_kernel_timer_end(ctx);
         return aqg_check_launch(ctx, "dense_agg_kernel");
     };
+    // key columns all int32 / uint32, at most three of them, up to four accumulators: the register-resident instantiations
+    int nk = ks.nkeys <= 3 && as.nacc >= 1 && as.nacc <= 4 ? ks.nkeys : 0;
+    for (int c = 0; c < ks.nkeys; ++c) if (ks.dt[c] != AQG_INT32 && ks.dt[c] != AQG_UINT32) nk = 0;
+    static const bool nk_off = getenv("AQG_DENSE_GENERIC") != nullptr;
+    if (nk_off) nk = 0;
+    auto by_nk = [&](auto nacc_tag, auto block_tag) -> int {
+        constexpr int N = decltype(nacc_tag)::value, B = decltype(block_tag)::value;
+        switch (nk) {
+        case 1: return launch(&dense_agg_kernel<N, B, 1>);
+        case 2: return launch(&dense_agg_kernel<N, B, 2>);
+        case 3: return launch(&dense_agg_kernel<N, B, 3>);
+        default: return launch(&dense_agg_kernel<N, B, 0>);
+        }
+    };
+    using B1024 = std::integral_constant<int, 1024>;
+    using B512 = std::integral_constant<int, 512>;
     switch (as.nacc) {
     case 0: return launch(&dense_agg_kernel<0, 1024>);
-    case 1: return launch(&dense_agg_kernel<1, 1024>);
-    case 2: return launch(&dense_agg_kernel<2, 1024>);
-    case 3: return launch(&dense_agg_kernel<3, 512>);
-    case 4: return launch(&dense_agg_kernel<4, 512>);
+    case 1: return by_nk(std::integral_constant<int, 1>{}, B1024{});
+    case 2: return by_nk(std::integral_constant<int, 2>{}, B1024{});
+    case 3: return by_nk(std::integral_constant<int, 3>{}, B512{});
+    case 4: return by_nk(std::integral_constant<int, 4>{}, B512{});
     case 5: return launch(&dense_agg_kernel<5, 512>);
     case 6: return launch(&dense_agg_kernel<6, 512>);
     case 7: return launch(&dense_agg_kernel<7, 512>);

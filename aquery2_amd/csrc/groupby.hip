@@ -1250,11 +1250,16 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(aqg_check_launch(ctx, "starjoin_kernel"));
     } else if (n && fast) {
         const size_t lds = (size_t)(lcap + 1) * ((fast_k64 ? 8 : 4) + 8 * (size_t)as.nacc + (plan.need_count ? 4 : 0)) + 64;
-        unsigned bpc = lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : 2;
-        unsigned grid = aqg_grid(ctx, n / 8 + 1, 256, 2, bpc);
+        // the table is sized by the hint, not by the groups that show up: a large one leaves room for few workgroups per CU, and with 256
+        // threads each the LDS round trips of two accumulators per row are no longer hidden (var(v1), 100 groups, hint 1024: two
+        // workgroups = 8 wavefronts per CU ran at 43 % of the HBM roofline).  So the workgroup grows with the table: 32 wavefronts per CU.
+        static const unsigned block_env = getenv("AQG_FAST_BLOCK") ? (unsigned)atoi(getenv("AQG_FAST_BLOCK")) : 0;
+        const unsigned block = block_env ? block_env : lds <= 20 * 1024 ? 256 : lds <= 40 * 1024 ? 512 : 1024;
+        unsigned bpc = lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : lds <= 78 * 1024 ? 2 : 1;
+        unsigned grid = aqg_grid(ctx, n / 8 + 1, block, 2, bpc);
         // (more workgroups than fit the chip cost more in table merges than they gain: 8192 -> +3 %, 32768 -> +30 % on Q1)
         const uint32_t* khi = fast_k64 && !fast_key8 ? static_cast<const uint32_t*>(ks.col[1]) : nullptr;
-        const int rc = aqg_fast_aggregate(ctx, static_cast<const uint32_t*>(ks.col[0]), khi, fast_k64, fast_v8, as.nacc, plan.need_count != 0, fv, gt, n, lcap, lds, grid);
+        const int rc = aqg_fast_aggregate(ctx, static_cast<const uint32_t*>(ks.col[0]), khi, fast_k64, fast_v8, as.nacc, plan.need_count != 0, fv, gt, n, lcap, lds, grid, block);
         AQG_TRY(rc);
     } else if (n && dense) {
         AQG_TRY(aqg_dense_aggregate(ctx, ks, dspec, as, n, plan.need_count, gt));

@@ -17,7 +17,7 @@ namespace {
 // (The generic agg_kernel ran max(v1),min(v2) by id1 at 27 % of the HBM roofline and var(v1) at 18 %; this kernel does SUM at 75 %.)
 
 template <int NV, bool COUNT, bool K64, int VW = 4>
-__global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_hi, FastVals fv, GTable gt, uint32_t n, uint32_t lcap) {
+__global__ void __launch_bounds__(1024) agg32_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ keys_hi, FastVals fv, GTable gt, uint32_t n, uint32_t lcap) {
     using KT = std::conditional_t<K64, uint64_t, uint32_t>;
     constexpr KT EMPTYK = K64 ? (KT)EMPTY64 : (KT)EMPTY32;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -310,11 +310,11 @@ __global__ void __launch_bounds__(256) agg32_kernel(const uint32_t* __restrict__
 } // namespace
 
 int aqg_fast_aggregate(aqg_ctx* ctx, const uint32_t* keys, const uint32_t* keys_hi, bool k64, bool v8, int nacc, bool need_count,
-                       const FastVals& fv, GTable gt, uint32_t n, uint32_t lcap, size_t lds, unsigned grid) {
+                       const FastVals& fv, GTable gt, uint32_t n, uint32_t lcap, size_t lds, unsigned grid, unsigned block) {
     auto launch = [&](auto kern) -> int {
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
         aqg_kernel_timer_begin(ctx);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, ctx->stream, keys, keys_hi, fv, gt, n, lcap);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds, ctx->stream, keys, keys_hi, fv, gt, n, lcap);
         aqg_kernel_timer_end(ctx);
         return aqg_check_launch(ctx, "agg32_kernel");
     };

@@ -11,4 +11,4 @@ constexpr uint32_t OCCUPIED = 0xFFFFFFFEu;   // first_row mark: "group exists, f
 // column), `nacc` accumulators described by fv (v8: some value column is not 4 bytes wide), per-workgroup LDS tables of lcap slots
 // merged into gt.  Records the kernel's duration in the context's kernel timer.
 int aqg_fast_aggregate(aqg_ctx* ctx, const uint32_t* keys, const uint32_t* keys_hi, bool k64, bool v8, int nacc, bool need_count,
-                       const FastVals& fv, GTable gt, uint32_t n, uint32_t lcap, size_t lds, unsigned grid);
+                       const FastVals& fv, GTable gt, uint32_t n, uint32_t lcap, size_t lds, unsigned grid, unsigned block);
