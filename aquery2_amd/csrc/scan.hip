@@ -589,6 +589,159 @@ __global__ void __launch_bounds__(SB) window_minmax_kernel(const T* __restrict__
     }
 }
 
+// ---- sliding min / max, long windows (w >= 128): van Herk / Gil-Werman ------------------------------------------------------------
+// The doubling kernel above pays log2(w) LDS passes over tile + halo (maxw(1000): nine, 34 % of the HBM roofline).  Here the LDS
+// positions are cut into segments of w; with F[p] = best of [segment start, p] and B[p] = best of [p, segment end], the window of
+// length w ending at p is better(B[p - w + 1], F[p]) -- three passes whatever w is.  A workgroup of 1024 lanes holds C x 1024 positions
+// (halo rounded up to a 16-byte vector, then the tile); a lane owns C consecutive positions (C odd: the strided LDS accesses of a
+// wavefront fall into distinct banks), scans them in registers in both directions, and the carries between lanes come from
+// segmented scans (value + "a segment border lies inside" flag): DPP row shifts inside the 16-lane rows, the three row totals
+// through v_readlane, the 16 wavefront totals through LDS and one more 16-lane row scan.  The kernel is bound by VALU issue
+// (one wave64 instruction per cycle and CU: ~40 per element leave 70 % of the HBM roofline), which is why the scans avoid
+// ds_bpermute shuffles and per-wavefront loops.
+template <class T, bool IS_MAX> __device__ inline T vh_better(T a, T b) { if constexpr (IS_MAX) return b > a ? b : a; else return b < a ? b : a; }
+template <int CTRL> __device__ inline uint32_t vh_dpp32(uint32_t old, uint32_t src) { return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, 0xF, false); }
+// lane i <- lane i -/+ N of its 16-lane row (CTRL 0x110 + N: row_shr, 0x100 + N: row_shl); lanes without a source keep `old`
+template <int CTRL, class T> __device__ inline T vh_dpp(T old, T src) {
+    if constexpr (sizeof(T) == 8) {
+        const uint64_t o = __builtin_bit_cast(uint64_t, old), v = __builtin_bit_cast(uint64_t, src);
+        const uint64_t r = (uint64_t)vh_dpp32<CTRL>((uint32_t)o, (uint32_t)v) | ((uint64_t)vh_dpp32<CTRL>((uint32_t)(o >> 32), (uint32_t)(v >> 32)) << 32);
+        return __builtin_bit_cast(T, r);
+    } else if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, vh_dpp32<CTRL>(__builtin_bit_cast(uint32_t, old), __builtin_bit_cast(uint32_t, src)));
+    else return (T)vh_dpp32<CTRL>((uint32_t)(int32_t)old, (uint32_t)(int32_t)src);
+}
+template <class T> __device__ inline T vh_readlane(T v, int l) {
+    if constexpr (sizeof(T) == 8) {
+        const uint64_t x = __builtin_bit_cast(uint64_t, v);
+        const uint64_t r = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), l) << 32);
+        return __builtin_bit_cast(T, r);
+    } else if constexpr (sizeof(T) == 4) return __builtin_bit_cast(T, (uint32_t)__builtin_amdgcn_readlane((int)__builtin_bit_cast(uint32_t, v), l));
+    else return (T)__builtin_amdgcn_readlane((int)v, l);
+}
+// inclusive segmented scan over the 16-lane rows: UP = towards higher lanes (prefix), else towards lower lanes (suffix)
+template <class T, bool IS_MAX, bool UP> __device__ inline void vh_row_scan(T& v, uint32_t& f, T ident) {
+#define AQG_VH_STEP(N) { const T ov = vh_dpp<(UP ? 0x110 : 0x100) + N>(ident, v); const uint32_t of = vh_dpp32<(UP ? 0x110 : 0x100) + N>(0u, f); \
+                         if (!f) v = vh_better<T, IS_MAX>(ov, v); f |= of; }
+    AQG_VH_STEP(1) AQG_VH_STEP(2) AQG_VH_STEP(4) AQG_VH_STEP(8)
+#undef AQG_VH_STEP
+}
+template <class T, bool IS_MAX, int C, int WPE>
+__global__ void __launch_bounds__(1024, WPE) window_minmax_vh_kernel(const T* __restrict__ x, uint32_t n, uint32_t w, uint32_t tile_rows, T* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    constexpr uint32_t NT = 1024, L = C * NT;
+    constexpr int V = 16 / sizeof(T);                            // elements per 16-byte vector
+    T* A = reinterpret_cast<T*>(smem_raw);                       // [L] inputs, later the results
+    T* Bs = A + L;                                               // [L] suffix bests
+    __shared__ T wv[2][16];
+    __shared__ uint32_t wf[2][16];
+    const uint32_t Hp = L - tile_rows;                            // halo (>= w - 1, a multiple of V like tile_rows)
+    const uint64_t tile_start = (uint64_t)blockIdx.x * tile_rows;
+    T ident;
+    if constexpr (std::is_floating_point_v<T>) ident = IS_MAX ? -(T)INFINITY : (T)INFINITY;
+    else ident = IS_MAX ? dlimits<T>::min() : dlimits<T>::max();
+    struct alignas(16) vec_t { T v[V]; };
+    const bool oal = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    // position p <-> row tile_start - Hp + p (x is 16-byte aligned: the host sends other columns to the doubling kernel)
+    const int64_t base = (int64_t)tile_start - (int64_t)Hp;
+    if (base >= 0 && base + (int64_t)L <= (int64_t)n) {
+        for (uint32_t q = threadIdx.x; q < L / V; q += NT) *reinterpret_cast<vec_t*>(A + (size_t)q * V) = *reinterpret_cast<const vec_t*>(x + base + (int64_t)q * V);
+    } else {
+        for (uint32_t p = threadIdx.x; p < L; p += NT) { const int64_t r = base + p; A[p] = r >= 0 && r < (int64_t)n ? x[r] : ident; }
+    }
+    __syncthreads();
+    const uint32_t p0 = threadIdx.x * C, lane = threadIdx.x & 63, row = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    T a[C], f[C], bk[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) a[j] = A[p0 + j];
+    const uint32_t r0 = p0 % w;                                  // position inside its segment; w > C: at most one border in the chunk
+    // forward: f[j] = best of [max(segment start, p0), p0 + j]; jf = first index that starts a segment (C: none)
+    int jf = C;
+    f[0] = a[0];
+    if (r0 == 0) jf = 0;
+#pragma unroll
+    for (int j = 1; j < C; ++j) {
+        const bool start = r0 + j == w;
+        if (start) jf = j;
+        f[j] = start ? a[j] : vh_better<T, IS_MAX>(f[j - 1], a[j]);
+    }
+    // backward: bk[j] = best of [p0 + j, min(segment end, p0 + C - 1)]; je = last index that ends a segment (-1: none)
+    int je = -1;
+    bk[C - 1] = a[C - 1];
+    if (r0 + C == w) je = C - 1;
+#pragma unroll
+    for (int j = C - 2; j >= 0; --j) {
+        const bool end = r0 + j + 1 == w;
+        if (end && je < 0) je = j;
+        bk[j] = end ? a[j] : vh_better<T, IS_MAX>(bk[j + 1], a[j]);
+    }
+    // ---- carries inside the wavefront: row scans, then the totals of the rows before (F) / behind (B) ----
+    T fv = f[C - 1]; uint32_t ff = jf < C;
+    T bv = bk[0]; uint32_t bf = je >= 0;
+    vh_row_scan<T, IS_MAX, true>(fv, ff, ident);
+    vh_row_scan<T, IS_MAX, false>(bv, bf, ident);
+    T fcr = ident, bcr = ident; uint32_t fgr = 0, bgr = 0;          // what enters this lane's row from the other rows
+    {
+        const T t0 = vh_readlane(fv, 15), t1 = vh_readlane(fv, 31), t2 = vh_readlane(fv, 47);
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)ff, 15), g1 = (uint32_t)__builtin_amdgcn_readlane((int)ff, 31), g2 = (uint32_t)__builtin_amdgcn_readlane((int)ff, 47);
+        const T c1 = t0, c2 = g1 ? t1 : vh_better<T, IS_MAX>(c1, t1), c3 = g2 ? t2 : vh_better<T, IS_MAX>(c2, t2);
+        fcr = row == 0 ? ident : row == 1 ? c1 : row == 2 ? c2 : c3;
+        fgr = row == 0 ? 0u : row == 1 ? g0 : row == 2 ? (g0 | g1) : (g0 | g1 | g2);
+        const T u3 = vh_readlane(bv, 48), u2 = vh_readlane(bv, 32), u1 = vh_readlane(bv, 16);
+        const uint32_t h3 = (uint32_t)__builtin_amdgcn_readlane((int)bf, 48), h2 = (uint32_t)__builtin_amdgcn_readlane((int)bf, 32), h1 = (uint32_t)__builtin_amdgcn_readlane((int)bf, 16);
+        const T d2 = u3, d1 = h2 ? u2 : vh_better<T, IS_MAX>(d2, u2), d0 = h1 ? u1 : vh_better<T, IS_MAX>(d1, u1);
+        bcr = row == 3 ? ident : row == 2 ? d2 : row == 1 ? d1 : d0;
+        bgr = row == 3 ? 0u : row == 2 ? h3 : row == 1 ? (h3 | h2) : (h3 | h2 | h1);
+    }
+    // this lane's EXCLUSIVE value inside the wavefront (the lane before / behind; across a row border: what enters the row)
+    T fe = vh_dpp<0x111>(fcr, fv); uint32_t fef = vh_dpp32<0x111>(fgr, ff);
+    T be = vh_dpp<0x101>(bcr, bv); uint32_t bef = vh_dpp32<0x101>(bgr, bf);
+    if ((lane & 15) != 0) { if (!fef) fe = vh_better<T, IS_MAX>(fcr, fe); fef |= fgr; }
+    if ((lane & 15) != 15) { if (!bef) be = vh_better<T, IS_MAX>(bcr, be); bef |= bgr; }
+    // wavefront totals
+    if (lane == 63) { wv[0][wave] = ff ? fv : vh_better<T, IS_MAX>(fcr, fv); wf[0][wave] = ff | fgr; }
+    if (lane == 0) { wv[1][wave] = bf ? bv : vh_better<T, IS_MAX>(bcr, bv); wf[1][wave] = bf | bgr; }
+    __syncthreads();
+    // ---- carries between the wavefronts: the 16 totals, scanned in a 16-lane row; wavefront W takes lane W - 1 (F) / W + 1 (B) ----
+    T fc = ident, bc = ident;
+    {
+        T tv = wv[0][lane & 15]; uint32_t tf = wf[0][lane & 15];
+        vh_row_scan<T, IS_MAX, true>(tv, tf, ident);
+        const T got = vh_readlane(tv, wave > 0 ? wave - 1 : 0);
+        if (wave > 0) fc = got;
+        T sv = wv[1][lane & 15]; uint32_t sf = wf[1][lane & 15];
+        vh_row_scan<T, IS_MAX, false>(sv, sf, ident);
+        const T got2 = vh_readlane(sv, wave < 15 ? wave + 1 : 15);
+        if (wave < 15) bc = got2;
+    }
+    const T fcar = fef ? fe : vh_better<T, IS_MAX>(fc, fe);
+    const T bcar = bef ? be : vh_better<T, IS_MAX>(bc, be);
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        if (j < jf) f[j] = vh_better<T, IS_MAX>(fcar, f[j]);
+        if (j > je) bk[j] = vh_better<T, IS_MAX>(bcar, bk[j]);
+        Bs[p0 + j] = bk[j];
+    }
+    __syncthreads();
+    const uint32_t back = w - 1;
+#pragma unroll
+    for (int j = 0; j < C; ++j) {
+        const uint32_t p = p0 + j;
+        if (p >= Hp) A[p] = vh_better<T, IS_MAX>(Bs[p - back], f[j]);
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < tile_rows / V; q += NT) {
+        const uint64_t g0 = tile_start + (uint64_t)q * V;
+        if (g0 >= n) break;
+        const vec_t b = *reinterpret_cast<const vec_t*>(A + Hp + (size_t)q * V);
+        if (g0 + V <= n && oal) *reinterpret_cast<vec_t*>(out + g0) = b;
+        else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) if (g0 + e < n) out[g0 + e] = b.v[e];
+        }
+    }
+}
+
 // large-window fallback for min/max: doubling passes through HBM (ping-pong), then the two-span combine
 template <class T, bool IS_MAX>
 __global__ void __launch_bounds__(SB) doubling_pass_kernel(const T* __restrict__ src, T* __restrict__ dst, uint32_t n, uint32_t d) {
@@ -846,6 +999,51 @@ int aqg_scan(aqg_ctx* ctx, int op, int t, const void* xv, uint32_t n, uint32_t w
             // the deque never expires anything when w == 0 or w >= n: plain running min / max (no seed)
             uint32_t ww = (w == 0 || w > n) ? n : w;
             if (ww == n) return is_max ? run_prefix<T, max_alg<T>, W_MAXP>(ctx, x, n, out) : run_prefix<T, min_alg<T>, W_MINS>(ctx, x, n, out);
+            // long windows: van Herk / Gil-Werman over C x 1024 LDS positions (C odd; two arrays of them; two workgroups per CU while
+            // they take <= 78 KB and the kernel keeps to 64 VGPRs).  Needs a 16-byte aligned column; others take the doubling kernel.
+            static const bool vh_off = getenv("AQG_DISABLE_VANHERK") != nullptr;
+            static const int vh_c = getenv("AQG_VANHERK_C") ? atoi(getenv("AQG_VANHERK_C")) : 0;
+            if (ww >= 128 && !vh_off && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && n >= 64) {
+                constexpr uint32_t V = 16 / sizeof(T);
+                constexpr int CMAX2 = sizeof(T) <= 4 ? 9 : 3;                           // largest C still run with two workgroups per CU
+                const uint32_t hp = (ww - 1 + V - 1) / V * V;
+                int c = 0;
+                for (int cand : {9, 7, 5, 3}) if (cand <= CMAX2 && (size_t)cand * 2048 * sizeof(T) <= 78 * 1024 && (size_t)cand * 1024 >= 2 * (size_t)hp + V) { c = cand; break; }
+                if (!c) for (int cand : {5, 7, 9, 11}) if ((sizeof(T) <= 4 || cand <= 7) && (size_t)cand * 2048 * sizeof(T) <= 150 * 1024 && (size_t)cand * 1024 >= 2 * (size_t)hp + V) { c = cand; break; }
+                if (vh_c && (size_t)vh_c * 1024 >= (size_t)hp + V && (size_t)vh_c * 2048 * sizeof(T) <= 150 * 1024 && (sizeof(T) <= 4 || vh_c <= 7)) c = vh_c;
+                if (c) {
+                    const uint32_t tile_rows = (uint32_t)c * 1024 - hp;
+                    const size_t vlds = (size_t)c * 2048 * sizeof(T);
+                    const bool two = c <= CMAX2 && vlds <= 78 * 1024;
+                    const unsigned vtiles = (unsigned)(((uint64_t)n + tile_rows - 1) / tile_rows);
+                    auto gov = [&](auto kern) -> int {
+                        AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)vlds));
+                        aqg_kernel_timer_begin(ctx);
+                        hipLaunchKernelGGL(kern, dim3(vtiles), dim3(1024), vlds, ctx->stream, x, n, ww, tile_rows, static_cast<T*>(out));
+                        aqg_kernel_timer_end(ctx);
+                        return aqg_check_launch(ctx, "window_minmax_vh_kernel");
+                    };
+                    auto byc = [&](auto mx) -> int {
+                        constexpr bool MX = decltype(mx)::value;
+                        if constexpr (sizeof(T) <= 4) {
+                            switch (c) {
+                            case 3: return gov(&window_minmax_vh_kernel<T, MX, 3, 8>);
+                            case 5: return gov(&window_minmax_vh_kernel<T, MX, 5, 8>);
+                            case 7: return two ? gov(&window_minmax_vh_kernel<T, MX, 7, 8>) : gov(&window_minmax_vh_kernel<T, MX, 7, 4>);
+                            case 9: return two ? gov(&window_minmax_vh_kernel<T, MX, 9, 8>) : gov(&window_minmax_vh_kernel<T, MX, 9, 4>);
+                            default: return gov(&window_minmax_vh_kernel<T, MX, 11, 4>);
+                            }
+                        } else {
+                            switch (c) {
+                            case 3: return gov(&window_minmax_vh_kernel<T, MX, 3, 8>);
+                            case 5: return gov(&window_minmax_vh_kernel<T, MX, 5, 4>);
+                            default: return gov(&window_minmax_vh_kernel<T, MX, 7, 4>);
+                            }
+                        }
+                    };
+                    return is_max ? byc(std::true_type{}) : byc(std::false_type{});
+                }
+            }
             size_t lds = (size_t)(TS + (ww - 1 + 7) / 8 * 8) * sizeof(T) * 2;
             if (lds <= HALO_MAX_BYTES) {
                 auto go = [&](auto kern) -> int {

@@ -182,3 +182,25 @@ def test_col_pin_async_upload_is_stream_ordered(gpu, oracle):
         assert gb.ngroups == o["ngroups"] and np.array_equal(gb.first_rows(), o["first_rows"])
         gb.destroy()
     gpu.col_unpin_all()
+
+
+@pytest.mark.parametrize("off", [0, 1])
+def test_long_window_minmax(gpu, oracle, off):
+    """minw / maxw with w >= 128 (the van Herk / Gil-Werman kernel): every element type, windows around the segment and tile
+    borders, inputs shorter than / equal to / a few rows longer than one tile, misaligned columns (aggregations.h:127-167)"""
+    rng = np.random.default_rng(300 + off)
+    for dt in (np.int32, np.int8, np.uint16, np.int64, np.uint64, np.float32, np.float64):
+        fp = np.dtype(dt).kind == "f"
+        for n, ws in ((6169, (128, 1000)), (6170, (129, 1023)), (20_011, (128, 1024, 2047, 3000, 5000)), (300_007, (1000, 2500))):
+            x = np.round(rng.uniform(-1000, 1000, n), 3).astype(dt) if fp else rand(rng, dt, n, small=False)
+            xv = view(gpu, x, off)
+            for w in ws:
+                for name in ("minw", "maxw"):
+                    assert gu.same_bits(gpu.scan(ck.SCAN_NAMES[name], xv, w), oracle.scan(ck.SCAN_NAMES[name], x, w)), (dt, n, name, w)
+    # a sorted and a reverse-sorted series: every window's best sits at one of its ends
+    x = np.arange(50_000, dtype=np.int32)
+    for y in (x, x[::-1].copy()):
+        yv = view(gpu, y, off)
+        for w in (128, 777, 4096):
+            assert gu.same_bits(gpu.scan(ck.SCAN_MAXW, yv, w), oracle.scan(ck.SCAN_MAXW, y, w)), w
+            assert gu.same_bits(gpu.scan(ck.SCAN_MINW, yv, w), oracle.scan(ck.SCAN_MINW, y, w)), w
