@@ -175,6 +175,10 @@ int aqg_memset(aqg_ctx* ctx, void* dst, int byte, size_t bytes) {
 // including the registration (PCIe line rate) against 21 GB/s for a first pageable hipMemcpy; chunks whose registration fails
 // (ranges sharing a page with an earlier registration, read-only mappings) go through the runtime's pageable path.
 static void pin_release(aqg_ctx* ctx, aqg_pin& p) {
+    // every upload in flight first, not only this column's: a LATER column whose host range overlaps pages registered for this one is
+    // copied by DMA straight out of them (test_col_pin_async_upload_is_stream_ordered pins overlapping slices; unlocking the pages
+    // under such a copy aborted the process once in ~7 runs)
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (p.ev) { hipEventSynchronize(p.ev); hipEventDestroy(p.ev); p.ev = nullptr; }
     for (auto& r : p.regs) (void)hipHostUnregister(r.first);
     p.regs.clear();

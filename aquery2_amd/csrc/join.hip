@@ -18,7 +18,12 @@ namespace {
 constexpr uint64_t JEMPTY = ~0ull;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
-__device__ inline uint32_t jhash(uint64_t k) { k *= 0x9E3779B97F4A7C15ull; return (uint32_t)(k >> 32) ^ (uint32_t)k; }
+// slot of a key in a table of 2^bits slots: 32-bit multiplies only (the probe loop is bound by VALU issue, and a 64-bit multiply
+// costs four quarter-rate 32-bit ones); the TOP bits of the product are the well-mixed ones
+__device__ inline uint32_t jslot(uint64_t k, uint32_t bits) {
+    const uint32_t h = ((uint32_t)k ^ ((uint32_t)(k >> 32) * 0x85EBCA6Bu)) * 0x9E3779B1u;
+    return h >> (32 - bits);
+}
 
 __device__ inline uint64_t key_bits(int dt, const void* col, size_t i) {   // sign-extended value as the join key
     switch (dt) {
@@ -54,11 +59,11 @@ __device__ inline void key_bits4(int dt, const void* col, const size_t (&ix)[4],
 struct JTable { uint64_t* keys; uint32_t* val; uint32_t cap; uint32_t* sentinel_val; };   // sentinel: the key equal to JEMPTY
 
 __global__ void __launch_bounds__(256) jt_build_kernel(int dt, const void* __restrict__ col, uint32_t n, JTable t) {
-    const uint32_t mask = t.cap - 1;
+    const uint32_t mask = t.cap - 1, bits = 31 - __clz(t.cap);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         uint64_t k = key_bits(dt, col, i);
         if (k == JEMPTY) { atomicMin(t.sentinel_val, i); continue; }
-        uint32_t s = jhash(k) & mask;
+        uint32_t s = jslot(k, bits);
         for (uint32_t p = 0; p < t.cap; ++p) {
             uint64_t cur = t.keys[s];
             if (cur == JEMPTY) {
@@ -70,12 +75,13 @@ __global__ void __launch_bounds__(256) jt_build_kernel(int dt, const void* __res
         }
     }
 }
-// Probe: four CONSECUTIVE rows per lane per step (one vector load of the keys, one 16-byte store of the results), the four
-// first slots read before the first compare.  LDS: the whole table is copied into LDS first (dimension sides of a few
-// thousand rows: every probe is an LDS access instead of an L2 round trip).
+// Probe: R CONSECUTIVE rows per lane per step (16-byte loads of the keys, 16-byte stores of the results; R = 8 for keys up to four
+// bytes), every first slot -- key and payload -- read before the first compare; only rows whose first slot holds another key walk on.
+// LDS: the whole table is copied into LDS first (dimension sides of a few thousand rows: every probe is an LDS access instead of
+// an L2 round trip).
 template <bool LDS, class T>
 __device__ inline void probe_rows(const T* __restrict__ col, uint32_t n, const JTable& t, const uint64_t* keys, const uint32_t* val, uint32_t* __restrict__ out) {
-    const uint32_t mask = t.cap - 1;
+    const uint32_t mask = t.cap - 1, bits = 31 - __clz(t.cap);
     const uint32_t sentinel = *t.sentinel_val;
     auto key_of = [](T v) -> uint64_t { if constexpr (std::is_signed_v<T>) return (uint64_t)(int64_t)v; else return (uint64_t)v; };
     auto finish = [&](uint64_t k, uint32_t sl, uint64_t c) -> uint32_t {
@@ -88,26 +94,35 @@ __device__ inline void probe_rows(const T* __restrict__ col, uint32_t n, const J
         }
         return NONE;
     };
-    const uint32_t nchunk = n >> 2;
-    const bool aligned = ((reinterpret_cast<uintptr_t>(col) & (sizeof(T) * 4 > 16 ? 15 : sizeof(T) * 4 - 1)) | (reinterpret_cast<uintptr_t>(out) & 15)) == 0;
+    constexpr int KV = 16 / sizeof(T) > 4 ? 4 : 16 / sizeof(T);          // keys per vector load (at most four: one 16-byte store of results)
+    constexpr int R = sizeof(T) <= 4 ? 8 : 4, NKV = R / KV;
+    const uint32_t nchunk = n / R;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(col) & (sizeof(T) * KV - 1)) | (reinterpret_cast<uintptr_t>(out) & 15)) == 0;
     if (aligned) {
         uint32_t c_lo, c_hi;
         wg_span(nchunk, c_lo, c_hi);
         for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
-            const pack<T, 4> kv = *reinterpret_cast<const pack<T, 4>*>(col + (size_t)c * 4);
-            uint64_t k[4], cur[4];
-            uint32_t s[4];
+            pack<T, KV> kv[NKV];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { k[q] = key_of(kv.v[q]); s[q] = jhash(k[q]) & mask; cur[q] = keys[s[q]]; }
-            pack<uint32_t, 4> o;
+            for (int v = 0; v < NKV; ++v) kv[v] = *reinterpret_cast<const pack<T, KV>*>(col + (size_t)c * R + v * KV);
+            uint64_t k[R], cur[R];
+            uint32_t s[R], o[R];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o.v[q] = finish(k[q], s[q], cur[q]);
-            *reinterpret_cast<pack<uint32_t, 4>*>(out + (size_t)c * 4) = o;
+            for (int q = 0; q < R; ++q) { k[q] = key_of(kv[q / KV].v[q % KV]); s[q] = jslot(k[q], bits); cur[q] = keys[s[q]]; o[q] = val[s[q]]; }
+#pragma unroll
+            for (int q = 0; q < R; ++q) if (cur[q] != k[q] || k[q] == JEMPTY) o[q] = finish(k[q], s[q], cur[q]);
+#pragma unroll
+            for (int v = 0; v < R / 4; ++v) {
+                pack<uint32_t, 4> ov;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ov.v[e] = o[v * 4 + e];
+                *reinterpret_cast<pack<uint32_t, 4>*>(out + (size_t)c * R + v * 4) = ov;
+            }
         }
     }
-    for (uint32_t i = (aligned ? nchunk << 2 : 0u) + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = (aligned ? nchunk * R : 0u) + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint64_t k = key_of(col[i]);
-        const uint32_t sl = jhash(k) & mask;
+        const uint32_t sl = jslot(k, bits);
         out[i] = finish(k, sl, keys[sl]);
     }
 }
