@@ -85,13 +85,24 @@ template <bool FIRST> __device__ inline void load_pair(const uint32_t* __restric
     if constexpr (FIRST) { v = n - 1 - q; k = keys[v]; } else { k = keys[q]; v = vals[q]; }
 }
 
+// Tile of a workgroup.  Workgroups go to the eight XCDs round-robin; with tile = blockIdx consecutive tiles sit on different XCDs,
+// and the pieces they write next to each other -- the end of one tile's run of a digit and the start of the next tile's, the
+// [digit][tile] histogram words -- become partial-line writes out of eight different L2s.  Here XCD x walks the tiles
+// [x * per, (x + 1) * per) in order, so neighbouring pieces meet in one L2 before they are written back.  (grid = 8 * per)
+__device__ inline uint32_t xcd_tile(uint32_t ntiles) {
+    const uint32_t per = (ntiles + 7) / 8;
+    return (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+}
+
 template <bool FIRST>
 __global__ void __launch_bounds__(RB) radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t ntiles,
                                                         uint32_t* __restrict__ hist /* [256][ntiles] */) {
     __shared__ uint32_t h[256];
+    const uint32_t tile = xcd_tile(ntiles);
+    if (tile >= ntiles) return;
     if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t tbase = blockIdx.x * RT;
+    const uint32_t tbase = tile * RT;
     uint32_t k[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -101,7 +112,7 @@ __global__ void __launch_bounds__(RB) radix_hist_kernel(const uint32_t* __restri
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) if (tbase + r * RB + threadIdx.x < n) atomicAdd(&h[(k[r] >> shift) & 255], 1u);
     __syncthreads();
-    if (threadIdx.x < 256) hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < 256) hist[(size_t)threadIdx.x * ntiles + tile] = h[threadIdx.x];
 }
 
 // Stable scatter of one tile.  Rank of a row among the tile's rows of its digit = rows of that digit in earlier
@@ -116,12 +127,14 @@ __global__ void __launch_bounds__(RB) radix_scatter_kernel(const uint32_t* __res
     __shared__ uint16_t cell[CELLS][256];              // rows of each digit per cell, then their exclusive prefix over the cells
     __shared__ uint32_t gbase[256], lbase[256], wsum[4];
     __shared__ uint32_t stage[RT], delta[RT];
-    const uint32_t tbase = blockIdx.x * RT;
+    const uint32_t tile = xcd_tile(ntiles);
+    if (tile >= ntiles) return;
+    const uint32_t tbase = tile * RT;
     const uint32_t nrows = n - tbase < (uint32_t)RT ? n - tbase : (uint32_t)RT;
     const int lane = lane_id(), wid = wave_id();
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     for (uint32_t i = threadIdx.x; i < CELLS * 256 / 2; i += RB) reinterpret_cast<uint32_t*>(&cell[0][0])[i] = 0;
-    if (threadIdx.x < 256) gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * ntiles + blockIdx.x];
+    if (threadIdx.x < 256) gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * ntiles + tile];
     uint32_t k[ROUNDS], v[ROUNDS], d[ROUNDS], rank[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) load_pair<FIRST>(keys, vals, n, tbase + r * RB + threadIdx.x, k[r], v[r]);
@@ -204,6 +217,7 @@ extern "C" int aqg_groupby_postproc(aqg_groupby* g, uint32_t* offsets_dev, uint3
     while (bits < 32 && (1ull << bits) < G) ++bits;
     const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;
     const uint64_t hcount = (uint64_t)256 * ntiles;
+    const uint32_t grid8 = (ntiles + 7) / 8 * 8;                 // xcd_tile: eight interleaved walks over the tiles
 
     AQG_TRY(aqg_ws_reset(ctx));
     size_t need = hcount * 4 + ((hcount + 2047) / 2048 + (G + 2048) / 2048 + 16) * 4 + 8192;
@@ -228,13 +242,13 @@ extern "C" int aqg_groupby_postproc(aqg_groupby* g, uint32_t* offsets_dev, uint3
         const uint32_t shift = pass * 8;
         uint32_t* kout = last ? nullptr : ((pass & 1) ? k1 : k0);
         uint32_t* vout = last ? row_ids_dev : ((pass & 1) ? v1 : v0);
-        if (first) hipLaunchKernelGGL((radix_hist_kernel<true>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
-        else hipLaunchKernelGGL((radix_hist_kernel<false>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
+        if (first) hipLaunchKernelGGL((radix_hist_kernel<true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
+        else hipLaunchKernelGGL((radix_hist_kernel<false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
         AQG_TRY(aqg_exclusive_scan_u32(ctx, hist, hcount, bsum));
-        if (first && last) { aqg_kernel_timer_begin(ctx); hipLaunchKernelGGL((radix_scatter_kernel<true, true>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout); aqg_kernel_timer_end(ctx); }
-        else if (first) hipLaunchKernelGGL((radix_scatter_kernel<true, false>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
-        else if (last) hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
-        else hipLaunchKernelGGL((radix_scatter_kernel<false, false>), dim3(ntiles), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
+        if (first && last) { aqg_kernel_timer_begin(ctx); hipLaunchKernelGGL((radix_scatter_kernel<true, true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout); aqg_kernel_timer_end(ctx); }
+        else if (first) hipLaunchKernelGGL((radix_scatter_kernel<true, false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
+        else if (last) hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
+        else hipLaunchKernelGGL((radix_scatter_kernel<false, false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
         AQG_TRY(aqg_check_launch(ctx, "radix pass"));
         kin = kout; vin = vout;
     }
