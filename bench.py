@@ -82,7 +82,7 @@ def secondary_entries(dev, n, ck, aq, id1, v1):
     for name, op, w, bpr in (("avgw5_price", ck.SCAN_AVGW, 5, 12), ("sumw5_price", ck.SCAN_SUMW, 5, 20), ("minw10_price", ck.SCAN_MINW, 10, 8)):
         ot = dev.lib.aqg_scan_out_dtype(op, price.tag)
         o = aq.DevBuf(dev, big.ptr, aq.capi.TAG2NP[ot], n, owned=False)
-        ms = timed(lambda: dev.scan(op, price, w, keep=True, out=o))
+        ms = timed(lambda: dev.scan(op, price, w, keep=True, out=o), reps=5)
         entry(name, ms, bpr * n, kernel_ms=round(dev.last_kernel_ms(), 4))
     big.free(); price.free()
     # ---- config 4 (one shard of it): fact JOIN small(id4, w), sum(v1 * w) by id1, fused
@@ -294,7 +294,7 @@ def main():
                          # the file it comes from: Q1 8.0255 GB read + 0.0121 GB written, join 12.001 + 0.018.
                          "traffic": None,
                          "traffic_profiled": {"bytes_at_1e9_rows": 12.019e9 if join else 8.0376e9,
-                                              "source": "profiles/r1_groupby_join_1e9_pmc.md" if join else "profiles/r1_bench_q1_1e9_pmc.md"},
+                                              "source": "profiles/r1_groupby_join_1e9_pmc.md" if join else "profiles/r2_bench_q1_1e9_pmc.md"},
                          "kernel": "starjoin_kernel" if join else "agg32_kernel<1,false,false,4>", "kernel_ms": k_ms, "algorithmic_bytes": bpr * n},
         }
         if world == 1 and args.cpu_sample > 0 and not join:
