@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __
 // rows lie in one interval of <= C rows, so its first group id is its start offset and a group's id is that plus the number of set
 // bits below its first row in a bitmap of the interval.  The records are permuted into id order inside LDS and emitted from there:
 // every output column is written front to back, the key columns (wide tuples) are read in ascending row order.
-__global__ void __launch_bounds__(512) sorted_emit_kernel(SortedParts sp, uint32_t G, uint32_t n_rows, int nacc, int has_count, int wide, EmitSpec es, uint32_t* __restrict__ flags) {
+__global__ void __launch_bounds__(1024) sorted_emit_kernel(SortedParts sp, uint32_t G, uint32_t n_rows, int nacc, int has_count, int wide, EmitSpec es, uint32_t* __restrict__ flags) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const uint32_t C = sp.cap, W = C / 32 + 8;
     uint64_t* sacc = reinterpret_cast<uint64_t*>(smem_raw);                 // [nacc][C]
@@ -708,7 +708,8 @@ __global__ void __launch_bounds__(512) sorted_emit_kernel(SortedParts sp, uint32
     uint32_t* scount = sfirst + C;                                          // [C]
     uint32_t* bm = scount + C;                                              // [W] bitmap of the row interval
     uint32_t* wp = bm + W;                                                  // [W] set bits before every word
-    __shared__ uint32_t wsum[8];
+    __shared__ uint32_t wsum[16];
+    const uint32_t NT = blockDim.x;
     GTable lt;
     lt.kb = reinterpret_cast<unsigned char*>(skey); lt.fb = reinterpret_cast<unsigned char*>(sfirst); lt.cb = reinterpret_cast<unsigned char*>(scount);
     lt.ab = reinterpret_cast<unsigned char*>(sacc);
@@ -722,11 +723,11 @@ __global__ void __launch_bounds__(512) sorted_emit_kernel(SortedParts sp, uint32
         const uint32_t lo = (uint32_t)lo64, hi = hi64 < n_rows ? (uint32_t)hi64 : n_rows;
         const uint32_t c = e - b, nw = (hi - lo + 31) / 32;
         if (hi - lo > C || c > C || e > G) { if (threadIdx.x == 0) flags[0] = 1; continue; }       // (the plan rules it out)
-        for (uint32_t w = threadIdx.x; w < nw; w += 512) bm[w] = 0;
+        for (uint32_t w = threadIdx.x; w < nw; w += NT) bm[w] = 0;
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < c; j += 512) { const uint32_t r = sp.first[b + j] - lo; atomicOr(&bm[r >> 5], 1u << (r & 31)); }
+        for (uint32_t j = threadIdx.x; j < c; j += NT) { const uint32_t r = sp.first[b + j] - lo; atomicOr(&bm[r >> 5], 1u << (r & 31)); }
         __syncthreads();
-        {   // nw <= 512: one word per thread
+        {   // nw <= 512 <= NT: one word per thread
             const uint32_t t = threadIdx.x < nw ? __popc(bm[threadIdx.x]) : 0;
             const uint32_t incl = wave_scan_incl(t, OpAdd{}, lane_id());
             if (lane_id() == 63) wsum[wave_id()] = incl;
@@ -736,7 +737,7 @@ __global__ void __launch_bounds__(512) sorted_emit_kernel(SortedParts sp, uint32
             if (threadIdx.x < nw) wp[threadIdx.x] = base;
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < c; j += 512) {
+        for (uint32_t j = threadIdx.x; j < c; j += NT) {
             const uint32_t fr = sp.first[b + j], r = fr - lo;
             const uint32_t rank = wp[r >> 5] + __popc(bm[r >> 5] & ((1u << (r & 31)) - 1u));
             sfirst[rank] = fr;
@@ -746,7 +747,7 @@ __global__ void __launch_bounds__(512) sorted_emit_kernel(SortedParts sp, uint32
         }
         __syncthreads();
         if (k32) {      // wide tuples of 4-byte columns: the key loads of a record issued together (emit_record's run one after the other)
-            for (uint32_t i = threadIdx.x; i < c; i += 512) {
+            for (uint32_t i = threadIdx.x; i < c; i += NT) {
                 const uint32_t row = sfirst[i], g = b + i;
                 uint32_t kv[MAXKEYS];
 #pragma unroll
@@ -756,7 +757,7 @@ __global__ void __launch_bounds__(512) sorted_emit_kernel(SortedParts sp, uint32
                 emit_record<false>(lt, i, g, es, 0);
             }
         } else {
-            for (uint32_t i = threadIdx.x; i < c; i += 512) emit_record(lt, i, b + i, es, wide ? (uint64_t)sfirst[i] : skey[i]);
+            for (uint32_t i = threadIdx.x; i < c; i += NT) emit_record(lt, i, b + i, es, wide ? (uint64_t)sfirst[i] : skey[i]);
         }
         __syncthreads();
     }
@@ -1196,6 +1197,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         }
     }
     AQG_TRY(aqg_ws_get(ctx, 64, &gt.flags));
+    if (sorted_tail && use_wpart) gt.kb = nullptr;       // wide tuples through the ordering tail: the key word would repeat the first-row plane
     occ = gid_of_occ = slot_gid = nullptr;
     if (!sorted_tail) {
         AQG_TRY(aqg_ws_get(ctx, slots, &occ));
@@ -1312,11 +1314,14 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     // ---- dense ids ---------------------------------------------------------------------------------
     unsigned cgrid = aqg_grid(ctx, slots, 256, 1, 8);
     if (!(n && (use_part || use_wpart))) hipLaunchKernelGGL(collect_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, gt, occ);
-    uint32_t fl[4] = {0, 0, 0, 0};                    // [0] overflow, [1] occupied slots, [3] a row outside the sampled key ranges
+    uint32_t fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // [0] overflow, [1] occupied slots, [3] a row outside the sampled key ranges, [4], [5] diagnostics
     uint32_t G = 0;
     auto judge_flags = [&]() -> int {
         if (dense && fl[3]) { h->dense_exact = true; return AQG_ERR_RANGE_MISS; }
-        if (use_wpart && fl[0]) { h->no_wide_part = true; return AQG_ERR_RANGE_MISS; }        // a partition larger than LDS: the HBM table, same hint
+        if (use_wpart && fl[0]) {
+            if (getenv("AQG_DEBUG_FLAGS")) fprintf(stderr, "aqg: wide partition plan gave up: flags %u %u %u %u, partition %u holds %u rows (n %u, hint %u)\n", fl[0], fl[1], fl[2], fl[3], fl[4], fl[5], n, hint);
+            h->no_wide_part = true; return AQG_ERR_RANGE_MISS;                                // a partition larger than LDS: the HBM table, same hint
+        }
         if (fl[0]) return AQG_ERR_OVERFLOW;
         G = fl[1];
         if (small_rank && G > 4096) return AQG_ERR_OVERFLOW;
@@ -1324,7 +1329,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         return AQG_OK;
     };
     auto read_flags = [&]() -> int {
-        AQG_HIP(ctx, hipMemcpyAsync(fl, gt.flags, 16, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipMemcpyAsync(fl, gt.flags, 32, hipMemcpyDeviceToHost, ctx->stream));
         AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return judge_flags();
     };
@@ -1401,7 +1406,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&sorted_emit_kernel), sparts.lds));
         const unsigned per_cu = sparts.lds <= 80 * 1024 ? 2 : 1;
         const unsigned sg = sparts.nparts < 4u * per_cu * ctx->num_cu ? sparts.nparts : 4u * per_cu * ctx->num_cu;
-        hipLaunchKernelGGL(sorted_emit_kernel, dim3(sg), dim3(512), sparts.lds, ctx->stream, sparts, G, n, as.nacc, (int)gt.has_count, (int)(ks.wide != 0), es, gt.flags);
+        static const unsigned se_block = getenv("AQG_SORTED_EMIT_BLOCK") ? (unsigned)atoi(getenv("AQG_SORTED_EMIT_BLOCK")) : 1024u;
+        hipLaunchKernelGGL(sorted_emit_kernel, dim3(sg), dim3(se_block), sparts.lds, ctx->stream, sparts, G, n, as.nacc, (int)gt.has_count, (int)(ks.wide != 0), es, gt.flags);
         AQG_TRY(aqg_check_launch(ctx, "sorted_emit_kernel"));
     } else if (defer || G) {
         unsigned eg = aqg_grid(ctx, defer ? gupper : G, 256, 1, 8);

@@ -619,6 +619,51 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
 __global__ void __launch_bounds__(256) pw_hash_kernel(KeySpec ks, uint32_t n, uint32_t* __restrict__ out) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = hash_wide(ks, i);
 }
+// the same for key columns that are all 4 bytes wide and 16-byte aligned (h2o Q10): four rows per lane by vector loads, 32-bit
+// multiplies only (murmur3's block mix and finaliser -- NOT the chain pw_agg hashes a partition's rows with: the slots inside a
+// partition must not follow from the bits that chose the partition).  (the generic pw_hash_kernel: 9.2 ms per 1e9 rows of six columns)
+struct Keys32 { const uint32_t* col[MAXKEYS]; int n; };
+__device__ inline uint32_t pw_mix32(uint32_t h, uint32_t k, uint32_t c1, uint32_t c2) {
+    k *= c1; k = (k << 15) | (k >> 17); k *= c2;
+    h ^= k; h = (h << 13) | (h >> 19);
+    return h * 5u + 0xE6546B64u;
+}
+__device__ inline uint32_t pw_fin32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; return h ^ (h >> 16); }
+// TWO 32-bit states with different multipliers: with one, the 1e11 distinct (id1, id2, id3) prefixes of h2o Q10 collide in the
+// state after three columns and stay collided, and the partition sizes grow a tail (one partition of 1164 rows where 954 + 6.4
+// sigma were allowed: the whole call fell back to the HBM table)
+__device__ inline uint32_t pw_hash_row(const uint32_t* k, int nk) {
+    uint32_t a = 0x2F0B4C9Du, b = 0x8A91E5C3u;
+    for (int j = 0; j < nk; ++j) { a = pw_mix32(a, k[j], 0xCC9E2D51u, 0x1B873593u); b = pw_mix32(b, k[j], 0x9E3779B1u, 0x85EBCA77u); }
+    return pw_fin32(a ^ pw_fin32(b));
+}
+__global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, uint32_t* __restrict__ out) {
+    const uint32_t nchunk = n >> 2;
+    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < nchunk; c += gridDim.x * 256) {
+        pack<uint32_t, 4> v[MAXKEYS];
+#pragma unroll
+        for (int k = 0; k < MAXKEYS; ++k) if (k < ks.n) v[k] = *reinterpret_cast<const pack<uint32_t, 4>*>(ks.col[k] + (size_t)c * 4);
+        pack<uint32_t, 4> a, b, h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a.v[j] = 0x2F0B4C9Du; b.v[j] = 0x8A91E5C3u; }
+#pragma unroll
+        for (int k = 0; k < MAXKEYS; ++k) {
+            if (k < ks.n) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a.v[j] = pw_mix32(a.v[j], v[k].v[j], 0xCC9E2D51u, 0x1B873593u); b.v[j] = pw_mix32(b.v[j], v[k].v[j], 0x9E3779B1u, 0x85EBCA77u); }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) h.v[j] = pw_fin32(a.v[j] ^ pw_fin32(b.v[j]));
+        *reinterpret_cast<pack<uint32_t, 4>*>(out + (size_t)c * 4) = h;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = ((size_t)nchunk << 2) + threadIdx.x;
+        uint32_t k[MAXKEYS];
+        for (int j = 0; j < ks.n; ++j) k[j] = ks.col[j][i];
+        out[i] = pw_hash_row(k, ks.n);
+    }
+}
 __global__ void __launch_bounds__(256) pn_gather_strided_kernel(const uint32_t* __restrict__ src, uint32_t stride, uint32_t count, uint32_t* __restrict__ dst) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) dst[i] = src[(size_t)i * stride];
 }
@@ -691,7 +736,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
         const uint32_t b = pstart[part], e = part + 1 < nparts ? pstart[part + 1] : ntotal;
         const uint32_t m = e - b;
         if (!m) continue;
-        if (m > R) { if (threadIdx.x == 0) out.flags[0] = 1; continue; }        // a partition larger than LDS holds: the host falls back
+        if (m > R) { if (threadIdx.x == 0) { out.flags[0] = 1; out.flags[4] = part; out.flags[5] = m; } continue; }   // a partition larger than LDS holds: the host falls back (flags 4, 5: which, how large)
         uint32_t myrow[RPT];
         uint64_t myval[NACC > 0 ? NACC : 1][RPT];
 #pragma unroll
@@ -770,7 +815,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
             if (rep[i] != i) continue;
             const uint32_t g = gbase + atomicAdd(&lemit, 1u);
             if (g >= out_cap) { out.flags[0] = 1; continue; }
-            *out.key_p(g) = (uint64_t)lfirst[i];                               // wide tuples: the key word is a representative ROW
+            if (out.kb) *out.key_p(g) = (uint64_t)lfirst[i];                   // wide tuples: the key word is a representative ROW (null: the ordering tail takes the first-row plane)
             *out.first_p(g) = lfirst[i];
             *out.count_p(g) = need_count ? lcount[i] : 0;
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) *out.acc_p(a, g) = lacc[(size_t)a * R + i];
@@ -1097,6 +1142,7 @@ static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n) {
     for (int k = 0; k < ks.nkeys; ++k) nkd += aqg_dtype_size(ks.dt[k]) <= 4 ? 1 : 2;
     if (nkd > 2 * MAXKEYS) return best;
     // workgroups per CU: three of 512 threads, two of 1024, one of 1024 -- the first that needs no more levels than the last
+    // (four workgroups of 512 -- 39 KB each, 128 x 128 x 128 partitions of ~720 rows -- measured 39 ms against 24-26 for three)
     const struct { size_t budget; int nt; } shapes[3] = {{52 * 1024, 512}, {78 * 1024, 1024}, {AGG_LDS, 1024}};
     for (int si = 2; si >= 0; --si) {
         WidePlan w;
@@ -1106,7 +1152,7 @@ static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n) {
         if (R > 3u * (uint32_t)w.nt) R = 3u * (uint32_t)w.nt;
         R &= ~7u;
         double mu = (double)R;
-        for (int it = 0; it < 8; ++it) mu = (double)R - 5.0 * sqrt(mu);
+        for (int it = 0; it < 8; ++it) mu = (double)R - 6.0 * sqrt(mu);       // (a million partitions: five sigma leave a quarter of the calls with one partition over)
         if (mu < 64) continue;
         const uint64_t P = (uint64_t)((double)n / mu) + 1;
         w.R = R;
@@ -1144,7 +1190,19 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     // the partition key: a 32-bit hash of the tuple
     uint32_t* h32;
     AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &h32));
-    hipLaunchKernelGGL(pw_hash_kernel, dim3(g4), dim3(256), 0, ctx->stream, ks, n, h32);
+    {
+        Keys32 k32;
+        memset(&k32, 0, sizeof k32);
+        bool all32 = true;
+        for (int k = 0; k < ks.nkeys; ++k) {
+            all32 = all32 && aqg_dtype_size(ks.dt[k]) == 4 && ((uintptr_t)ks.col[k] & 15) == 0;
+            k32.col[k] = static_cast<const uint32_t*>(ks.col[k]);
+        }
+        k32.n = ks.nkeys;
+        static const bool generic_hash = getenv("AQG_PW_GENERIC_HASH") != nullptr;
+        if (all32 && !generic_hash) hipLaunchKernelGGL(pw_hash32_kernel, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 16)), dim3(256), 0, ctx->stream, k32, n, h32);
+        else hipLaunchKernelGGL(pw_hash_kernel, dim3(g4), dim3(256), 0, ctx->stream, ks, n, h32);
+    }
     // source planes: the key columns as dwords (1- / 2-byte ones widened, 8-byte ones as two planes), then the distinct value columns
     struct Src { const void* p; int stride, off, bytes; };
     std::vector<Src> ksrc, vsrc;
@@ -1264,7 +1322,9 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         ops.opc[a] = opc;
     }
     const size_t lds = w.lds;
-    const unsigned per_cu = w.nt == 512 ? 3u : lds <= 78 * 1024 ? 2u : 1u;
+    unsigned per_cu = (unsigned)((160 * 1024) / (lds + 512));
+    if (per_cu > 2048u / (unsigned)w.nt) per_cu = 2048u / (unsigned)w.nt;
+    if (per_cu < 1) per_cu = 1;
     const unsigned grid = nseg < per_cu * (unsigned)ctx->num_cu ? nseg : per_cu * (unsigned)ctx->num_cu;
     auto launch = [&](auto kern) -> int {
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
