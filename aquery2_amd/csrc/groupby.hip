@@ -1267,7 +1267,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(aqg_dense_aggregate(ctx, ks, dspec, as, n, plan.need_count, gt));
     } else if (n && (use_wpart || use_part)) {
         const size_t mark = ctx->ws_off;
-        if (use_wpart) AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap));
+        if (use_wpart) AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed));
         else if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap));
         else if (p2_parts) AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap));
         else AQG_TRY(aqg_partition_aggregate(ctx, ks, as, n, pbits, part_lcap, plan.need_count, gt, gcap));
@@ -1319,8 +1319,13 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     auto judge_flags = [&]() -> int {
         if (dense && fl[3]) { h->dense_exact = true; return AQG_ERR_RANGE_MISS; }
         if (use_wpart && fl[0]) {
-            if (getenv("AQG_DEBUG_FLAGS")) fprintf(stderr, "aqg: wide partition plan gave up: flags %u %u %u %u, partition %u holds %u rows (n %u, hint %u)\n", fl[0], fl[1], fl[2], fl[3], fl[4], fl[5], n, hint);
-            h->no_wide_part = true; return AQG_ERR_RANGE_MISS;                                // a partition larger than LDS: the HBM table, same hint
+            // a partition larger than LDS holds (fl[5] rows).  A little over: chance (a million partitions sized at mean + 6 sigma) --
+            // ONE more try with another seed of the partition hash; far over, or over again: a tuple that dominates the input, which no
+            // seed spreads -- the HBM table, same hint
+            if (getenv("AQG_DEBUG_FLAGS")) fprintf(stderr, "aqg: wide partition plan gave up: flags %u %u %u %u, partition %u holds %u rows (n %u, hint %u, seed %u)\n", fl[0], fl[1], fl[2], fl[3], fl[4], fl[5], n, hint, h->wide_seed);
+            const uint32_t rcap = aqg_partitionw_rows(ks, as, n);
+            if (h->wide_seed == 0 && fl[5] && fl[5] <= rcap + rcap / 2) h->wide_seed = 0x5BD1E995u; else h->no_wide_part = true;
+            return AQG_ERR_RANGE_MISS;
         }
         if (fl[0]) return AQG_ERR_OVERFLOW;
         G = fl[1];
@@ -1470,7 +1475,8 @@ int run_with_retry(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n
     for (int attempt = 0; attempt < 12; ++attempt) {
         if (cur > n && n) cur = n;
         int rc = run_agg(ctx, ks, plan, n, (uint32_t)cur, for_build, h, gt_out, slot_gid_out, occ_out, dense_out);
-        if (rc == AQG_ERR_RANGE_MISS) rc = run_agg(ctx, ks, plan, n, (uint32_t)cur, for_build, h, gt_out, slot_gid_out, occ_out, dense_out);   // exact ranges now
+        // (exact key ranges now; or the wide-tuple plan with another hash seed, then without it: at most three repeats)
+        for (int again = 0; again < 3 && rc == AQG_ERR_RANGE_MISS; ++again) rc = run_agg(ctx, ks, plan, n, (uint32_t)cur, for_build, h, gt_out, slot_gid_out, occ_out, dense_out);
         if (rc != AQG_ERR_OVERFLOW) { if (rc == AQG_OK) h->hint_used = (uint32_t)cur; return rc; }
         if (n && cur >= n) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "group-by: table overflow at full capacity");
         cur *= 16;

@@ -616,8 +616,9 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
 // the representative.  The record's key word is the group's first row: emit fetches the key columns through it (the wide-tuple
 // convention of groupby.hip).  Sized by rows, not by groups: a tuple that dominates the input overflows its partition and the call
 // falls back to the HBM table.
-__global__ void __launch_bounds__(256) pw_hash_kernel(KeySpec ks, uint32_t n, uint32_t* __restrict__ out) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = hash_wide(ks, i);
+__device__ inline uint32_t pw_seeded(uint32_t h, uint32_t seed) { h ^= seed; h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; return h ^ (h >> 16); }
+__global__ void __launch_bounds__(256) pw_hash_kernel(KeySpec ks, uint32_t n, uint32_t seed, uint32_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const uint32_t h = hash_wide(ks, i); out[i] = seed ? pw_seeded(h, seed) : h; }
 }
 // the same for key columns that are all 4 bytes wide and 16-byte aligned (h2o Q10): four rows per lane by vector loads, 32-bit
 // multiplies only (murmur3's block mix and finaliser -- NOT the chain pw_agg hashes a partition's rows with: the slots inside a
@@ -632,12 +633,12 @@ __device__ inline uint32_t pw_fin32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu
 // TWO 32-bit states with different multipliers: with one, the 1e11 distinct (id1, id2, id3) prefixes of h2o Q10 collide in the
 // state after three columns and stay collided, and the partition sizes grow a tail (one partition of 1164 rows where 954 + 6.4
 // sigma were allowed: the whole call fell back to the HBM table)
-__device__ inline uint32_t pw_hash_row(const uint32_t* k, int nk) {
-    uint32_t a = 0x2F0B4C9Du, b = 0x8A91E5C3u;
+__device__ inline uint32_t pw_hash_row(const uint32_t* k, int nk, uint32_t seed) {
+    uint32_t a = 0x2F0B4C9Du ^ seed, b = 0x8A91E5C3u + seed;
     for (int j = 0; j < nk; ++j) { a = pw_mix32(a, k[j], 0xCC9E2D51u, 0x1B873593u); b = pw_mix32(b, k[j], 0x9E3779B1u, 0x85EBCA77u); }
     return pw_fin32(a ^ pw_fin32(b));
 }
-__global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, uint32_t* __restrict__ out) {
+__global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, uint32_t seed, uint32_t* __restrict__ out) {
     const uint32_t nchunk = n >> 2;
     for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < nchunk; c += gridDim.x * 256) {
         pack<uint32_t, 4> v[MAXKEYS];
@@ -645,7 +646,7 @@ __global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, u
         for (int k = 0; k < MAXKEYS; ++k) if (k < ks.n) v[k] = *reinterpret_cast<const pack<uint32_t, 4>*>(ks.col[k] + (size_t)c * 4);
         pack<uint32_t, 4> a, b, h;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a.v[j] = 0x2F0B4C9Du; b.v[j] = 0x8A91E5C3u; }
+        for (int j = 0; j < 4; ++j) { a.v[j] = 0x2F0B4C9Du ^ seed; b.v[j] = 0x8A91E5C3u + seed; }
 #pragma unroll
         for (int k = 0; k < MAXKEYS; ++k) {
             if (k < ks.n) {
@@ -661,7 +662,7 @@ __global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, u
         const size_t i = ((size_t)nchunk << 2) + threadIdx.x;
         uint32_t k[MAXKEYS];
         for (int j = 0; j < ks.n; ++j) k[j] = ks.col[j][i];
-        out[i] = pw_hash_row(k, ks.n);
+        out[i] = pw_hash_row(k, ks.n, seed);
     }
 }
 __global__ void __launch_bounds__(256) pn_gather_strided_kernel(const uint32_t* __restrict__ src, uint32_t stride, uint32_t count, uint32_t* __restrict__ dst) {
@@ -1152,7 +1153,8 @@ static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n) {
         if (R > 3u * (uint32_t)w.nt) R = 3u * (uint32_t)w.nt;
         R &= ~7u;
         double mu = (double)R;
-        for (int it = 0; it < 8; ++it) mu = (double)R - 6.0 * sqrt(mu);       // (a million partitions: five sigma leave a quarter of the calls with one partition over)
+        static const double sigmas = getenv("AQG_PW_SIGMA") ? atof(getenv("AQG_PW_SIGMA")) : 6.0;     // (tests: a small value makes partitions overflow by chance)
+        for (int it = 0; it < 8; ++it) mu = (double)R - sigmas * sqrt(mu);       // (a million partitions: five sigma leave a quarter of the calls with one partition over)
         if (mu < 64) continue;
         const uint64_t P = (uint64_t)((double)n / mu) + 1;
         w.R = R;
@@ -1170,6 +1172,7 @@ static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n) {
     return best;
 }
 bool aqg_partitionw_applies(const KeySpec& ks, const AccSpec& as, uint32_t n) { return ks.wide && pw_plan(ks, as, n).ok; }
+uint32_t aqg_partitionw_rows(const KeySpec& ks, const AccSpec& as, uint32_t n) { return pw_plan(ks, as, n).R; }
 
 size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as) {
     const WidePlan w = pw_plan(ks, as, n);
@@ -1181,7 +1184,7 @@ size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
     return ((size_t)n + 64) * per_row + 256 * (16 + 8 * MAXACC + 8 * MAXKEYS) + ((size_t)w.P + 4096) * 24 + ((size_t)n / P2_PT + (size_t)w.P + 64) * 8 + 65536;
 }
 
-int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap) {
+int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap, uint32_t seed) {
     const WidePlan w = pw_plan(ks, as, n);
     if (!w.ok) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "wide-tuple partitioned group-by: the input does not fit 128 x 128 x 128 partitions");
     ValCols vc;
@@ -1200,8 +1203,8 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         }
         k32.n = ks.nkeys;
         static const bool generic_hash = getenv("AQG_PW_GENERIC_HASH") != nullptr;
-        if (all32 && !generic_hash) hipLaunchKernelGGL(pw_hash32_kernel, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 16)), dim3(256), 0, ctx->stream, k32, n, h32);
-        else hipLaunchKernelGGL(pw_hash_kernel, dim3(g4), dim3(256), 0, ctx->stream, ks, n, h32);
+        if (all32 && !generic_hash) hipLaunchKernelGGL(pw_hash32_kernel, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 16)), dim3(256), 0, ctx->stream, k32, n, seed, h32);
+        else hipLaunchKernelGGL(pw_hash_kernel, dim3(g4), dim3(256), 0, ctx->stream, ks, n, seed, h32);
     }
     // source planes: the key columns as dwords (1- / 2-byte ones widened, 8-byte ones as two planes), then the distinct value columns
     struct Src { const void* p; int stride, off, bytes; };

@@ -329,3 +329,32 @@ def test_wide_tuples_through_the_hash_partition_pipeline(gpu, oracle):
     gb = gpu.groupby_agg(dom, [ck.RED_COUNT], [v1], hint=n)
     assert gb.ngroups == o3["ngroups"] and np.array_equal(gb.first_rows(), o3["first_rows"]) and np.array_equal(gb.counts(), o3["counts"])
     gb.destroy()
+
+
+def test_wide_partition_overflow_by_chance_retries_with_another_seed_then_falls_back():
+    """partitions sized far too tightly (AQG_PW_SIGMA = -2: below the mean): a partition is over by a little, the plan is tried once
+    more with another seed of the partition hash, is over again and the call falls back to the HBM table -- three attempts, one exact
+    result.  A fresh process: the sizing knob is read once."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+import numpy as np
+sys.path.insert(0, "tests")
+import aquery2_amd, checker as ck
+gpu, oracle = aquery2_amd.Device(0), ck.load_oracle()
+rng = np.random.default_rng(11)
+n = 2_400_007
+ids = [rng.integers(1, 101, n).astype(np.int32), rng.integers(1, n // 100, n).astype(np.int32), rng.integers(1, 101, n).astype(np.int32), rng.integers(1, n // 100, n).astype(np.int32)]
+v1 = rng.integers(-5, 6, n).astype(np.int32)
+o = oracle.groupby(ids)
+gb = gpu.groupby_agg(ids, [ck.RED_SUM, ck.RED_COUNT], [v1, v1], hint=n)
+assert gb.ngroups == o["ngroups"] and np.array_equal(gb.first_rows(), o["first_rows"]) and np.array_equal(gb.counts(), o["counts"])
+assert np.array_equal(ck.i128_to_int(gb.result(0, ck.RED_SUM, ck.INT32)), ck.i128_to_int(oracle.grouped_reduce(ck.RED_SUM, v1, o)))
+print("OK", gb.ngroups)
+'''
+    env = dict(os.environ, AQG_PW_SIGMA="-2", AQG_DEBUG_FLAGS="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]
+    gave_up = [l for l in out.stderr.splitlines() if "wide partition plan gave up" in l]
+    assert len(gave_up) == 2 and "seed 0)" in gave_up[0] and "seed 0)" not in gave_up[1], out.stderr[-2000:]
