@@ -79,6 +79,9 @@ int aqg_host_stage(aqg_ctx* ctx, size_t bytes, void** out);
 // in-place exclusive scan of `count` uint32 words; bsum: scratch of ceil(count/2048) words (postproc.hip)
 int aqg_exclusive_scan_u32(aqg_ctx* ctx, uint32_t* d, uint64_t count, uint32_t* bsum);
 
+// internal aggregate of aqg_groupby_agg (not in aqg.h): the sum of squares, typed like SUM -- the second moment the sharded call ships for VAR / STDDEV
+constexpr int AQG_RED_SUMSQ = 64;
+
 // HIP events around the dominant kernel of a call (read back by aqg_last_kernel_ms)
 static inline void aqg_kernel_timer_begin(aqg_ctx* ctx) { if (!ctx->evk_frozen) (void)hipEventRecord(ctx->evk0, ctx->stream); }
 static inline void aqg_kernel_timer_end(aqg_ctx* ctx) { if (!ctx->evk_frozen) { (void)hipEventRecord(ctx->evk1, ctx->stream); ctx->evk_valid = true; } }

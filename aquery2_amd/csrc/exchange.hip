@@ -7,7 +7,8 @@
 //                              caller-supplied all-gather (tests and rehearsals on one GPU, hosts with their own transport)
 //   aqg_groupby_agg_sharded    group-by + aggregates over THIS rank's row range, then ONE all-gather of the shard's group table
 //                              -- k key columns, the global first row, one partial per aggregate (SUM -> sum, COUNT -> count,
-//                              MIN / MAX -> itself, AVG -> sum and count) -- and a re-aggregation of the concatenation on every
+//                              MIN / MAX -> itself, AVG -> sum and count, VAR / STDDEV -> sum, sum of squares and count; 128-bit
+//                              partials as two 8-byte columns) -- and a re-aggregation of the concatenation on every
 //                              rank.  Shards are contiguous row ranges gathered in rank order, so first occurrence in the
 //                              concatenation is the global first occurrence: the merged groups come out in the reference's order
 //                              (server/hasher.h:176-198) without any row id but each group's first crossing the wire.
@@ -21,7 +22,8 @@
 
 namespace {
 
-constexpr int MAXPART = 2 * MAXAGG;      // partial columns of one exchange (AVG ships two)
+constexpr int MAXPART = 2 * MAXAGG;      // payload columns of one exchange (AVG ships two, a 128-bit partial two)
+constexpr int DT_HI128 = 1001;           // pseudo dtype of a payload column: the HIGH 8 bytes of a 128-bit result column
 
 // ---- RCCL through dlopen ------------------------------------------------------------------------------------------------------
 struct NcclId { char internal[128]; };
@@ -47,7 +49,10 @@ Rccl* rccl(std::string* err) {
     return &r;
 }
 
-struct Partial { int local_op; int val_dt; int val_index; int part_dt; int merge_op; };   // one shipped column
+// one partial of the local group-by.  `wide`: its result is a 128-bit integer that does not fit 64 bits per shard (sums of 8-byte
+// integers, sums of squares): it travels as two payload columns -- low halves summed as uint64, high halves as int64 / uint64 -- and
+// total = (sum of the high halves << 64) + sum of the low halves, all mod 2^128
+struct Partial { int local_op; int val_dt; int val_index; int part_dt; int merge_op; int wide; int col0; };   // col0: its first payload column
 
 } // namespace
 
@@ -61,6 +66,10 @@ struct aqg_comm {
     void *send = nullptr, *recv = nullptr, *cat = nullptr, *hdr = nullptr;
     size_t send_cap = 0, recv_cap = 0, cat_cap = 0, hdr_cap = 0;
     aqg_groupby *local = nullptr, *merged = nullptr;
+    aqg_groupby* merged_x[3] = {nullptr, nullptr, nullptr};     // further merge calls when one cannot hold all payload columns (8 accumulators per call)
+    // the merged columns after exchange_core: [0] global first rows (int64), [1 + c] payload column c re-aggregated
+    const void* mres[1 + 2 * MAXAGG] = {};
+    int mres_dt[1 + 2 * MAXAGG] = {};
 };
 
 namespace {
@@ -96,6 +105,7 @@ __device__ inline uint64_t load_native(int dt, const void* col, size_t i) {
     case AQG_UINT8: case AQG_BOOL: return static_cast<const uint8_t*>(col)[i];
     case AQG_UINT16: return static_cast<const uint16_t*>(col)[i];
     case AQG_UINT32: case AQG_FLOAT: return static_cast<const uint32_t*>(col)[i];
+    case DT_HI128: return static_cast<const uint64_t*>(col)[2 * i + 1];
     case AQG_INT128: case AQG_UINT128: return static_cast<const uint64_t*>(col)[2 * i];          // low half: partial sums of <= 4-byte integers over < 2^32 rows fit
     default: return static_cast<const uint64_t*>(col)[i];
     }
@@ -154,25 +164,50 @@ __global__ void __launch_bounds__(256) xunpack_kernel(const uint64_t* __restrict
 struct FinalSpec {
     int nagg;
     int op[MAXAGG], dt[MAXAGG];
-    const void* a[MAXAGG];            // merged partial (SUM / MIN / MAX / COUNT), or the merged sum of AVG
-    const void* b[MAXAGG];            // merged count of AVG (128-bit)
+    const void* a[MAXAGG];            // merged partial (SUM / MIN / MAX / COUNT), or the merged sum of AVG / VAR (low halves when wide)
+    const void* a_hi[MAXAGG];         // merged high halves of a wide sum (null: `a` is the whole sum)
+    const void* b[MAXAGG];            // merged count of AVG / VAR (128-bit)
+    const void* q[MAXAGG];            // VAR / STDDEV: merged sum of squares (double, or the low halves of the 128-bit one)
+    const void* q_hi[MAXAGG];         //               ... its high halves (integers)
     void* out[MAXAGG];
     int out_size[MAXAGG];
 };
+// (sum of the high halves << 64) + sum of the low halves, mod 2^128; both sums are 128-bit results of the merge
+__device__ inline aqg_i128 join_halves(const void* lo, const void* hi, uint32_t g) {
+    const aqg_i128 l = static_cast<const aqg_i128*>(lo)[g], h = static_cast<const aqg_i128*>(hi)[g];
+    return {l.lo, h.lo + l.hi};
+}
+__device__ inline aqg_i128 xmul_128(aqg_i128 a, aqg_i128 b) { return {a.lo * b.lo, __umul64hi(a.lo, b.lo) + a.lo * b.hi + a.hi * b.lo}; }
 __global__ void __launch_bounds__(256) xfinal_kernel(FinalSpec fs, uint32_t G) {
     for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < G; g += gridDim.x * 256) {
         for (int j = 0; j < fs.nagg; ++j) {
             const bool fp = fs.dt[j] == AQG_FLOAT || fs.dt[j] == AQG_DOUBLE;
             const bool uns = fs.dt[j] == AQG_UINT8 || fs.dt[j] == AQG_UINT16 || fs.dt[j] == AQG_UINT32 || fs.dt[j] == AQG_UINT64 || fs.dt[j] == AQG_BOOL;
+            auto int_sum = [&]() -> aqg_i128 { return fs.a_hi[j] ? join_halves(fs.a[j], fs.a_hi[j], g) : static_cast<const aqg_i128*>(fs.a[j])[g]; };
+            auto to_double = [&](aqg_i128 v) -> double { return uns ? u128_to_double(v.hi, v.lo) : i128_to_double(v); };
             switch (fs.op[j]) {
             case AQG_RED_COUNT: static_cast<uint64_t*>(fs.out[j])[g] = static_cast<const aqg_i128*>(fs.a[j])[g].lo; break;   // sum of uint32 counts: unsigned 128-bit
             case AQG_RED_AVG: {                                               // sum / (double)size (aggregations.h:28-32)
                 const aqg_i128 cn = static_cast<const aqg_i128*>(fs.b[j])[g];
-                double s;
-                if (fp) s = static_cast<const double*>(fs.a[j])[g];
-                else { const aqg_i128 v = static_cast<const aqg_i128*>(fs.a[j])[g]; s = uns ? u128_to_double(v.hi, v.lo) : i128_to_double(v); }
+                const double s = fp ? static_cast<const double*>(fs.a[j])[g] : to_double(int_sum());
                 static_cast<double*>(fs.out[j])[g] = s / (double)cn.lo;
             } break;
+            case AQG_RED_VAR: case AQG_RED_STDDEV: {                          // (ssq - s*s/(double)(n+1)) / (double)(n+1), as emit_record (groupby.hip)
+                const double np1 = (double)(static_cast<const aqg_i128*>(fs.b[j])[g].lo + 1);
+                double d;
+                if (fp) {
+                    const double sd = static_cast<const double*>(fs.a[j])[g], qq = static_cast<const double*>(fs.q[j])[g];
+                    d = (qq - sd * sd / np1) / np1;
+                } else {
+                    const aqg_i128 sm = int_sum(), qq = join_halves(fs.q[j], fs.q_hi[j], g);
+                    const aqg_i128 ss = xmul_128(sm, sm);                     // s * s in the 128-bit LongType (wraps like the reference)
+                    d = (to_double(qq) - to_double(ss) / np1) / np1;
+                }
+                static_cast<double*>(fs.out[j])[g] = fs.op[j] == AQG_RED_STDDEV ? sqrt(d) : d;
+            } break;
+            case AQG_RED_SUM:
+                if (!fp && fs.a_hi[j]) { static_cast<aqg_i128*>(fs.out[j])[g] = int_sum(); break; }
+                [[fallthrough]];
             default: {                                                        // SUM / MIN / MAX: the merged column is the result
                 const unsigned char* src = static_cast<const unsigned char*>(fs.a[j]) + (size_t)g * fs.out_size[j];
                 unsigned char* dst = static_cast<unsigned char*>(fs.out[j]) + (size_t)g * fs.out_size[j];
@@ -185,8 +220,9 @@ __global__ void __launch_bounds__(256) xfinal_kernel(FinalSpec fs, uint32_t G) {
 
 // steps 2-4 of the sharded group-by over an existing shard table L (keys, 32-bit first rows, one result column per partial):
 // sizes the payload, packs, ONE all-gather, concatenates, re-aggregates into comm->merged (aggregate 0 = MIN of the global first rows)
+// payload column p reads result column src_res[p] of L (null: p itself), its high 8 bytes when src_hi[p]
 int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtypes, int nparts, const int* part_dt, const int* merge_op,
-                  uint64_t row_base, uint32_t max_groups_hint, uint32_t gmax) {
+                  uint64_t row_base, uint32_t max_groups_hint, uint32_t gmax, const int* src_res = nullptr, const int* src_hi = nullptr) {
     aqg_ctx* ctx = comm->ctx;
     const uint32_t G = L->ngroups;
     // ---- 2. capacity of the exchange: the caller's bound, or the largest shard table (one 8-byte all-gather and a host read) -------
@@ -218,7 +254,10 @@ int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtyp
     ps.ncols = ncols; ps.nkeys = nkeys; ps.row_base = row_base;
     for (int k = 0; k < nkeys; ++k) { ps.src[k] = L->keys_out[k]; ps.src_dt[k] = key_dtypes[k]; }
     ps.src[nkeys] = L->first_rows; ps.src_dt[nkeys] = AQG_UINT32;
-    for (int p = 0; p < nparts; ++p) { ps.src[nkeys + 1 + p] = L->results[p]; ps.src_dt[nkeys + 1 + p] = L->res_dt[p]; }
+    for (int p = 0; p < nparts; ++p) {
+        const int r = src_res ? src_res[p] : p;
+        ps.src[nkeys + 1 + p] = L->results[r]; ps.src_dt[nkeys + 1 + p] = src_hi && src_hi[p] ? DT_HI128 : L->res_dt[r];
+    }
     hipLaunchKernelGGL(xpack_kernel, dim3(aqg_grid(ctx, (uint64_t)ncols * G + 1, 256, 2, 4)), dim3(256), 0, ctx->stream, ps, G, gcap, static_cast<uint64_t*>(comm->send));
     AQG_TRY(aqg_check_launch(ctx, "xpack_kernel"));
     AQG_TRY(allgather(comm, comm->send, comm->recv, bytes));
@@ -248,16 +287,33 @@ int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtyp
     }
     if (total > AQG_MAX_ROWS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: more shard groups than AQG_MAX_ROWS");
     // ---- 4. re-aggregate the concatenation (first occurrence in it = global first occurrence) ------------------------------------------
-    int mops[MAXAGG], mdts[MAXAGG];
-    const void* mvals[MAXAGG];
     const void* mkeys[MAXKEYS];
     for (int k = 0; k < nkeys; ++k) mkeys[k] = us.dst[k];
-    mops[0] = AQG_RED_MIN; mdts[0] = AQG_INT64; mvals[0] = us.dst[nkeys];
-    for (int p = 0; p < nparts; ++p) { mops[1 + p] = merge_op[p]; mdts[1 + p] = part_dt[p]; mvals[1 + p] = us.dst[nkeys + 1 + p]; }
     uint64_t mhint = total < 64 ? 64 : total;
     if (max_groups_hint && (uint64_t)max_groups_hint * world < mhint) mhint = (uint64_t)max_groups_hint * world;
+    // one merge call holds 8 aggregates and 8 accumulators (an 8-byte SUM takes two: its result is 128 bits): the payload columns go
+    // through as many calls over the same concatenation as that takes -- the groups come out in the same order every time
+    auto acc_cost = [](int dt, int op) { return op == AQG_RED_SUM && (dt == AQG_INT64 || dt == AQG_UINT64) ? 2 : 1; };
     ctx->evk_frozen = true;                  // aqg_last_kernel_ms keeps naming the pass over the shard's rows
-    const int mrc = aqg_groupby_agg(ctx, nkeys, key_dtypes, mkeys, nparts + 1, mops, mdts, mvals, (uint32_t)total, (uint32_t)mhint, &comm->merged);
+    int c = 0, batch = 0, mrc = AQG_OK;
+    uint32_t mgroups = 0;
+    do {
+        int mops[MAXAGG], mdts[MAXAGG], na = 0, acc = 0, col_of[MAXAGG];
+        const void* mvals[MAXAGG];
+        if (batch == 0) { mops[0] = AQG_RED_MIN; mdts[0] = AQG_INT64; mvals[0] = us.dst[nkeys]; col_of[0] = -1; na = 1; acc = 1; }
+        while (c < nparts && na < MAXAGG && acc + acc_cost(part_dt[c], merge_op[c]) <= MAXACC) {
+            mops[na] = merge_op[c]; mdts[na] = part_dt[c]; mvals[na] = us.dst[nkeys + 1 + c]; col_of[na] = c;
+            acc += acc_cost(part_dt[c], merge_op[c]); ++na; ++c;
+        }
+        if (batch > 3) { mrc = aqg_fail(ctx, AQG_ERR_ARG, "exchange: too many payload columns"); break; }
+        aqg_groupby** slot = batch == 0 ? &comm->merged : &comm->merged_x[batch - 1];
+        mrc = aqg_groupby_agg(ctx, nkeys, key_dtypes, mkeys, na, mops, mdts, mvals, (uint32_t)total, (uint32_t)mhint, slot);
+        if (mrc != AQG_OK) break;
+        if (batch == 0) mgroups = (*slot)->ngroups;
+        else if ((*slot)->ngroups != mgroups) { mrc = aqg_fail(ctx, AQG_ERR_HIP, "exchange: merge calls disagree on the group count"); break; }
+        for (int a = 0; a < na; ++a) { comm->mres[1 + col_of[a]] = (*slot)->results[a]; comm->mres_dt[1 + col_of[a]] = (*slot)->res_dt[a]; }
+        ++batch;
+    } while (c < nparts);
     ctx->evk_frozen = false;
     AQG_TRY(mrc);
     return AQG_OK;
@@ -312,6 +368,7 @@ void aqg_comm_destroy(aqg_comm* c) {
     for (void* p : {c->send, c->recv, c->cat, c->hdr}) if (p) hipFree(p);
     if (c->local) aqg_groupby_destroy(c->local);
     if (c->merged) aqg_groupby_destroy(c->merged);
+    for (aqg_groupby* m : c->merged_x) if (m) aqg_groupby_destroy(m);
     delete c;
 }
 int aqg_comm_rank(const aqg_comm* c) { return c ? c->rank : -1; }
@@ -320,7 +377,7 @@ int aqg_comm_world(const aqg_comm* c) { return c ? c->world : 0; }
 const int64_t* aqg_groupby_first_rows64(const aqg_groupby* g) { return g ? g->first_rows64 : nullptr; }
 
 int aqg_groupby_exchange(aqg_comm* comm, aqg_groupby* local, int nparts, const int* merge_ops, uint64_t row_base, uint32_t gmax, aqg_groupby** out) {
-    if (!comm || !local || !out || nparts < 0 || nparts + 1 > MAXAGG || nparts > local->nagg) return aqg_fail(comm ? comm->ctx : nullptr, AQG_ERR_ARG, "aqg_groupby_exchange: bad argument (at most 7 partial columns)");
+    if (!comm || !local || !out || nparts < 0 || nparts > MAXAGG || nparts > local->nagg) return aqg_fail(comm ? comm->ctx : nullptr, AQG_ERR_ARG, "aqg_groupby_exchange: bad argument");
     aqg_ctx* ctx = comm->ctx;
     if (local->nuser) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_exchange: plain integer key columns only");
     int pdt[MAXPART];
@@ -345,11 +402,11 @@ int aqg_groupby_exchange(aqg_comm* comm, aqg_groupby* local, int nparts, const i
         if (rc == AQG_OK) rc = d2d(H->keys_out[k], M->keys_out[k], (size_t)M->ngroups * aqg_dtype_size(local->key_dt[k]));
     }
     if (rc == AQG_OK) rc = grow(ctx, reinterpret_cast<void**>(&H->first_rows64), &H->cap_first64, GG * 8);
-    if (rc == AQG_OK) rc = d2d(H->first_rows64, M->results[0], (size_t)M->ngroups * 8);
+    if (rc == AQG_OK) rc = d2d(H->first_rows64, comm->mres[0], (size_t)M->ngroups * 8);
     for (int p = 0; p < nparts && rc == AQG_OK; ++p) {
-        H->res_dt[p] = M->res_dt[1 + p];
+        H->res_dt[p] = comm->mres_dt[1 + p];
         rc = grow(ctx, &H->results[p], &H->cap_results[p], GG * 16);
-        if (rc == AQG_OK) rc = d2d(H->results[p], M->results[1 + p], (size_t)M->ngroups * aqg_dtype_size(M->res_dt[1 + p]));
+        if (rc == AQG_OK) rc = d2d(H->results[p], comm->mres[1 + p], (size_t)M->ngroups * aqg_dtype_size(comm->mres_dt[1 + p]));
     }
     if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(H); return rc == AQG_ERR_HIP ? aqg_fail(ctx, rc, "aqg_groupby_exchange: device copy failed") : rc; }
     *out = H;
@@ -361,31 +418,45 @@ int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, co
     if (!comm || !out) return AQG_ERR_ARG;
     aqg_ctx* ctx = comm->ctx;
     if (nkeys < 1 || nkeys > MAXKEYS || naggs < 0 || naggs > MAXAGG) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_agg_sharded: 1..8 key columns, 0..8 aggregates");
-    // ---- what travels: one partial per aggregate (AVG: sum and count), identical (op, column) pairs once -------------------------
+    // ---- what travels: one partial per aggregate (AVG: sum and count; VAR / STDDEV: sum, sum of squares, count), identical (op, column) pairs once
     Partial parts[MAXPART];
-    int nparts = 0, part_of[MAXAGG], part2_of[MAXAGG];
+    int nparts = 0, ncols = 0, part_of[MAXAGG], cnt_of[MAXAGG], sq_of[MAXAGG];
+    auto is_unsigned = [](int dt) { return dt == AQG_UINT8 || dt == AQG_UINT16 || dt == AQG_UINT32 || dt == AQG_UINT64 || dt == AQG_BOOL; };
     auto add_part = [&](int lop, int j) -> int {
         const int dt = val_dtypes[j];
         for (int p = 0; p < nparts; ++p) if (parts[p].local_op == lop && (lop == AQG_RED_COUNT || (vals[parts[p].val_index] == vals[j] && parts[p].val_dt == dt))) return p;
+        if (nparts >= MAXPART) return -1;
         Partial& P = parts[nparts];
-        P.local_op = lop; P.val_dt = dt; P.val_index = j;
-        if (lop == AQG_RED_SUM) { P.part_dt = is_fp(dt) ? AQG_DOUBLE : AQG_INT64; P.merge_op = AQG_RED_SUM; }
+        P.local_op = lop; P.val_dt = dt; P.val_index = j; P.wide = 0; P.col0 = ncols;
+        if (lop == AQG_RED_SUM || lop == AQG_RED_SUMSQ) {
+            P.merge_op = AQG_RED_SUM;
+            if (is_fp(dt)) P.part_dt = AQG_DOUBLE;
+            else if (lop == AQG_RED_SUM && small_int(dt)) P.part_dt = AQG_INT64;       // a shard's sum of <= 4-byte integers over < 2^32 rows fits 64 bits
+            else { P.part_dt = is_unsigned(dt) ? AQG_UINT64 : AQG_INT64; P.wide = 1; }  // (dtype of the HIGH halves; the low ones are uint64)
+        }
         else if (lop == AQG_RED_COUNT) { P.part_dt = AQG_UINT32; P.merge_op = AQG_RED_SUM; }   // a shard has < 2^32 rows: one accumulator in the merge
         else { P.part_dt = dt; P.merge_op = lop; }
+        ncols += P.wide ? 2 : 1;
         return nparts++;
     };
     for (int j = 0; j < naggs; ++j) {
         const int op = ops[j], dt = val_dtypes[j];
-        part_of[j] = part2_of[j] = -1;
-        if (op != AQG_RED_COUNT && !(small_int(dt) || is_fp(dt) || ((op == AQG_RED_MIN || op == AQG_RED_MAX) && (dt == AQG_INT64 || dt == AQG_UINT64))))
-            return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: SUM / AVG over 1-, 2-, 4-byte integers and floating columns; MIN / MAX also over 8-byte integers");
+        part_of[j] = cnt_of[j] = sq_of[j] = -1;
+        const bool num = small_int(dt) || is_fp(dt) || dt == AQG_INT64 || dt == AQG_UINT64;
+        if (op != AQG_RED_COUNT && !num) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: integer columns of 1 to 8 bytes and floating columns");
+        bool ok = true;
         switch (op) {
-        case AQG_RED_SUM: case AQG_RED_MIN: case AQG_RED_MAX: case AQG_RED_COUNT: part_of[j] = add_part(op, j); break;
-        case AQG_RED_AVG: part_of[j] = add_part(AQG_RED_SUM, j); part2_of[j] = add_part(AQG_RED_COUNT, j); break;
-        default: return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: SUM / COUNT / MIN / MAX / AVG (VAR / STDDEV / FIRST / LAST do not decompose through this call)");
+        case AQG_RED_SUM: case AQG_RED_MIN: case AQG_RED_MAX: case AQG_RED_COUNT: part_of[j] = add_part(op, j); ok = part_of[j] >= 0; break;
+        case AQG_RED_AVG: part_of[j] = add_part(AQG_RED_SUM, j); cnt_of[j] = add_part(AQG_RED_COUNT, j); ok = part_of[j] >= 0 && cnt_of[j] >= 0; break;
+        case AQG_RED_VAR: case AQG_RED_STDDEV:
+            part_of[j] = add_part(AQG_RED_SUM, j); sq_of[j] = add_part(AQG_RED_SUMSQ, j); cnt_of[j] = add_part(AQG_RED_COUNT, j);
+            ok = part_of[j] >= 0 && sq_of[j] >= 0 && cnt_of[j] >= 0;
+            break;
+        default: return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: SUM / COUNT / MIN / MAX / AVG / VAR / STDDEV (FIRST / LAST do not decompose through this call)");
         }
+        if (!ok) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_agg_sharded: too many partial columns");
     }
-    if (nparts + 1 > MAXAGG) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_agg_sharded: too many partial columns (7 per call)");
+    if (nparts > MAXAGG || ncols > MAXPART) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_agg_sharded: too many partials (8 local aggregates, 16 payload columns per call; a 128-bit partial takes two columns)");
     // ---- 1. this shard ------------------------------------------------------------------------------------------------------------
     int lops[MAXAGG], ldts[MAXAGG];
     const void* lvals[MAXAGG];
@@ -393,9 +464,13 @@ int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, co
     AQG_TRY(aqg_groupby_agg(ctx, nkeys, key_dtypes, keys, nparts, lops, ldts, lvals, n, max_groups_hint, &comm->local));
     aqg_groupby* L = comm->local;
     if (L->nuser) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: plain integer key columns only (dates / times / 128-bit / floating keys: single-GPU calls)");
-    int pdt[MAXPART], mop[MAXPART];
-    for (int p = 0; p < nparts; ++p) { pdt[p] = parts[p].part_dt; mop[p] = parts[p].merge_op; }
-    AQG_TRY(exchange_core(comm, L, nkeys, key_dtypes, nparts, pdt, mop, row_base, max_groups_hint, gmax));
+    int pdt[MAXPART], mop[MAXPART], sres[MAXPART], shi[MAXPART];
+    for (int p = 0; p < nparts; ++p) {
+        int c = parts[p].col0;
+        if (parts[p].wide) { pdt[c] = AQG_UINT64; mop[c] = AQG_RED_SUM; sres[c] = p; shi[c] = 0; ++c; }      // low halves
+        pdt[c] = parts[p].part_dt; mop[c] = parts[p].merge_op; sres[c] = p; shi[c] = parts[p].wide;
+    }
+    AQG_TRY(exchange_core(comm, L, nkeys, key_dtypes, ncols, pdt, mop, row_base, max_groups_hint, gmax, sres, shi));
     aqg_groupby* M = comm->merged;
     // ---- 5. the result handle: keys and global first rows of the merged table, every aggregate in its own result dtype --------------
     aqg_groupby* H = *out ? *out : new aqg_groupby();
@@ -410,7 +485,7 @@ int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, co
         if (rc == AQG_OK && M->ngroups) rc = hipMemcpyAsync(H->keys_out[k], M->keys_out[k], (size_t)M->ngroups * aqg_dtype_size(key_dtypes[k]), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? AQG_OK : AQG_ERR_HIP;
     }
     if (rc == AQG_OK) rc = grow_h(reinterpret_cast<void**>(&H->first_rows64), &H->cap_first64, GG * 8);
-    if (rc == AQG_OK && M->ngroups) rc = hipMemcpyAsync(H->first_rows64, M->results[0], (size_t)M->ngroups * 8, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? AQG_OK : AQG_ERR_HIP;
+    if (rc == AQG_OK && M->ngroups) rc = hipMemcpyAsync(H->first_rows64, comm->mres[0], (size_t)M->ngroups * 8, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? AQG_OK : AQG_ERR_HIP;
     FinalSpec fs;
     memset(&fs, 0, sizeof fs);
     fs.nagg = naggs;
@@ -418,8 +493,15 @@ int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, co
         H->res_dt[j] = aqg_reduce_out_dtype(ops[j], val_dtypes[j]);
         rc = grow_h(&H->results[j], &H->cap_results[j], GG * 16);
         fs.op[j] = ops[j]; fs.dt[j] = val_dtypes[j]; fs.out[j] = H->results[j]; fs.out_size[j] = (int)aqg_dtype_size(H->res_dt[j]);
-        fs.a[j] = M->results[1 + part_of[j]];
-        fs.b[j] = part2_of[j] >= 0 ? M->results[1 + part2_of[j]] : nullptr;
+        const Partial& P = parts[part_of[j]];
+        fs.a[j] = comm->mres[1 + P.col0];
+        fs.a_hi[j] = P.wide ? comm->mres[1 + P.col0 + 1] : nullptr;
+        fs.b[j] = cnt_of[j] >= 0 ? comm->mres[1 + parts[cnt_of[j]].col0] : nullptr;
+        if (sq_of[j] >= 0) {
+            const Partial& Q = parts[sq_of[j]];
+            fs.q[j] = comm->mres[1 + Q.col0];
+            fs.q_hi[j] = Q.wide ? comm->mres[1 + Q.col0 + 1] : nullptr;
+        }
     }
     if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(H); return rc == AQG_ERR_HIP ? aqg_fail(ctx, rc, "aqg_groupby_agg_sharded: device copy failed") : rc; }
     if (M->ngroups && naggs) hipLaunchKernelGGL(xfinal_kernel, dim3(aqg_grid(ctx, M->ngroups, 256, 1, 4)), dim3(256), 0, ctx->stream, fs, M->ngroups);

@@ -645,7 +645,7 @@ __device__ inline void emit_record(const GTable& gt, uint32_t s, uint32_t g, con
         };
         auto to_double = [&](aqg_i128 v) -> double { return vc == VC_U ? u128_to_double(v.hi, v.lo) : i128_to_double(v); };
         switch (a.op) {
-        case AQG_RED_SUM:                                               // -> GetLongType
+        case AQG_RED_SUM: case AQG_RED_SUMSQ:                           // -> GetLongType
             if (vc == VC_F) static_cast<double*>(a.out)[g] = __builtin_bit_cast(double, v0);
             else static_cast<aqg_i128*>(a.out)[g] = sum128(a.acc0, a.acc1);
             break;
@@ -1054,6 +1054,10 @@ int make_plan(aqg_ctx* ctx, int naggs, const int* ops, const int* dts, const voi
                 else { a.acc2 = add_acc(p, addk, dt, vals[j], 1); ok = ok && a.acc2 >= 0; }
             }
             if (op != AQG_RED_SUM) p->need_count = 1;
+            break;
+        case AQG_RED_SUMSQ:                                               // (internal: the accumulators VAR calls acc2 / acc3, emitted like a SUM)
+            if (wide) { a.acc0 = add_acc(p, addk, dt, vals[j], 1, 1); a.acc1 = add_acc(p, addk, dt, vals[j], 1, 2); ok = a.acc0 >= 0 && a.acc1 >= 0; }
+            else { a.acc0 = add_acc(p, addk, dt, vals[j], 1); ok = a.acc0 >= 0; }
             break;
         case AQG_RED_MIN: a.acc0 = add_acc(p, ACC_MIN, dt, vals[j], 0); ok = a.acc0 >= 0; break;
         case AQG_RED_MAX: a.acc0 = add_acc(p, ACC_MAX, dt, vals[j], 0); ok = a.acc0 >= 0; break;

@@ -250,7 +250,7 @@ extern "C" {
 int aqg_reduce_out_dtype(int op, int t) {
     if (!dt_is_num(t)) return AQG_ERROR;
     switch (op) {
-    case AQG_RED_SUM: return aqg_long_type(t);
+    case AQG_RED_SUM: case AQG_RED_SUMSQ: return aqg_long_type(t);
     case AQG_RED_MIN: case AQG_RED_MAX: case AQG_RED_FIRST: case AQG_RED_LAST: return t;
     case AQG_RED_COUNT: return AQG_UINT64;
     case AQG_RED_AVG: case AQG_RED_VAR: case AQG_RED_STDDEV: return AQG_DOUBLE;

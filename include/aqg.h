@@ -277,13 +277,16 @@ int aqg_comm_rank(const aqg_comm* comm);
 int aqg_comm_world(const aqg_comm* comm);
 /* aqg_groupby_agg over a table sharded by ROW RANGE: this rank holds rows [row_base, row_base + n) of every column.  Every rank
  * groups its own rows, ONE all-gather moves the shards' group tables (k key columns, the global first row and one partial per
- * aggregate: SUM -> sum, COUNT -> count, MIN / MAX -> itself, AVG -> sum and count), every rank re-aggregates the concatenation
+ * aggregate: SUM -> sum, COUNT -> count, MIN / MAX -> itself, AVG -> sum and count, VAR / STDDEV -> sum, sum of squares and count;
+ * a partial that needs 128 bits per shard -- sums of 8-byte integers, sums of squares -- as two 8-byte columns), every rank re-aggregates the concatenation
  * and gets the same merged result: keys / aggregates of all groups in GLOBAL first-occurrence order (shards are contiguous and
  * gathered in rank order, so first occurrence in the concatenation is the global one: server/hasher.h:176-198 semantics).
  * Integer sums are exact (128-bit results), AVG of integers is the exact sum over the count, as in the single-GPU call.
  * gmax: upper bound of a shard's group count (fixed-size payload, nothing but the one all-gather crosses the wire: h2o Q1 / Q4 /
  * config 4), or 0: the ranks first exchange their group counts (one 8-byte all-gather) and size the payload by the largest.
- * ops: SUM / COUNT / MIN / MAX / AVG.  The result handle has no 32-bit first rows (aqg_groupby_first_rows returns NULL):
+ * ops: SUM / COUNT / MIN / MAX / AVG / VAR / STDDEV over integer columns of 1 to 8 bytes and floating columns (VAR / STDDEV use the
+ * reference's formula on the merged moments, bit-identical to the single-GPU call for integers; up to 8 distinct partials per call).
+ * The result handle has no 32-bit first rows (aqg_groupby_first_rows returns NULL):
  * aqg_groupby_first_rows64 gives the global row id of every group's first row.  `*out` is in/out like aqg_groupby_agg.             */
 int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, const void* const* keys,
                             int naggs, const int* ops, const int* val_dtypes, const void* const* vals,

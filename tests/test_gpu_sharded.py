@@ -65,6 +65,15 @@ def check(world, keys, ops, vals, oracle, **kw):
             if x.dtype.kind == "f" and op in (ck.RED_SUM, ck.RED_AVG):
                 w, g = want.astype(np.float64), got.astype(np.float64)
                 assert np.all(np.abs(g - w) <= np.maximum(1.0, np.abs(w)) * len(x) * 2.0 ** -50), op
+            elif x.dtype.kind == "f" and op in (ck.RED_VAR, ck.RED_STDDEV):
+                # moments summed in another order: q - s*s/(n+1) cancels, so the bound is relative to the second moment
+                w, g = want.astype(np.float64), got.astype(np.float64)
+                q = oracle.grouped_reduce(ck.RED_SUM, (x.astype(np.float64) ** 2), o).astype(np.float64)
+                cnt = o["counts"].astype(np.float64)
+                tol = (q / (cnt + 1)) * len(x) * 2.0 ** -48 + 1e-300
+                if op == ck.RED_STDDEV:
+                    tol = np.sqrt(tol) + tol / np.maximum(np.abs(w), 1e-300)
+                assert np.all(np.abs(g - w) <= tol), op
             else:
                 assert gu.same_bits(got, want), (op, x.dtype)
 
@@ -95,6 +104,30 @@ def test_multi_key_high_cardinality_variable_payload(oracle):
     check(3, ids, [ck.RED_SUM, ck.RED_COUNT], [v3, v3], oracle)                                   # Q10 shape: wide tuple
     d = rng.standard_normal(n)
     check(2, [id6, ids[1]], [ck.RED_MAX, ck.RED_MIN, ck.RED_AVG, ck.RED_SUM], [d, v1, d, d], oracle)
+
+
+def test_second_moments_and_eight_byte_sums(oracle):
+    """VAR / STDDEV travel as {sum, sum of squares, count}; a partial that needs 128 bits per shard (sums of 8-byte integers, sums of
+    squares) as two 8-byte columns.  Integer results are bit-identical to the oracle's whole-table aggregates."""
+    rng = np.random.default_rng(3)
+    n = 300_007
+    id1 = rng.integers(1, 101, n).astype(np.int32)
+    v1 = rng.integers(-50_000, 50_000, n).astype(np.int32)
+    v2 = rng.integers(-300, 300, n).astype(np.int16)
+    u4 = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    big = rng.integers(-2**62, 2**62, n).astype(np.int64)             # a group's sum passes 64 bits
+    ubig = rng.integers(0, 2**64, n, dtype=np.uint64)
+    v3 = np.round(rng.uniform(0, 100, n), 6).astype(np.float32)
+    d = rng.standard_normal(n) * 1e3
+    check(3, [id1], [ck.RED_VAR, ck.RED_STDDEV], [v1, v1], oracle, hint=128, gmax=128)
+    check(4, [id1], [ck.RED_VAR, ck.RED_AVG, ck.RED_SUM], [v2, v2, v1], oracle)
+    check(2, [id1], [ck.RED_STDDEV], [u4], oracle, hint=128)
+    check(3, [id1], [ck.RED_SUM, ck.RED_AVG, ck.RED_MIN], [big, big, big], oracle)
+    check(2, [id1], [ck.RED_SUM, ck.RED_AVG], [ubig, ubig], oracle, empty_rank=1)
+    check(3, [id1], [ck.RED_VAR, ck.RED_STDDEV], [v3, d], oracle)
+    check(5, [id1, v2 % 3], [ck.RED_VAR, ck.RED_COUNT], [d, d], oracle)
+    mid = rng.integers(-2**40, 2**40, n).astype(np.int64)            # 8-byte integers: sum and sum of squares both as two columns, three merge calls
+    check(3, [id1], [ck.RED_VAR, ck.RED_STDDEV, ck.RED_AVG, ck.RED_MAX], [mid, mid, mid, v1], oracle)
 
 
 def test_group_order_is_global_first_occurrence(oracle):
