@@ -38,7 +38,21 @@ struct Rccl {
 Rccl* rccl(std::string* err) {
     static Rccl r;
     if (r.lib) return &r;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
+    // The RCCL that sits NEXT TO the HIP runtime this library is bound to: a process may hold two ROCm stacks (PyTorch wheels bundle
+    // their own libamdhip64 / libhsa-runtime64 / librccl), and an RCCL from the other one opens its own, uninitialised HSA runtime and
+    // reports "no ROCm-capable device" (seen when torch was imported after this library and before the first communicator).
+    {
+        Dl_info di;
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash);
+                for (const char* leaf : {"/librccl.so.1", "/librccl.so"}) { r.lib = dlopen((dir + leaf).c_str(), RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
+            }
+        }
+    }
+    if (!r.lib) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
     if (!r.lib) { if (err) *err = std::string("librccl not found: ") + dlerror(); return nullptr; }
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));

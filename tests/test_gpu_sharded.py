@@ -198,3 +198,27 @@ def test_bench_multi_rank_path_rehearsed_on_one_gpu(workload):
 def test_bench_self_merge_world_of_one():
     line = _bench(["--rows", "3e6", "--steps", "3", "--warmup", "1", "--cpu-sample", "0"], {"AQG_BENCH_SELFMERGE": "1"})
     assert line["n_gpus"] == 1 and line["config"]["groups"] == 100 and "secondary" not in line
+
+
+def test_rccl_transport_after_torch_has_loaded_its_own_rocm_stack():
+    """bench.py --gpus N imports torch (whose wheel bundles libamdhip64 / libhsa-runtime64 / librccl) BEFORE the library makes its
+    communicator: the library must open the RCCL that sits next to the HIP runtime it is bound to (a fresh process, torch first)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import torch
+torch.cuda.init(); torch.zeros(4, device="cuda"); torch.cuda.synchronize()
+import sys; sys.path.insert(0, "tests")
+import numpy as np, aquery2_amd, checker as ck
+side = torch.cuda.Stream(device=0); torch.cuda.set_stream(side)
+dev = aquery2_amd.Device(0, stream=torch.cuda.current_stream().cuda_stream)
+comm = aquery2_amd.Comm(dev, 0, 1, nccl_id=aquery2_amd.Comm.unique_id())
+k = (np.arange(100_000, dtype=np.int32) * 7919) % 101; v = np.arange(100_000, dtype=np.int32)
+gb = comm.groupby_agg_sharded([k], [ck.RED_SUM, ck.RED_VAR], [v, v], row_base=0, hint=128, gmax=128)
+want = np.bincount(k, weights=v.astype(np.float64), minlength=101)
+got = ck.i128_to_int(gb.result(0, ck.RED_SUM, ck.INT32))
+assert gb.ngroups == 101 and [int(x) for x in got] == [int(want[key]) for key in gb.keys(0, np.int32)]
+print("OK")
+'''
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
