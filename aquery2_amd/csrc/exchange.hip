@@ -88,6 +88,9 @@ struct aqg_comm {
 
 namespace {
 
+bool small_int(int dt) { return dt == AQG_INT8 || dt == AQG_INT16 || dt == AQG_INT32 || dt == AQG_UINT8 || dt == AQG_UINT16 || dt == AQG_UINT32 || dt == AQG_BOOL; }
+bool is_fp(int dt) { return dt == AQG_FLOAT || dt == AQG_DOUBLE; }
+
 int grow(aqg_ctx* ctx, void** p, size_t* cap, size_t need) {
     if (need <= *cap && *p) return AQG_OK;
     if (*p) { AQG_HIP(ctx, hipStreamSynchronize(ctx->stream)); AQG_HIP(ctx, hipFree(*p)); *p = nullptr; *cap = 0; }
@@ -232,6 +235,130 @@ __global__ void __launch_bounds__(256) xfinal_kernel(FinalSpec fs, uint32_t G) {
     }
 }
 
+// ---- the merge of SMALL exchanges in one launch -------------------------------------------------------------------------------------
+// world x gcap <= 1024 rows, one key column (h2o Q1 / Q4, config 4: 8 ranks x 128 groups).  ONE workgroup reads the gathered
+// payloads directly (no concatenation), groups the rows in an LDS table, numbers the groups by first occurrence in rank order (a
+// bitmap of the rows that lead a group + popcounts) and reduces every payload column into dense per-group accumulators: integer
+// sums into 128 bits (low word by atomic add, carry and sign into the high word), doubles by atomic add, MIN / MAX through an
+// order-preserving 64-bit map.  Replaces concatenate + host read of the row count + a whole aqg_groupby_agg call (ten launches, two
+// host round trips): what the exchange adds to a 1.4 ms Q1 step went from ~0.10 to ~0.05 ms at a world of one.
+constexpr uint32_t XS_ROWS = 1024, XS_CAP = 2048, XS_MAXCOL = 6;
+constexpr unsigned long long XS_EMPTY = 0x8000000000000001ull;
+struct SmallMerge {
+    int ncols;                         // payload columns
+    int kind[XS_MAXCOL];               // 0 signed 128-bit sum, 1 unsigned 128-bit sum, 2 double sum, 3 / 4 signed min / max, 5 / 6 unsigned min / max
+    int out_size[XS_MAXCOL];           // bytes per group of the result column (16 / 8 / the native size)
+    void* out[XS_MAXCOL];
+    void* keys_out; int key_size;
+    long long* first_out;
+    uint32_t* info;                    // [0] groups, [1] bad header
+};
+__global__ void __launch_bounds__(1024) xmerge_small_kernel(const uint64_t* __restrict__ gathered, uint32_t world, uint32_t gcap, size_t words_per_rank, SmallMerge sm) {
+    __shared__ unsigned long long tkey[XS_CAP + 1];          // (last: the key equal to the empty mark)
+    __shared__ uint32_t tlead[XS_CAP + 1];                   // lowest row of the slot's key, later its group id
+    __shared__ unsigned long long lead_bits[XS_ROWS / 64];
+    __shared__ uint32_t lead_before[XS_ROWS / 64 + 1];
+    __shared__ unsigned long long alo[XS_MAXCOL][XS_ROWS], ahi[XS_MAXCOL][XS_ROWS];
+    __shared__ long long gfirst[XS_ROWS];
+    __shared__ uint32_t off[65];
+    __shared__ uint32_t s_bad;
+    if (threadIdx.x == 0) {
+        uint32_t o = 0, bad = 0;
+        for (uint32_t r = 0; r < world; ++r) {
+            const uint64_t c = gathered[(size_t)r * words_per_rank];
+            if (c > gcap) bad = 1;
+            off[r] = o;
+            o += bad ? 0u : (uint32_t)c;
+        }
+        off[world] = o;
+        s_bad = bad;
+    }
+    for (uint32_t t = threadIdx.x; t <= XS_CAP; t += 1024) { tkey[t] = XS_EMPTY; tlead[t] = 0xFFFFFFFFu; }
+    if (threadIdx.x < XS_ROWS / 64) lead_bits[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t total = s_bad ? 0u : off[world];
+    const uint32_t i = threadIdx.x;                          // one row per lane
+    const bool live = i < total;
+    uint32_t slot = XS_CAP, r = 0, g_in = 0;
+    unsigned long long key = 0;
+    if (live) {
+        while (i >= off[r + 1]) ++r;                           // world <= 64
+        g_in = i - off[r];
+        key = gathered[(size_t)r * words_per_rank + 2 + g_in];
+        if (key != XS_EMPTY) {
+            slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 53);          // top 11 bits: XS_CAP slots
+            while (true) {
+                const unsigned long long cur = tkey[slot];
+                if (cur == key) break;
+                if (cur == XS_EMPTY) {
+                    const unsigned long long old = atomicCAS(&tkey[slot], XS_EMPTY, key);
+                    if (old == XS_EMPTY || old == key) break;
+                }
+                slot = (slot + 1) & (XS_CAP - 1);                             // at most XS_ROWS keys in XS_CAP slots: always ends
+            }
+        }
+        atomicMin(&tlead[slot], i);
+    }
+    __syncthreads();
+    const bool leader = live && tlead[slot] == i;
+    if (leader) atomicOr(&lead_bits[i >> 6], 1ull << (i & 63));
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t c = 0; for (uint32_t w = 0; w < XS_ROWS / 64; ++w) { lead_before[w] = c; c += (uint32_t)__popcll(lead_bits[w]); } lead_before[XS_ROWS / 64] = c; }
+    __syncthreads();
+    const uint32_t G = lead_before[XS_ROWS / 64];
+    // dense accumulators of the G groups
+    for (uint32_t g = threadIdx.x; g < G; g += 1024) {
+        gfirst[g] = 0x7FFFFFFFFFFFFFFFll;
+        for (int c = 0; c < sm.ncols; ++c) {
+            const int k = sm.kind[c];
+            alo[c][g] = k == 3 || k == 5 ? ~0ull : 0ull;       // min: all ones in the mapped order; sums and max: zero
+            ahi[c][g] = 0;
+        }
+    }
+    uint32_t gid = 0;
+    if (leader) { gid = lead_before[i >> 6] + (uint32_t)__popcll(lead_bits[i >> 6] & ((1ull << (i & 63)) - 1ull)); }
+    __syncthreads();
+    if (leader) tlead[slot] = gid;                             // (every row of the key read its leader's row above)
+    __syncthreads();
+    if (live) {
+        const uint32_t g = tlead[slot];
+        const uint64_t* base = gathered + (size_t)r * words_per_rank + 2;
+        atomicMin(reinterpret_cast<long long*>(&gfirst[g]), (long long)base[(size_t)gcap + g_in]);
+        for (int c = 0; c < sm.ncols; ++c) {
+            const unsigned long long v = base[(size_t)(2 + c) * gcap + g_in];
+            switch (sm.kind[c]) {
+            case 0: case 1: {
+                const unsigned long long old = atomicAdd(&alo[c][g], v);
+                const unsigned long long hi_add = (sm.kind[c] == 0 && (long long)v < 0 ? ~0ull : 0ull) + (old + v < old ? 1ull : 0ull);
+                if (hi_add) atomicAdd(&ahi[c][g], hi_add);
+            } break;
+            case 2: atomicAdd(reinterpret_cast<double*>(&alo[c][g]), __builtin_bit_cast(double, v)); break;
+            case 3: atomicMin(&alo[c][g], v ^ 0x8000000000000000ull); break;
+            case 4: atomicMax(&alo[c][g], v ^ 0x8000000000000000ull); break;
+            case 5: atomicMin(&alo[c][g], v); break;
+            default: atomicMax(&alo[c][g], v); break;
+            }
+        }
+    }
+    __syncthreads();
+    if (leader) {
+        unsigned char* kd = static_cast<unsigned char*>(sm.keys_out) + (size_t)gid * sm.key_size;
+        for (int b = 0; b < sm.key_size; ++b) kd[b] = (unsigned char)(key >> (8 * b));
+    }
+    for (uint32_t g = threadIdx.x; g < G; g += 1024) {
+        sm.first_out[g] = gfirst[g];
+        for (int c = 0; c < sm.ncols; ++c) {
+            unsigned long long lo = alo[c][g];
+            const int k = sm.kind[c];
+            if (k == 3 || k == 4) lo ^= 0x8000000000000000ull;
+            unsigned char* dst = static_cast<unsigned char*>(sm.out[c]) + (size_t)g * sm.out_size[c];
+            if (sm.out_size[c] == 16) { reinterpret_cast<unsigned long long*>(dst)[0] = lo; reinterpret_cast<unsigned long long*>(dst)[1] = ahi[c][g]; }
+            else for (int b = 0; b < sm.out_size[c]; ++b) dst[b] = (unsigned char)(lo >> (8 * b));
+        }
+    }
+    if (threadIdx.x == 0) { sm.info[0] = G; sm.info[1] = s_bad; }
+}
+
 // steps 2-4 of the sharded group-by over an existing shard table L (keys, 32-bit first rows, one result column per partial):
 // sizes the payload, packs, ONE all-gather, concatenates, re-aggregates into comm->merged (aggregate 0 = MIN of the global first rows)
 // payload column p reads result column src_res[p] of L (null: p itself), its high 8 bytes when src_hi[p]
@@ -275,6 +402,45 @@ int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtyp
     hipLaunchKernelGGL(xpack_kernel, dim3(aqg_grid(ctx, (uint64_t)ncols * G + 1, 256, 2, 4)), dim3(256), 0, ctx->stream, ps, G, gcap, static_cast<uint64_t*>(comm->send));
     AQG_TRY(aqg_check_launch(ctx, "xpack_kernel"));
     AQG_TRY(allgather(comm, comm->send, comm->recv, bytes));
+    // ---- 3'. small exchanges: one merge kernel over the gathered payloads --------------------------------------------------------------
+    {
+        static const bool small_off = getenv("AQG_DISABLE_SMALL_MERGE") != nullptr;
+        bool small = !small_off && gmax && nkeys == 1 && nparts >= 0 && nparts <= (int)XS_MAXCOL && (uint64_t)gcap * world <= XS_ROWS && aqg_dtype_size(key_dtypes[0]) <= 8 && !is_fp(key_dtypes[0]);
+        SmallMerge sm;
+        memset(&sm, 0, sizeof sm);
+        int rdt[XS_MAXCOL];
+        for (int p = 0; p < nparts && small; ++p) {
+            const int dt = part_dt[p], op = merge_op[p];
+            const bool uns = dt == AQG_UINT8 || dt == AQG_UINT16 || dt == AQG_UINT32 || dt == AQG_UINT64 || dt == AQG_BOOL;
+            if (op == AQG_RED_SUM && is_fp(dt)) { if (dt != AQG_DOUBLE) small = false; sm.kind[p] = 2; rdt[p] = AQG_DOUBLE; sm.out_size[p] = 8; }
+            else if (op == AQG_RED_SUM) { sm.kind[p] = uns ? 1 : 0; rdt[p] = uns ? AQG_UINT128 : AQG_INT128; sm.out_size[p] = 16; }
+            else if ((op == AQG_RED_MIN || op == AQG_RED_MAX) && !is_fp(dt) && aqg_dtype_size(dt) <= 8) { sm.kind[p] = (uns ? 5 : 3) + (op == AQG_RED_MAX ? 1 : 0); rdt[p] = dt; sm.out_size[p] = (int)aqg_dtype_size(dt); }
+            else small = false;
+        }
+        if (small) {
+            aqg_groupby* M = comm->merged ? comm->merged : new aqg_groupby();
+            comm->merged = M;
+            M->ctx = ctx; M->nkeys = 1; M->key_dt[0] = key_dtypes[0]; M->nagg = nparts + 1; M->has_counts = false; M->has_reversemap = false; M->sharded = false;
+            AQG_TRY(grow(ctx, &M->keys_out[0], &M->cap_keys[0], XS_ROWS * 8));
+            for (int a = 0; a <= nparts; ++a) AQG_TRY(grow(ctx, &M->results[a], &M->cap_results[a], XS_ROWS * 16));
+            AQG_TRY(grow(ctx, &comm->hdr, &comm->hdr_cap, 8 * ((size_t)world + 1) + 64));
+            sm.ncols = nparts;
+            for (int p = 0; p < nparts; ++p) { sm.out[p] = M->results[1 + p]; M->res_dt[1 + p] = rdt[p]; }
+            M->res_dt[0] = AQG_INT64;
+            sm.keys_out = M->keys_out[0]; sm.key_size = (int)aqg_dtype_size(key_dtypes[0]);
+            sm.first_out = static_cast<long long*>(M->results[0]);
+            sm.info = reinterpret_cast<uint32_t*>(static_cast<char*>(comm->hdr) + 8 * ((size_t)world + 1));
+            hipLaunchKernelGGL(xmerge_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const uint64_t*>(comm->recv), world, gcap, words, sm);
+            AQG_TRY(aqg_check_launch(ctx, "xmerge_small_kernel"));
+            uint32_t info[2] = {0, 0};
+            AQG_HIP(ctx, hipMemcpyAsync(info, sm.info, 8, hipMemcpyDeviceToHost, ctx->stream));
+            AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (info[1]) return aqg_fail(ctx, AQG_ERR_ARG, "exchange: corrupt shard header");
+            M->ngroups = info[0]; M->n = info[0];
+            for (int a = 0; a <= nparts; ++a) { comm->mres[a] = M->results[a]; comm->mres_dt[a] = M->res_dt[a]; }
+            return AQG_OK;
+        }
+    }
     // concatenated columns: keys in their own dtypes, first rows and partials
     const size_t cat_rows = (size_t)gcap * world;
     size_t col_off[MAXKEYS + 1 + MAXPART], cat_bytes = 0;
@@ -333,8 +499,6 @@ int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtyp
     return AQG_OK;
 }
 
-bool small_int(int dt) { return dt == AQG_INT8 || dt == AQG_INT16 || dt == AQG_INT32 || dt == AQG_UINT8 || dt == AQG_UINT16 || dt == AQG_UINT32 || dt == AQG_BOOL; }
-bool is_fp(int dt) { return dt == AQG_FLOAT || dt == AQG_DOUBLE; }
 
 } // namespace
 
