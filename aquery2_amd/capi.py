@@ -213,6 +213,28 @@ class Comm:
         gb._keep = (kd, vd)
         return gb
 
+    def prepare_groupby_agg_sharded(self, keys, ops, vals, row_base, hint=0, gmax=0):
+        """groupby_agg_sharded with its argument arrays marshalled once (Device.prepare_groupby_agg's counterpart): returns a function
+        that runs the same call again on the same device columns and result handle"""
+        d = self.dev
+        kd, dts, ptrs = d._keyargs(keys)
+        vd = [d._dev(v) if v is not None else None for v in vals]
+        vdt = (C.c_int * max(1, len(vd)))(*[(v.tag if v is not None else INT32) for v in vd])
+        vp = (C.c_void_p * max(1, len(vd)))(*[(v.ptr if v is not None else None) for v in vd])
+        opa = (C.c_int * max(1, len(ops)))(*ops)
+        h = C.c_void_p()
+        args = (self.h, len(kd), dts, ptrs, len(ops), opa, vdt, vp, C.c_uint32(kd[0].n), C.c_uint64(row_base), C.c_uint32(hint), C.c_uint32(gmax), C.byref(h))
+        fn, chk = d.lib.aqg_groupby_agg_sharded, d._chk
+        gb = GroupBy(d, h)
+        gb._keep = (kd, vd, dts, ptrs, vdt, vp, opa)
+
+        def run():
+            rc = fn(*args)
+            if rc != 0:
+                chk(rc, "aqg_groupby_agg_sharded")
+            return gb
+        return run, gb
+
     def groupby_exchange(self, local, merge_ops, row_base, gmax=0, handle=None):
         """the exchange alone over an existing shard table (aqg_groupby_exchange): partial p = aggregate p of `local`"""
         d = self.dev

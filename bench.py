@@ -219,6 +219,8 @@ def main():
     if comm is not None:                       # communicator warm-up (RCCL sets its channels up on the first collective)
         w = comm.groupby_agg_sharded([id1], [ck.RED_SUM], [v1], row_base=rank * n, hint=128, gmax=GMAX)
         w.destroy()
+        if not join:                           # the sharded Q1 call, marshalled once like the N=1 one
+            state["q1s"], state["merged"] = comm.prepare_groupby_agg_sharded([id1], [ck.RED_SUM], [v1], row_base=rank * n, hint=128, gmax=GMAX)
 
     def step(record):
         if join:
@@ -230,7 +232,7 @@ def main():
                 state["merged"] = comm.groupby_exchange(gb, [ck.RED_SUM], row_base=rank * n, gmax=GMAX, handle=state["merged"])
         elif comm is not None:
             # ONE library call: this rank's group-by, pack, ONE all-gather of 129 x 3 words per rank, re-aggregation on every rank
-            state["merged"] = comm.groupby_agg_sharded([id1], [ck.RED_SUM], [v1], row_base=rank * n, hint=128, gmax=GMAX, handle=state["merged"])
+            state["merged"] = state["q1s"]()
             if record:
                 kernel_ms.append(dev.last_kernel_ms())     # the pass over this shard's rows (the re-aggregation does not replace it)
         else:
