@@ -76,6 +76,29 @@ def secondary_entries(dev, n, ck, aq, id1, v1):
     G = h["q5"].ngroups
     entry("h2o_q5_sum_v1_v2_v3_by_id6", ms, 16 * n + 44 * G, groups=int(G), kernel_ms_last_stage=round(dev.last_kernel_ms(), 4))
     h["q5"].destroy(); id6.free(); v2.free(); v3.free()
+    # ---- config 2 again: h2o Q2 (two keys, 1e4 groups: the dense-domain plan) and Q10 (six keys, ~N groups: the wide-tuple partition
+    # plan + the ordering tail; 48 GB of output), benchmark/h2o/groupby.sql:7,23
+    try:
+        id2 = dev.gen_column(ck.GEN_ID2, 42, 0, n, n, K)
+        def q2():
+            h["q2"] = dev.groupby_agg([id1, id2], [ck.RED_SUM], [v1], hint=16384, handle=h.get("q2"))
+        ms = timed(q2)
+        entry("h2o_q2_sum_v1_by_id1_id2", ms, 12 * n, groups=int(h["q2"].ngroups), kernel_ms=round(dev.last_kernel_ms(), 4))
+        h["q2"].destroy()
+        if n <= 1_000_000_000:
+            ids = [id1, id2] + [dev.gen_column(c, 42, 0, n, n, K) for c in (ck.GEN_ID3, ck.GEN_ID4, ck.GEN_ID5, ck.GEN_ID6)]
+            v3 = dev.gen_column(ck.GEN_V3, 42, 0, n, n, K)
+            def q10():
+                h["q10"] = dev.groupby_agg(ids, [ck.RED_SUM, ck.RED_COUNT], [v3, v3], hint=n, handle=h.get("q10"))
+            ms = timed(q10, reps=2)
+            G = h["q10"].ngroups
+            entry("h2o_q10_sum_v3_count_by_id1_to_id6", ms, 28 * n + 48 * G, groups=int(G))
+            h["q10"].destroy()
+            for c in ids[2:]: c.free()
+            v3.free()
+        id2.free()
+    except Exception as e:                                    # noqa: BLE001 -- a secondary entry never costs the line
+        out.append({"name": "h2o_q2_q10", "error": str(e)[:300]})
     # ---- config 3: moving windows over an ordered series (tests/stock.a shapes; aggregations.h:127-281)
     price = dev.gen_column(ck.GEN_PRICE, 42, 0, n, n, K)
     big = dev.empty(n, ck.I128)
@@ -303,7 +326,10 @@ def main():
             line["cpu_baseline"] = cpu_baseline(int(args.cpu_sample))
         if world == 1 and not join and not selfmerge and not args.no_secondary:
             state["gb"].destroy()
-            line["secondary"] = secondary_entries(dev, n, ck, aquery2_amd, id1, v1)
+            try:
+                line["secondary"] = secondary_entries(dev, n, ck, aquery2_amd, id1, v1)
+            except Exception as e:                            # noqa: BLE001 -- the headline line is printed whatever happens behind it
+                line["secondary_error"] = str(e)[:500]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
