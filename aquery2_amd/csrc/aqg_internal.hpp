@@ -29,6 +29,8 @@ struct aqg_ctx {
     hipEvent_t ev_flags = nullptr;               // recorded behind the copy of a group table's flag words (run_agg)
     hipStream_t copy_stream = nullptr;           // uploads of borrowed host columns (aqg_col_pin), created on first use
     void* up_buf[2] = {nullptr, nullptr};        // pinned staging of the fallback upload path (ranges the runtime refuses to copy directly)
+    uint32_t* rank_bm = nullptr;                 // a bitmap over row ids that is ALL ZERO between calls (group ranking of mid-size tables sets and clears only its own bits)
+    size_t rank_bm_words = 0;
     hipEvent_t up_ev[2] = {nullptr, nullptr};
     bool tail_in_flight = false;                 // the last group-by returned with its tail kernels still queued (stream-ordered)
     bool evk_valid = false;
