@@ -78,15 +78,13 @@ inline GroupTable& build_groups(int nkeys, const int* dts, const void* const* de
     t.offsets = static_cast<uint32_t*>(std::malloc(((size_t)t.G + 1) * 4));
     t.counts = static_cast<uint32_t*>(std::malloc(((size_t)t.G + 1) * 4));
     t.row_ids = static_cast<uint32_t*>(std::malloc(((size_t)n + 1) * 4));
-    void *doff = nullptr, *drows = nullptr;
-    dev::check(aqg_malloc(rt.ctx(), ((size_t)t.G + 1) * 4, &doff), "aqg_malloc");
-    dev::check(aqg_malloc(rt.ctx(), ((size_t)n + 1) * 4, &drows), "aqg_malloc");
-    dev::check(aqg_groupby_postproc(t.handle, static_cast<uint32_t*>(doff), static_cast<uint32_t*>(drows)), "aqg_groupby_postproc");
-    dev::check(aqg_d2h(rt.ctx(), t.offsets, doff, ((size_t)t.G + 1) * 4), "aqg_d2h");
+    // offsets = exclusive scan of the group sizes (what aqg_groupby_postproc would return); the row lists themselves are made on
+    // first use (device.h fill_rows): generated code that only reduces `col[vecs[g]]` never asks for them
     if (t.G) dev::check(aqg_d2h(rt.ctx(), t.counts, aqg_groupby_counts(t.handle), (size_t)t.G * 4), "aqg_d2h");
+    t.offsets[0] = 0;
+    for (uint32_t g = 0; g < t.G; ++g) t.offsets[g + 1] = t.offsets[g] + t.counts[g];
     if (want_reversemap && n) dev::check(aqg_d2h(rt.ctx(), reversemap_host, aqg_groupby_reversemap(t.handle), (size_t)n * 4), "aqg_d2h");
-    aqg_free(rt.ctx(), doff);
-    rt.adopt_group(&t, drows);    // vecs[g] views resolve to the device copy and identify their group
+    rt.adopt_group(&t, nullptr);  // vecs[g] views identify their group; their device copy is filled lazily
     return t;
 }
 
