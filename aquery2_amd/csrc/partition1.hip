@@ -745,7 +745,11 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
             const uint32_t i = threadIdx.x + q * NT;
             myrow[q] = 0;
             if (i < m) {
-                for (int k = 0; k < in.nkd; ++k) lkey[(size_t)k * R + i] = in.kplane[k][b + i];
+                // all key dwords of the row in flight together (a loop over a run-time number of planes waits for every load before
+                // the LDS store behind it: 6 planes x 3 rows = 18 memory latencies in a row per partition)
+                uint32_t kv[2 * MAXKEYS];
+                _Pragma("unroll") for (int k = 0; k < 2 * MAXKEYS; ++k) if (k < in.nkd) kv[k] = in.kplane[k][b + i];
+                _Pragma("unroll") for (int k = 0; k < 2 * MAXKEYS; ++k) if (k < in.nkd) lkey[(size_t)k * R + i] = kv[k];
                 myrow[q] = in.rows[b + i];
                 lfirst[i] = NOROW; lcount[i] = 0;
                 _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
