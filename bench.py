@@ -170,11 +170,14 @@ def main():
 
     # AQG_BENCH_REHEARSAL=1: every rank on GPU 0 and the exchange over gloo -- a way to run the N>1 code path on a one-GPU
     # box (RCCL refuses two ranks on one device).  Never set by the driver; the numbers of such a run mean nothing.
+    # AQG_BENCH_FORCE_COMM=1 (under torchrun with ONE rank): the multi-rank code path -- process group, communicator, sharded call --
+    # with a world of one; AQG_BENCH_FORCE_TORCH_ALLGATHER=1 additionally takes the fallback transport.  Never set by the driver.
+    multi = world > 1 or os.environ.get("AQG_BENCH_FORCE_COMM") == "1"
     rehearsal = world > 1 and os.environ.get("AQG_BENCH_REHEARSAL") == "1"
     gpu = 0 if rehearsal else local_rank
     xdev = "cpu" if rehearsal else "cuda"       # where the exchanged tensors live
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         torch.cuda.set_device(gpu)
         if rehearsal:
@@ -195,14 +198,36 @@ def main():
     # ncclAllGather on the library's stream.  torch.distributed only carries the 128-byte RCCL id from rank 0 to the others (and
     # the barrier / max-over-ranks of the timing).  Rehearsal and self-merge runs plug a host-side all-gather into the same C code.
     comm = None
-    if world > 1 and not rehearsal:
+    transport = "rccl in the library"
+    if multi and not rehearsal:
         idt = torch.zeros(128, dtype=torch.uint8, device=xdev)
         if rank == 0:
             idt = torch.tensor(list(aquery2_amd.Comm.unique_id()), dtype=torch.uint8, device=xdev)
         dist.broadcast(idt, 0)
         torch.cuda.synchronize()
-        comm = aquery2_amd.Comm(dev, rank, world, nccl_id=bytes(idt.cpu().tolist()))
-    elif world > 1:
+        ok = torch.ones(1, dtype=torch.int32, device=xdev)
+        try:
+            comm = aquery2_amd.Comm(dev, rank, world, nccl_id=bytes(idt.cpu().tolist()))
+        except Exception as e:                                # noqa: BLE001 -- reported below; every rank must take the same path
+            comm = None
+            print(f"[bench] rank {rank}: the library's own RCCL communicator failed ({e}); falling back to torch's all-gather", file=sys.stderr, flush=True)
+            ok.zero_()
+        if os.environ.get("AQG_BENCH_FORCE_TORCH_ALLGATHER") == "1":
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            # the same C code (aqg_groupby_agg_sharded) with torch.distributed's RCCL all-gather plugged in as the transport, on the
+            # shared stream: a run that lands here still measures the exchange, and says so in its line
+            if comm is not None:
+                comm.destroy()
+            def torch_allgather(send, recv, nbytes, stream):
+                src = torch.as_tensor(aquery2_amd.DevBuf(dev, send, np.uint8, nbytes, owned=False), device="cuda")
+                dst = torch.as_tensor(aquery2_amd.DevBuf(dev, recv, np.uint8, world * nbytes, owned=False), device="cuda")
+                dist.all_gather_into_tensor(dst, src)
+                return 0
+            comm = aquery2_amd.Comm(dev, rank, world, allgather=torch_allgather)
+            transport = "torch.distributed all_gather (library communicator failed)"
+    elif multi:
         def gloo_allgather(send, recv, nbytes, stream):
             hs = np.empty(nbytes, np.uint8)
             dev._chk(dev.lib.aqg_d2h(dev.ctx, ctypes.c_void_p(hs.ctypes.data), ctypes.c_void_p(send), ctypes.c_size_t(nbytes)), "aqg_d2h")
@@ -264,7 +289,7 @@ def main():
                 kernel_ms.append(dev.last_kernel_ms())
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         dev.sync()
@@ -277,7 +302,7 @@ def main():
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -293,7 +318,7 @@ def main():
         by4.destroy()
     else:
         local_sum = int(dev.reduce(ck.RED_SUM, v1))
-    if world > 1:
+    if multi:
         t = torch.tensor([local_sum], dtype=torch.int64, device=xdev)
         dist.all_reduce(t)
         local_sum = int(t.item())
@@ -311,7 +336,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": (f"h2o_join_small_id4_w_then_sum_v1_times_w_by_id1_{n:.0e}_rows_per_gpu" if join else
                                     f"h2o_groupby_q1_sum_v1_by_id1_{n:.0e}_rows_per_gpu"), "rows_per_gpu": n, "K": 100,
-                       "seed": 42, "groups": int(final.ngroups), "parallelism": f"row-range shards x{world}"},
+                       "seed": 42, "groups": int(final.ngroups), "parallelism": f"row-range shards x{world}", **({"exchange": transport} if multi else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          # `traffic` is a PMC counter of THIS run or null: bench.py collects none (counters need their own rocprofv3
@@ -322,16 +347,16 @@ def main():
                                               "source": "profiles/r1_groupby_join_1e9_pmc.md" if join else "profiles/r2_bench_q1_1e9_pmc.md"},
                          "kernel": "starjoin_kernel" if join else "agg32_kernel<1,false,false,4>", "kernel_ms": k_ms, "algorithmic_bytes": bpr * n},
         }
-        if world == 1 and args.cpu_sample > 0 and not join:
+        if world == 1 and comm is None and args.cpu_sample > 0 and not join:
             line["cpu_baseline"] = cpu_baseline(int(args.cpu_sample))
-        if world == 1 and not join and not selfmerge and not args.no_secondary:
+        if world == 1 and comm is None and not join and not args.no_secondary:
             state["gb"].destroy()
             try:
                 line["secondary"] = secondary_entries(dev, n, ck, aquery2_amd, id1, v1)
             except Exception as e:                            # noqa: BLE001 -- the headline line is printed whatever happens behind it
                 line["secondary_error"] = str(e)[:500]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
     dev.close()
 

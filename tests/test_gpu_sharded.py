@@ -170,11 +170,11 @@ def gpu_dev():
     d.close()
 
 
-def _bench(args, env_extra, nproc=1):
+def _bench(args, env_extra, nproc=1, torchrun=False):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, **env_extra)
-    if nproc > 1:
+    if nproc > 1 or torchrun:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1", "--master-port", "29511",
                os.path.join(root, "bench.py"), "--gpus", str(nproc)] + args
     else:
@@ -222,3 +222,16 @@ print("OK")
 '''
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+@pytest.mark.parametrize("force_torch", [False, True])
+def test_bench_multi_rank_code_path_with_real_rccl_world_of_one(force_torch):
+    """bench.py under torchrun with ONE rank and AQG_BENCH_FORCE_COMM: torch's process group on RCCL, the RCCL id broadcast, the
+    library's own communicator (or, forced, the fallback transport over torch.distributed's all-gather) and the prepared sharded call --
+    everything `--gpus N` runs except a second GPU"""
+    env = {"AQG_BENCH_FORCE_COMM": "1"}
+    if force_torch:
+        env["AQG_BENCH_FORCE_TORCH_ALLGATHER"] = "1"
+    line = _bench(["--rows", "3e6", "--steps", "3", "--warmup", "1", "--cpu-sample", "0"], env, nproc=1, torchrun=True)
+    assert line["n_gpus"] == 1 and line["config"]["groups"] == 100
+    assert ("torch.distributed" in line["config"]["exchange"]) == force_torch
