@@ -708,7 +708,7 @@ __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __
 // rows lie in one interval of <= C rows, so its first group id is its start offset and a group's id is that plus the number of set
 // bits below its first row in a bitmap of the interval.  The records are permuted into id order inside LDS and emitted from there:
 // every output column is written front to back, the key columns (wide tuples) are read in ascending row order.
-__global__ void __launch_bounds__(1024) sorted_emit_kernel(SortedParts sp, uint32_t G, uint32_t n_rows, int nacc, int has_count, int wide, EmitSpec es, uint32_t* __restrict__ flags) {
+__global__ void __launch_bounds__(1024, 8) sorted_emit_kernel(SortedParts sp, uint32_t G, uint32_t n_rows, int nacc, int has_count, int wide, EmitSpec es, uint32_t* __restrict__ flags) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const uint32_t C = sp.cap, W = C / 32 + 8;
     uint64_t* sacc = reinterpret_cast<uint64_t*>(smem_raw);                 // [nacc][C]
@@ -734,7 +734,15 @@ __global__ void __launch_bounds__(1024) sorted_emit_kernel(SortedParts sp, uint3
         if (hi - lo > C || c > C || e > G) { if (threadIdx.x == 0) flags[0] = 1; continue; }       // (the plan rules it out)
         for (uint32_t w = threadIdx.x; w < nw; w += NT) bm[w] = 0;
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < c; j += NT) { const uint32_t r = sp.first[b + j] - lo; atomicOr(&bm[r >> 5], 1u << (r & 31)); }
+        // (four rows of a lane per step, their loads issued together from clamped indices: a partition is a chain of barriers, and a
+        // loop that loads, uses and loads again puts one memory latency per row between them)
+        for (uint32_t j0 = threadIdx.x; j0 < c; j0 += 4 * NT) {
+            uint32_t fr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const uint32_t j = j0 + u * NT; fr[u] = sp.first[b + (j < c ? j : c - 1)]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (j0 + u * NT < c) { const uint32_t r = fr[u] - lo; atomicOr(&bm[r >> 5], 1u << (r & 31)); }
+        }
         __syncthreads();
         {   // nw <= 512 <= NT: one word per thread
             const uint32_t t = threadIdx.x < nw ? __popc(bm[threadIdx.x]) : 0;
@@ -746,24 +754,50 @@ __global__ void __launch_bounds__(1024) sorted_emit_kernel(SortedParts sp, uint3
             if (threadIdx.x < nw) wp[threadIdx.x] = base;
         }
         __syncthreads();
-        for (uint32_t j = threadIdx.x; j < c; j += NT) {
-            const uint32_t fr = sp.first[b + j], r = fr - lo;
-            const uint32_t rank = wp[r >> 5] + __popc(bm[r >> 5] & ((1u << (r & 31)) - 1u));
-            sfirst[rank] = fr;
-            scount[rank] = has_count ? sp.count[b + j] : 0;
-            if (!wide) skey[rank] = sp.key[b + j];
-            for (int a = 0; a < nacc; ++a) sacc[(size_t)a * C + rank] = sp.acc[a][b + j];
+        for (uint32_t j0 = threadIdx.x; j0 < c; j0 += 2 * NT) {
+            uint32_t fr[2], cn[2];
+            uint64_t ky[2], ac[4][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t j = j0 + u * NT, jj = b + (j < c ? j : c - 1);
+                fr[u] = sp.first[jj];
+                cn[u] = has_count ? sp.count[jj] : 0;
+                ky[u] = wide ? 0ull : sp.key[jj];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) ac[a][u] = a < nacc ? sp.acc[a][jj] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (j0 + u * NT >= c) continue;
+                const uint32_t r = fr[u] - lo;
+                const uint32_t rank = wp[r >> 5] + __popc(bm[r >> 5] & ((1u << (r & 31)) - 1u));
+                sfirst[rank] = fr[u];
+                scount[rank] = cn[u];
+                if (!wide) skey[rank] = ky[u];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) if (a < nacc) sacc[(size_t)a * C + rank] = ac[a][u];
+            }
+            for (int a = 4; a < nacc; ++a)                    // (more than four accumulators: the rest one by one)
+                for (int u = 0; u < 2; ++u) { const uint32_t j = j0 + u * NT; if (j < c) { const uint32_t r = fr[u] - lo; sacc[(size_t)a * C + wp[r >> 5] + __popc(bm[r >> 5] & ((1u << (r & 31)) - 1u))] = sp.acc[a][b + j]; } }
         }
         __syncthreads();
         if (k32) {      // wide tuples of 4-byte columns: the key loads of a record issued together (emit_record's run one after the other)
-            for (uint32_t i = threadIdx.x; i < c; i += NT) {
-                const uint32_t row = sfirst[i], g = b + i;
-                uint32_t kv[MAXKEYS];
+            for (uint32_t i0 = threadIdx.x; i0 < c; i0 += 2 * NT) {          // two records per step: up to sixteen key loads in flight
+                uint32_t kv[2][MAXKEYS];
 #pragma unroll
-                for (int k = 0; k < MAXKEYS; ++k) kv[k] = k < es.nkeys ? static_cast<const uint32_t*>(es.key_col[k])[row] : 0;
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t i = i0 + u * NT, row = sfirst[i < c ? i : c - 1];
 #pragma unroll
-                for (int k = 0; k < MAXKEYS; ++k) if (k < es.nkeys) static_cast<uint32_t*>(es.key_out[k])[g] = kv[k];
-                emit_record<false>(lt, i, g, es, 0);
+                    for (int k = 0; k < MAXKEYS; ++k) kv[u][k] = k < es.nkeys ? static_cast<const uint32_t*>(es.key_col[k])[row] : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t i = i0 + u * NT, g = b + i;
+                    if (i >= c) continue;
+#pragma unroll
+                    for (int k = 0; k < MAXKEYS; ++k) if (k < es.nkeys) static_cast<uint32_t*>(es.key_out[k])[g] = kv[u][k];
+                    emit_record<false>(lt, i, g, es, 0);
+                }
             }
         } else {
             for (uint32_t i = threadIdx.x; i < c; i += NT) emit_record(lt, i, b + i, es, wide ? (uint64_t)sfirst[i] : skey[i]);
