@@ -704,7 +704,14 @@ __global__ void __launch_bounds__(TB) pn_level_hist_kernel(const uint32_t* __res
     const uint32_t nrows = b + TPT > e ? (uint32_t)(e - b) : TPT;
     if (threadIdx.x < 128) h[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nrows; i += TB) atomicAdd(&h[(__umulhi(HASHED ? key_hash<false>(keys[b + i]) : keys[b + i], lv.P) >> lv.shift) & lv.mask], 1u);
+    {   // the tile's TR rows of a lane loaded together (a row at a time: TR memory latencies per tile)
+        static_assert(TR % 4 == 0, "whole groups of four rows");
+        uint32_t key[TR];
+        if (nrows == TPT) load_rows_t<TB, true>(keys, (size_t)b, nrows, 0, key); else load_rows_t<TB, false>(keys, (size_t)b, nrows, 0, key);
+#pragma unroll
+        for (int r = 0; r < TR; ++r)
+            if (trow<TB>(r) < nrows) atomicAdd(&h[(__umulhi(HASHED ? key_hash<false>(key[r]) : key[r], lv.P) >> lv.shift) & lv.mask], 1u);
+    }
     __syncthreads();
     if (threadIdx.x < lv.nbins && h[threadIdx.x]) atomicAdd(&cnt[(size_t)seg * lv.nbins + threadIdx.x], h[threadIdx.x]);
 }
