@@ -278,11 +278,36 @@ __global__ void __launch_bounds__(BLOCK) dense_agg_kernel(KeySpec ks, DenseSpec 
 }
 
 // second pass of aqg_groupby_build over a dense domain: reversemap[i] = dense id of row i's group, counts[g] += 1
-template <bool LDS_COUNTS>
-__global__ void __launch_bounds__(256) dense_assign_kernel(KeySpec ks, DenseSpec ds, const uint32_t* __restrict__ slot_gid, uint32_t n, uint32_t G,
-                                                           uint32_t* __restrict__ reversemap, uint32_t* __restrict__ counts) {
+// NK > 0: exactly NK key columns, all int32 / uint32, their specs in registers (see dense_agg_kernel: the generic form re-loads
+// ks / ds from kernel-argument memory inside the loop)
+// LDS_MAP: the {index -> dense id} map of the whole domain copied into LDS behind the counts (h2o Q2 keys: 1e4 + 1e4 words): a
+// look-up per row out of L2 kept the pass at 5.0 ms per 1e9 rows (64 different lines per gather instruction); the workgroup then has
+// 1024 threads, so that the table is paid for once per 16 wavefronts.
+template <bool LDS_COUNTS, int NK = 0, bool LDS_MAP = false>
+__global__ void __launch_bounds__(1024) dense_assign_kernel(KeySpec ks, DenseSpec ds, const uint32_t* __restrict__ slot_gid, uint32_t n, uint32_t G,
+                                                            uint32_t* __restrict__ reversemap, uint32_t* __restrict__ counts) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint32_t* lc = reinterpret_cast<uint32_t*>(smem_raw);
+    uint32_t* lm = lc + G;                                                    // [ds.D] if LDS_MAP
+    if constexpr (LDS_MAP) for (uint32_t s2 = threadIdx.x; s2 < ds.D; s2 += blockDim.x) lm[s2] = slot_gid[s2];
+    const uint32_t* kcol[NK ? NK : 1]; uint32_t kmin[NK ? NK : 1], kmult[NK ? NK : 1], krange[NK ? NK : 1];
+#pragma unroll
+    for (int c = 0; c < NK; ++c) { kcol[c] = static_cast<const uint32_t*>(ks.col[c]); kmin[c] = (uint32_t)ds.kmin[c]; kmult[c] = ds.mult[c]; krange[c] = ds.range[c]; }
+    auto idx4 = [&](size_t base, uint32_t (&idx)[4]) {
+        if constexpr (NK > 0) {
+            uint32_t bad[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) idx[j] = 0;
+#pragma unroll
+            for (int c = 0; c < NK; ++c) {
+                const pack<uint32_t, 4> v = *reinterpret_cast<const pack<uint32_t, 4>*>(kcol[c] + base);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const uint32_t d = v.v[j] - kmin[c]; bad[j] |= d >= krange[c]; idx[j] += d * kmult[c]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (bad[j]) idx[j] = 0xFFFFFFFFu;
+        } else dense_idx4(ks, ds, base, idx);
+    };
     if constexpr (LDS_COUNTS) { for (uint32_t g = threadIdx.x; g < G; g += blockDim.x) lc[g] = 0; __syncthreads(); }
     const uint32_t nchunk = n >> 2;
     uint32_t c_lo, c_hi;
@@ -290,10 +315,10 @@ __global__ void __launch_bounds__(256) dense_assign_kernel(KeySpec ks, DenseSpec
     for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
         const size_t base = (size_t)c * 4;
         uint32_t idx[4];
-        dense_idx4(ks, ds, base, idx);
+        idx4(base, idx);
         pack<uint32_t, 4> o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o.v[j] = slot_gid[idx[j]];
+        for (int j = 0; j < 4; ++j) { if constexpr (LDS_MAP) o.v[j] = lm[idx[j]]; else o.v[j] = slot_gid[idx[j]]; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { if constexpr (LDS_COUNTS) atomicAdd(&lc[o.v[j]], 1u); else atomicAdd(&counts[o.v[j]], 1u); }
         *reinterpret_cast<pack<uint32_t, 4>*>(reversemap + base) = o;
@@ -313,13 +338,33 @@ __global__ void __launch_bounds__(256) dense_assign_kernel(KeySpec ks, DenseSpec
 } // namespace
 
 int aqg_dense_assign(aqg_ctx* ctx, const KeySpec& ks, const DenseSpec& ds, const uint32_t* slot_gid, uint32_t n, uint32_t G, uint32_t* reversemap, uint32_t* counts) {
-    const size_t lds = (size_t)G * 4 + 16;
-    if (lds <= 144 * 1024) {
-        const unsigned per_cu = (unsigned)((160 * 1024) / (lds + 1024)) > 8 ? 8 : (unsigned)((160 * 1024) / (lds + 1024));
-        AQG_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_assign_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((dense_assign_kernel<true>), dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, per_cu ? per_cu : 1)), dim3(256), lds, ctx->stream, ks, ds, slot_gid, n, G, reversemap, counts);
+    const size_t lds_counts = (size_t)G * 4 + 16, lds_map = ((size_t)G + ds.D) * 4 + 16;
+    if (lds_counts <= 144 * 1024) {
+        const bool map = lds_map <= 144 * 1024;
+        const size_t lds = map ? lds_map : lds_counts;
+        const unsigned block = lds > 20 * 1024 ? 1024u : 256u;
+        unsigned per_cu = (unsigned)((160 * 1024) / (lds + 1024));
+        if (per_cu > 2048u / block) per_cu = 2048u / block;
+        if (per_cu < 1) per_cu = 1;
+        int nk = ks.nkeys <= 3 ? ks.nkeys : 0;
+        for (int c = 0; c < ks.nkeys; ++c) if (ks.dt[c] != AQG_INT32 && ks.dt[c] != AQG_UINT32) nk = 0;
+        auto go = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3(aqg_grid(ctx, n / 4 + 1, block, 2, per_cu)), dim3(block), lds, ctx->stream, ks, ds, slot_gid, n, G, reversemap, counts);
+        };
+        if (map) switch (nk) {
+            case 1: go(&dense_assign_kernel<true, 1, true>); break;
+            case 2: go(&dense_assign_kernel<true, 2, true>); break;
+            case 3: go(&dense_assign_kernel<true, 3, true>); break;
+            default: go(&dense_assign_kernel<true, 0, true>); break;
+        } else switch (nk) {
+            case 1: go(&dense_assign_kernel<true, 1, false>); break;
+            case 2: go(&dense_assign_kernel<true, 2, false>); break;
+            case 3: go(&dense_assign_kernel<true, 3, false>); break;
+            default: go(&dense_assign_kernel<true, 0, false>); break;
+        }
     } else {
-        hipLaunchKernelGGL((dense_assign_kernel<false>), dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 8)), dim3(256), 0, ctx->stream, ks, ds, slot_gid, n, G, reversemap, counts);
+        hipLaunchKernelGGL((dense_assign_kernel<false, 0, false>), dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 8)), dim3(256), 0, ctx->stream, ks, ds, slot_gid, n, G, reversemap, counts);
     }
     return aqg_check_launch(ctx, "dense_assign_kernel");
 }
@@ -379,8 +424,8 @@ int aqg_dense_aggregate(aqg_ctx* ctx, const KeySpec& ks, const DenseSpec& ds, co
         aqg_kernel_timer_end(ctx);
         return aqg_check_launch(ctx, "dense_agg_kernel");
     };
-    // key columns all int32 / uint32, at most three of them, up to four accumulators: the register-resident instantiations
-    int nk = ks.nkeys <= 3 && as.nacc >= 1 && as.nacc <= 4 ? ks.nkeys : 0;
+    // key columns all int32 / uint32, at most three of them, at most four accumulators: the register-resident instantiations
+    int nk = ks.nkeys <= 3 && as.nacc <= 4 ? ks.nkeys : 0;
     for (int c = 0; c < ks.nkeys; ++c) if (ks.dt[c] != AQG_INT32 && ks.dt[c] != AQG_UINT32) nk = 0;
     static const bool nk_off = getenv("AQG_DENSE_GENERIC") != nullptr;
     if (nk_off) nk = 0;
@@ -396,7 +441,7 @@ int aqg_dense_aggregate(aqg_ctx* ctx, const KeySpec& ks, const DenseSpec& ds, co
     using B1024 = std::integral_constant<int, 1024>;
     using B512 = std::integral_constant<int, 512>;
     switch (as.nacc) {
-    case 0: return launch(&dense_agg_kernel<0, 1024>);
+    case 0: return by_nk(std::integral_constant<int, 0>{}, B1024{});          // (the first pass of aqg_groupby_build: keys only)
     case 1: return by_nk(std::integral_constant<int, 1>{}, B1024{});
     case 2: return by_nk(std::integral_constant<int, 2>{}, B1024{});
     case 3: return by_nk(std::integral_constant<int, 3>{}, B512{});
