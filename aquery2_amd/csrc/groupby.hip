@@ -1150,7 +1150,17 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         // large inputs: ranges from the first 2^20 rows (a full pass over the key columns costs a third of Q2); the kernels check
         // every row against them and flag a miss, which re-runs the call once with exact ranges (and remembers it in the handle)
         const bool sampled = n >= (1u << 22) && !h->dense_exact;
-        AQG_TRY(aqg_key_ranges(ctx, ks, sampled ? (1u << 20) : n, mins, maxs, &ok));
+        bool cached = sampled && h->range_valid && h->range_nkeys == ks.nkeys && h->range_n == n;
+        for (int c = 0; c < ks.nkeys && cached; ++c) cached = h->range_col[c] == ks.col[c] && h->range_dt[c] == ks.dt[c];
+        if (cached) { for (int c = 0; c < ks.nkeys; ++c) { mins[c] = h->range_min[c]; maxs[c] = h->range_max[c]; } ok = true; }
+        else {
+            AQG_TRY(aqg_key_ranges(ctx, ks, sampled ? (1u << 20) : n, mins, maxs, &ok));
+            h->range_valid = sampled && ok;
+            if (h->range_valid) {
+                h->range_nkeys = ks.nkeys; h->range_n = n;
+                for (int c = 0; c < ks.nkeys; ++c) { h->range_col[c] = ks.col[c]; h->range_dt[c] = ks.dt[c]; h->range_min[c] = mins[c]; h->range_max[c] = maxs[c]; }
+            }
+        }
         dense = ok && aqg_dense_plan(ks, mins, maxs, as, plan.need_count, &dspec);
         dspec.sampled = sampled;
         if (dense && dspec.D <= 1536) {          // (ranges from a sample are fine here: the hashed table takes any key)
@@ -1378,7 +1388,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     uint32_t fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // [0] overflow, [1] occupied slots, [3] a row outside the sampled key ranges, [4], [5] diagnostics
     uint32_t G = 0;
     auto judge_flags = [&]() -> int {
-        if (dense && fl[3]) { h->dense_exact = true; return AQG_ERR_RANGE_MISS; }
+        if (dense && fl[3]) { h->dense_exact = true; h->range_valid = false; return AQG_ERR_RANGE_MISS; }
         if (use_wpart && fl[0]) {
             // a partition larger than LDS holds (fl[5] rows).  A little over: chance (a million partitions sized at mean + 6 sigma) --
             // ONE more try with another seed of the partition hash; far over, or over again: a tuple that dominates the input, which no

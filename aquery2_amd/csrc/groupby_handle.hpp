@@ -39,6 +39,10 @@ struct aqg_groupby {
     bool no_wide_part = false;                  // a wide-tuple partition overflowed its LDS capacity (a dominant tuple, or twice by chance): HBM table from now on
     uint32_t wide_seed = 0;                     // seed of the partition hash: bumped once when a partition overflowed by a little (chance, not a dominant tuple)
     bool dense_exact = false;         // a sampled key range missed values once: take exact ranges from now on
+    // sampled key ranges of the last dense plan made through this handle: a call over the same columns takes them without the
+    // sampling pass and its host round trip (the kernels verify every row against the ranges anyway; a miss drops the cache)
+    bool range_valid = false; int range_nkeys = 0; uint32_t range_n = 0;
+    const void* range_col[MAXKEYS] = {}; int range_dt[MAXKEYS] = {}; long long range_min[MAXKEYS] = {}, range_max[MAXKEYS] = {};
     aqg_groupby* scratch = nullptr;   // reusable handle for aqg_grouped_reduce
     // aqg_groupby_merge_packed: the concatenated shard tables (keys / values), owned by the merged handle
     void* xkeys = nullptr; void* xvals = nullptr;

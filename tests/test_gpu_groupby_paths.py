@@ -358,3 +358,31 @@ print("OK", gb.ngroups)
     assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-3000:]
     gave_up = [l for l in out.stderr.splitlines() if "wide partition plan gave up" in l]
     assert len(gave_up) == 2 and "seed 0)" in gave_up[0] and "seed 0)" not in gave_up[1], out.stderr[-2000:]
+
+
+def test_dense_plan_reuses_sampled_ranges_and_survives_changed_data(gpu, oracle):
+    """a handle keeps the sampled key ranges of its last dense plan: a second call over the same device columns skips the sampling
+    pass; when the columns have been overwritten with values outside those ranges, the kernels' per-row check sends the call
+    through the exact ranges once and the result is still the oracle's"""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    n = 5_000_011                                             # >= 2^22 rows: ranges come from the first 2^20
+    k1, k2 = rng.integers(1, 101, n).astype(np.int32), rng.integers(1, 101, n).astype(np.int32)
+    v = rng.integers(-9, 10, n).astype(np.int32)
+    d1, d2, dv = gpu.to_device(k1), gpu.to_device(k2), gpu.to_device(v)
+    gb = None
+    for _ in range(2):
+        gb = gpu.groupby_agg([d1, d2], [ck.RED_SUM, ck.RED_COUNT], [dv, dv], hint=16384, handle=gb)
+        o = oracle.groupby([k1, k2])
+        assert gb.ngroups == o["ngroups"] and np.array_equal(gb.first_rows(), o["first_rows"])
+        assert gu.same_bits(gb.result(0, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, v, o))
+    k1b = k1.copy()
+    k1b[2_000_000:] = rng.integers(50, 181, n - 2_000_000).astype(np.int32)      # beyond the cached [1, 100], behind the sampled rows
+    gpu._chk(gpu.lib.aqg_h2d(gpu.ctx, C.c_void_p(d1.ptr), k1b.ctypes.data_as(C.c_void_p), C.c_size_t(k1b.nbytes)), "aqg_h2d")
+    for _ in range(2):
+        gb = gpu.groupby_agg([d1, d2], [ck.RED_SUM, ck.RED_COUNT], [dv, dv], hint=32768, handle=gb)
+        o = oracle.groupby([k1b, k2])
+        assert gb.ngroups == o["ngroups"] and np.array_equal(gb.first_rows(), o["first_rows"])
+        assert np.array_equal(gb.counts(), o["counts"])
+        assert gu.same_bits(gb.result(0, ck.RED_SUM, ck.INT32), oracle.grouped_reduce(ck.RED_SUM, v, o))
+    gb.destroy()
