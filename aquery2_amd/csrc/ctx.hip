@@ -234,10 +234,21 @@ int aqg_col_pin(aqg_ctx* ctx, const void* host_ptr, size_t bytes, void** dptr) {
         char* rb = reinterpret_cast<char*>(((uintptr_t)src + PAGE - 1) & ~(uintptr_t)(PAGE - 1));
         char* re = reinterpret_cast<char*>(((uintptr_t)src + c) & ~(uintptr_t)(PAGE - 1));
         bool reg = false;
-        if (!no_register && c >= ((size_t)1 << 20) && re > rb) {
+        // never a range that touches pages this context has already page-locked (overlapping columns: slices of one array).  The runtime
+        // accepts some such registrations, cannot undo them ("Cannot unregister host_ptr") and aborts the process on a later
+        // unregistration ("Memobj map does not have ptr"): seen once in ~6 runs of the overlapping-slices test.  Such a chunk goes
+        // through the staging buffers instead.
+        bool overlaps = false;
+        auto hits = [&](const std::vector<std::pair<void*, size_t>>& regs) {
+            for (const auto& r : regs) if (rb < static_cast<char*>(r.first) + r.second && static_cast<char*>(r.first) < re) return true;
+            return false;
+        };
+        if (re > rb) { overlaps = hits(pin.regs); for (const auto& kv : ctx->pins) overlaps = overlaps || hits(kv.second.regs); }
+        if (!no_register && c >= ((size_t)1 << 20) && re > rb && !overlaps) {
             if (hipHostRegister(rb, (size_t)(re - rb), hipHostRegisterDefault) == hipSuccess) { pin.regs.emplace_back(rb, (size_t)(re - rb)); reg = true; }
             else (void)hipGetLastError();
         }
+        if (overlaps) { ok = staged(o, c); continue; }          // (a direct copy that starts in someone else's locked pages and runs past them faults)
         if (reg) ok = copy(o, (size_t)(rb - src)) && copy(o + (size_t)(rb - src), (size_t)(re - rb)) && copy(o + (size_t)(re - src), (size_t)(src + c - re));
         else ok = copy(o, c);
     }

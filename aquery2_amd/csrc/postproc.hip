@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(RB) radix_hist_kernel(const uint32_t* __restri
 template <bool FIRST, bool LAST>
 __global__ void __launch_bounds__(RB) radix_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n, uint32_t shift,
                                                            uint32_t ntiles, const uint32_t* __restrict__ hist_scanned,
-                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out) {
+                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int nbits /* significant bits of this pass's digit */) {
     constexpr int CELLS = ROUNDS * NW;                 // (round, wavefront) cells in rank order
     __shared__ uint16_t cell[CELLS][256];              // rows of each digit per cell, then their exclusive prefix over the cells
     __shared__ uint32_t gbase[256], lbase[256], wsum[4];
@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(RB) radix_scatter_kernel(const uint32_t* __res
         uint64_t peers = __ballot(live);                // lanes of this wave holding the same digit in this round
 #pragma unroll
         for (int bit = 0; bit < 8; ++bit) {
+            if (bit >= nbits) break;                    // (uniform: the digit's higher bits are zero in every row -- 100 groups: seven ballots)
             uint64_t bal = __ballot((d[r] >> bit) & 1);
             peers &= ((d[r] >> bit) & 1) ? bal : ~bal;
         }
@@ -240,15 +241,16 @@ extern "C" int aqg_groupby_postproc(aqg_groupby* g, uint32_t* offsets_dev, uint3
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const bool first = pass == 0, last = pass + 1 == passes;
         const uint32_t shift = pass * 8;
+        const int nbits = bits <= shift ? 1 : (int)(bits - shift < 8 ? bits - shift : 8);
         uint32_t* kout = last ? nullptr : ((pass & 1) ? k1 : k0);
         uint32_t* vout = last ? row_ids_dev : ((pass & 1) ? v1 : v0);
         if (first) hipLaunchKernelGGL((radix_hist_kernel<true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
         else hipLaunchKernelGGL((radix_hist_kernel<false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
         AQG_TRY(aqg_exclusive_scan_u32(ctx, hist, hcount, bsum));
-        if (first && last) { aqg_kernel_timer_begin(ctx); hipLaunchKernelGGL((radix_scatter_kernel<true, true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout); aqg_kernel_timer_end(ctx); }
-        else if (first) hipLaunchKernelGGL((radix_scatter_kernel<true, false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
-        else if (last) hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
-        else hipLaunchKernelGGL((radix_scatter_kernel<false, false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout);
+        if (first && last) { aqg_kernel_timer_begin(ctx); hipLaunchKernelGGL((radix_scatter_kernel<true, true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout, nbits); aqg_kernel_timer_end(ctx); }
+        else if (first) hipLaunchKernelGGL((radix_scatter_kernel<true, false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout, nbits);
+        else if (last) hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout, nbits);
+        else hipLaunchKernelGGL((radix_scatter_kernel<false, false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout, nbits);
         AQG_TRY(aqg_check_launch(ctx, "radix pass"));
         kin = kout; vin = vout;
     }
