@@ -29,6 +29,10 @@ struct aqg_ctx {
     hipEvent_t ev_flags = nullptr;               // recorded behind the copy of a group table's flag words (run_agg)
     hipStream_t copy_stream = nullptr;           // uploads of borrowed host columns (aqg_col_pin), created on first use
     void* up_buf[2] = {nullptr, nullptr};        // pinned staging of the fallback upload path (ranges the runtime refuses to copy directly)
+    // device buffers of destroyed / outgrown result handles, kept for the next handle (a fresh handle per query -- what the header
+    // layer does -- paid five hipMalloc + five hipFree, the latter each a device-wide synchronisation: ~0.1 ms of a 1.5 ms Q1 call)
+    std::vector<std::pair<void*, size_t>> pool;
+    size_t pool_bytes = 0;
     uint32_t* rank_bm = nullptr;                 // a bitmap over row ids that is ALL ZERO between calls (group ranking of mid-size tables sets and clears only its own bits)
     size_t rank_bm_words = 0;
     hipEvent_t up_ev[2] = {nullptr, nullptr};
@@ -69,6 +73,25 @@ static inline uint32_t aqg_ceil_div(uint32_t n, uint32_t d) { return (uint32_t)(
 // stream (earlier kernels may still read the old arena) -- call aqg_reserve_workspace
 // ahead of timed regions.
 int aqg_ws_reset(aqg_ctx* ctx);
+// small-buffer pool of a context (stream-ordered reuse: every user of these buffers runs on ctx->stream)
+static inline void* aqg_pool_take(aqg_ctx* ctx, size_t need, size_t* cap) {
+    int best = -1;
+    const size_t slack = need * 4 > ((size_t)64 << 10) ? need * 4 : ((size_t)64 << 10);
+    for (int i = 0; i < (int)ctx->pool.size(); ++i)
+        if (ctx->pool[i].second >= need && ctx->pool[i].second <= slack && (best < 0 || ctx->pool[i].second < ctx->pool[best].second)) best = i;
+    if (best < 0) return nullptr;
+    void* p = ctx->pool[best].first;
+    *cap = ctx->pool[best].second;
+    ctx->pool_bytes -= *cap;
+    ctx->pool[best] = ctx->pool.back();
+    ctx->pool.pop_back();
+    return p;
+}
+static inline void aqg_pool_give(aqg_ctx* ctx, void* p, size_t cap) {
+    if (!p) return;
+    if (ctx && cap && cap <= ((size_t)64 << 20) && ctx->pool.size() < 64 && ctx->pool_bytes + cap <= ((size_t)512 << 20)) { ctx->pool.emplace_back(p, cap); ctx->pool_bytes += cap; return; }
+    (void)hipFree(p);
+}
 int aqg_ws_alloc(aqg_ctx* ctx, size_t bytes, void** out);
 int aqg_ws_ensure(aqg_ctx* ctx, size_t bytes);
 template <class T> static inline int aqg_ws_get(aqg_ctx* ctx, size_t count, T** out) {

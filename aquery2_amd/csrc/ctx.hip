@@ -103,6 +103,7 @@ void aqg_ctx_destroy(aqg_ctx* ctx) {
     for (int k = 0; k < 2; ++k) { if (ctx->up_buf[k]) hipHostFree(ctx->up_buf[k]); if (ctx->up_ev[k]) hipEventDestroy(ctx->up_ev[k]); }
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->rank_bm) hipFree(ctx->rank_bm);
+    for (auto& e : ctx->pool) hipFree(e.first);
     if (ctx->host_stage) hipHostFree(ctx->host_stage);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);

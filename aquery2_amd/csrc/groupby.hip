@@ -1032,8 +1032,9 @@ uint32_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return (
 
 int dev_realloc(aqg_ctx* ctx, void** p, size_t* cap, size_t need) {
     if (need <= *cap && *p) return AQG_OK;
-    if (*p) { AQG_HIP(ctx, hipStreamSynchronize(ctx->stream)); AQG_HIP(ctx, hipFree(*p)); *p = nullptr; *cap = 0; }
+    if (*p) { aqg_pool_give(ctx, *p, *cap); *p = nullptr; *cap = 0; }        // (stream-ordered reuse; a buffer too large for the pool is freed, which synchronises)
     size_t want = need < 256 ? 256 : need;
+    if (void* q = aqg_pool_take(ctx, want, cap)) { *p = q; return AQG_OK; }
     hipError_t e = hipMalloc(p, want);
     if (e != hipSuccess) { ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e); return AQG_ERR_NOMEM; }
     *cap = want;
@@ -1684,11 +1685,13 @@ extern "C" {
 
 void aqg_groupby_destroy(aqg_groupby* g) {
     if (!g) return;
-    if (g->ctx) hipStreamSynchronize(g->ctx->stream);
-    for (int k = 0; k < MAXKEYS; ++k) if (g->keys_out[k]) hipFree(g->keys_out[k]);
-    for (int j = 0; j < MAXAGG; ++j) if (g->results[j]) hipFree(g->results[j]);
-    if (g->first_rows) hipFree(g->first_rows);
-    if (g->counts) hipFree(g->counts);
+    // result columns go back to the context's pool (the next handle takes them without a hipMalloc / hipFree pair); what does not
+    // fit there is freed, and hipFree waits for the device
+    aqg_ctx* ctx = g->ctx;
+    for (int k = 0; k < MAXKEYS; ++k) aqg_pool_give(ctx, g->keys_out[k], g->cap_keys[k]);
+    for (int j = 0; j < MAXAGG; ++j) aqg_pool_give(ctx, g->results[j], g->cap_results[j]);
+    aqg_pool_give(ctx, g->first_rows, g->cap_first);
+    aqg_pool_give(ctx, g->counts, g->cap_counts);
     if (g->reversemap) hipFree(g->reversemap);
     if (g->scratch) aqg_groupby_destroy(g->scratch);
     if (g->first_rows64) hipFree(g->first_rows64);
