@@ -1417,7 +1417,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     // still queued (stream-ordered, like every device result of this library), so the host's way to the next call overlaps them.
     // An overflow is noticed with the tail already queued on it: those kernels are bounded by the table and by `gmax`, their
     // results are discarded and the call re-plans as before.
-    const bool defer = n && (fast || plan.sj) && small_rank && !dense && !use_part && !use_wpart;
+    const bool defer = n && (fast || plan.sj) && small_rank && !dense && !use_part && !use_wpart && !h->count_only;
     const uint32_t gupper = (uint32_t)(slots + 1 < 4096 ? slots + 1 : 4096);
     uint32_t* pinned_flags = nullptr;
     if (defer) {
@@ -1426,6 +1426,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_HIP(ctx, hipEventRecord(ctx->ev_flags, ctx->stream));
     }
     if (!defer) AQG_TRY(read_flags());
+    if (h->count_only) { h->ngroups = G; return AQG_OK; }       // (estimate_groups: the rest of the tail would be thrown away)
     if ((defer || G) && n && fast) {
         // two launches: 32 workgroups over the first 32768 rows (where every group of an h2o-like column already shows up), then
         // the whole chip over the rest, whose workgroups leave at once when nothing is missing.  One launch of 256 workgroups
@@ -1524,7 +1525,7 @@ uint64_t estimate_groups(aqg_ctx* ctx, const KeySpec& ks, uint32_t n) {
     Plan none;
     memset(&none, 0, sizeof none);
     aqg_groupby* tmp = new aqg_groupby();
-    tmp->ctx = ctx; tmp->n = s;
+    tmp->ctx = ctx; tmp->n = s; tmp->count_only = true;
     uint64_t est = 0;
     if (run_with_retry(ctx, ks, none, s, 4096, false, tmp, nullptr, nullptr) == AQG_OK && hipStreamSynchronize(ctx->stream) == hipSuccess) {
         const double d = (double)tmp->ngroups, sd = (double)s;
