@@ -33,6 +33,7 @@ struct aqg_ctx {
     // layer does -- paid five hipMalloc + five hipFree, the latter each a device-wide synchronisation: ~0.1 ms of a 1.5 ms Q1 call)
     std::vector<std::pair<void*, size_t>> pool;
     size_t pool_bytes = 0;
+    void* pool_big = nullptr; size_t pool_big_cap = 0;      // ONE large buffer (a row-to-group map of a build: 4 bytes per row) kept for the next handle
     uint32_t* rank_bm = nullptr;                 // a bitmap over row ids that is ALL ZERO between calls (group ranking of mid-size tables sets and clears only its own bits)
     size_t rank_bm_words = 0;
     hipEvent_t up_ev[2] = {nullptr, nullptr};
@@ -75,6 +76,7 @@ static inline uint32_t aqg_ceil_div(uint32_t n, uint32_t d) { return (uint32_t)(
 int aqg_ws_reset(aqg_ctx* ctx);
 // small-buffer pool of a context (stream-ordered reuse: every user of these buffers runs on ctx->stream)
 static inline void* aqg_pool_take(aqg_ctx* ctx, size_t need, size_t* cap) {
+    if (ctx->pool_big && ctx->pool_big_cap >= need && ctx->pool_big_cap <= 2 * need) { void* p = ctx->pool_big; *cap = ctx->pool_big_cap; ctx->pool_big = nullptr; ctx->pool_big_cap = 0; return p; }
     int best = -1;
     const size_t slack = need * 4 > ((size_t)64 << 10) ? need * 4 : ((size_t)64 << 10);
     for (int i = 0; i < (int)ctx->pool.size(); ++i)
@@ -90,6 +92,11 @@ static inline void* aqg_pool_take(aqg_ctx* ctx, size_t need, size_t* cap) {
 static inline void aqg_pool_give(aqg_ctx* ctx, void* p, size_t cap) {
     if (!p) return;
     if (ctx && cap && cap <= ((size_t)64 << 20) && ctx->pool.size() < 64 && ctx->pool_bytes + cap <= ((size_t)512 << 20)) { ctx->pool.emplace_back(p, cap); ctx->pool_bytes += cap; return; }
+    if (ctx && cap > ((size_t)64 << 20) && cap <= ((size_t)8 << 30) && cap > ctx->pool_big_cap) {        // the larger one stays
+        if (ctx->pool_big) (void)hipFree(ctx->pool_big);
+        ctx->pool_big = p; ctx->pool_big_cap = cap;
+        return;
+    }
     (void)hipFree(p);
 }
 int aqg_ws_alloc(aqg_ctx* ctx, size_t bytes, void** out);

@@ -104,6 +104,7 @@ void aqg_ctx_destroy(aqg_ctx* ctx) {
     if (ctx->ws) hipFree(ctx->ws);
     if (ctx->rank_bm) hipFree(ctx->rank_bm);
     for (auto& e : ctx->pool) hipFree(e.first);
+    if (ctx->pool_big) hipFree(ctx->pool_big);
     if (ctx->host_stage) hipHostFree(ctx->host_stage);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);

@@ -1693,7 +1693,7 @@ void aqg_groupby_destroy(aqg_groupby* g) {
     for (int j = 0; j < MAXAGG; ++j) aqg_pool_give(ctx, g->results[j], g->cap_results[j]);
     aqg_pool_give(ctx, g->first_rows, g->cap_first);
     aqg_pool_give(ctx, g->counts, g->cap_counts);
-    if (g->reversemap) hipFree(g->reversemap);
+    aqg_pool_give(ctx, g->reversemap, g->cap_rows * 4);
     if (g->scratch) aqg_groupby_destroy(g->scratch);
     if (g->first_rows64) hipFree(g->first_rows64);
     for (int i = 0; i < 2 * MAXKEYS; ++i) if (g->norm_buf[i]) hipFree(g->norm_buf[i]);
