@@ -272,44 +272,49 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
     __shared__ uint32_t lused, lemit, gbase;
     const K EMPTYK = empty_key<K64>();
     struct Batch { K key[AR]; uint32_t row[AR]; VT v[NA][AR]; };
-    // rows o .. o + AR - 1 of this lane; beyond `e` a clamped index (every load is issued; the caller masks those rows)
-    auto load = [&](uint32_t i0, uint32_t e, Batch& t) {
+    // A step = SB * AR consecutive rows of the partition, AR per lane.  load_full: a step that lies wholly inside the planes -- vector
+    // loads, no branch, no clamp.  It is the ONLY form used for the prefetch of the next step: a loader with two code paths (or a
+    // conditional call) makes hipcc wait for the loads right behind them -- the paths meet in the same registers -- and the
+    // "prefetch" then overlaps nothing (seen in the ISA: vmcnt(0) ten instructions behind the loads; 5.5 ms per 1e9 rows of Q5).
+    auto load_full = [&](uint32_t i0, Batch& t) {
         const uint32_t o = i0 + threadIdx.x * AR;
-        if (o + AR <= e) {
-            __builtin_memcpy(t.key, static_cast<const K*>(rkeys) + o, sizeof t.key);
-            __builtin_memcpy(t.row, rrows + o, sizeof t.row);
-            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
-                if (!in.col[a]) continue;
-                if (!V8 || in.esz[a] == 4) {
-                    uint32_t w[AR];
-                    __builtin_memcpy(w, static_cast<const uint32_t*>(in.col[a]) + o, sizeof w);
-                    _Pragma("unroll") for (int q = 0; q < AR; ++q) t.v[a][q] = w[q];
-                } else {
-                    if constexpr (V8) __builtin_memcpy(t.v[a], static_cast<const uint64_t*>(in.col[a]) + o, sizeof(uint64_t) * AR);
-                }
-            }
-        } else {
-            _Pragma("unroll") for (int q = 0; q < AR; ++q) {
-                const uint32_t i = o + q < e ? o + q : e - 1;
-                t.key[q] = static_cast<const K*>(rkeys)[i]; t.row[q] = rrows[i];
-                _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
-                    if (!in.col[a]) continue;
-                    if (!V8 || in.esz[a] == 4) t.v[a][q] = static_cast<const uint32_t*>(in.col[a])[i];
-                    else if constexpr (V8) t.v[a][q] = static_cast<const uint64_t*>(in.col[a])[i];
-                }
+        __builtin_memcpy(t.key, static_cast<const K*>(rkeys) + o, sizeof t.key);
+        __builtin_memcpy(t.row, rrows + o, sizeof t.row);
+        _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+            if (!in.col[a]) continue;                            // row-index operand: the carried row id, taken at the use (a copy here would wait for the row load)
+            if (!V8 || in.esz[a] == 4) {
+                uint32_t w[AR];
+                __builtin_memcpy(w, static_cast<const uint32_t*>(in.col[a]) + o, sizeof w);
+                _Pragma("unroll") for (int q = 0; q < AR; ++q) t.v[a][q] = w[q];
+            } else {
+                if constexpr (V8) __builtin_memcpy(t.v[a], static_cast<const uint64_t*>(in.col[a]) + o, sizeof(uint64_t) * AR);
             }
         }
-        _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
-            if (in.col[a]) continue;
-            _Pragma("unroll") for (int q = 0; q < AR; ++q) t.v[a][q] = t.row[q];      // row-index operand: the carried row id
+    };
+    // the last, partial step of a partition: row by row from clamped indices (every load is issued; the caller masks rows >= e)
+    auto load_edge = [&](uint32_t i0, uint32_t e, Batch& t) {
+        const uint32_t o = i0 + threadIdx.x * AR;
+        _Pragma("unroll") for (int q = 0; q < AR; ++q) {
+            const uint32_t i = o + q < e ? o + q : e - 1;
+            t.key[q] = static_cast<const K*>(rkeys)[i]; t.row[q] = rrows[i];
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                if (!in.col[a]) continue;
+                if (!V8 || in.esz[a] == 4) t.v[a][q] = static_cast<const uint32_t*>(in.col[a])[i];
+                else if constexpr (V8) t.v[a][q] = static_cast<const uint64_t*>(in.col[a])[i];
+            }
         }
     };
     for (uint32_t part = blockIdx.x; part < NB; part += gridDim.x) {
         const uint32_t b = pstart[(size_t)part * pstride];
         const uint32_t e = part + 1 < NB ? pstart[(size_t)(part + 1) * pstride] : ntotal;
         if (b == e) continue;
+        constexpr uint32_t STEP = SB * AR;
+        const uint32_t nfull = (e - b) / STEP, nsteps = nfull + ((e - b) % STEP ? 1u : 0u);
+        // where a prefetch may always read a whole step: the last full step of this partition, or (a partition shorter than a step)
+        // any step inside the planes -- what it fetches then is never used
+        const uint32_t safe_last = nfull ? b + (nfull - 1) * STEP : (b + STEP <= ntotal ? b : ntotal - STEP);
         Batch cur;
-        load(b, e, cur);                                       // in flight while the tables are cleared
+        load_full(nfull ? b : safe_last, cur);                 // in flight while the tables are cleared
         for (uint32_t s = threadIdx.x; s < cap; s += SB) { ktab[s] = EMPTYK; idtab[s] = (uint16_t)ID_PENDING; }
         for (uint32_t g = threadIdx.x; g < gmax; g += SB) {
             lfirst[g] = NOROW;
@@ -318,11 +323,11 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
         }
         if (threadIdx.x == 0) { lused = 1; lemit = 0; }
         __syncthreads();
-        for (uint32_t i0 = b;;) {
-            const uint32_t inext = i0 + SB * AR;
-            const bool more = inext < e;
+        uint32_t i0 = b;
+        for (uint32_t st = 0; st < nsteps; ++st) {
+            if (st >= nfull) load_edge(i0, e, cur);            // (the last, partial step: nothing was prefetched for it)
             Batch nxt;
-            if (more) load(inext, e, nxt);                     // the next step's rows are in flight while this step's are aggregated
+            { const uint32_t inext = i0 + STEP; load_full(inext <= safe_last && st + 1 < nfull ? inext : safe_last, nxt); }   // in flight while this step is aggregated
             __builtin_amdgcn_sched_barrier(0);
             const uint32_t o = i0 + threadIdx.x * AR;
             uint32_t slot[AR];
@@ -378,7 +383,7 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
             }
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
                 uint64_t* acc = lacc + (size_t)a * gmax;
-#define AQG_ROWS(expr) _Pragma("unroll") for (int q = 0; q < AR; ++q) if (ok[q]) { const VT x = cur.v[a][q]; (void)x; expr; } break
+#define AQG_ROWS(expr) _Pragma("unroll") for (int q = 0; q < AR; ++q) if (ok[q]) { const VT x = in.col[a] ? cur.v[a][q] : (VT)cur.row[q]; (void)x; expr; } break
                 switch (ops.opc[a]) {
                 case OPC_ADDI_I32: AQG_ROWS(atomicAdd(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(long long)(int32_t)(uint32_t)x));
                 case OPC_ADDI_U32: AQG_ROWS(atomicAdd(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(uint32_t)x));
@@ -394,9 +399,8 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
                 }
 #undef AQG_ROWS
             }
-            if (!more) break;
             cur = nxt;
-            i0 = inext;
+            i0 += STEP;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
