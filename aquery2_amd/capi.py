@@ -563,6 +563,43 @@ class Device:
         self.sync()
         return out.to_host()
 
+    # -- per-group scans / windows / two-column aggregates over the flat layout of a build (include/aqg.h)
+    def group_offsets(self, gb):
+        self.lib.aqg_groupby_offsets.restype = C.c_void_p
+        p = self.lib.aqg_groupby_offsets(gb.h)
+        assert p, "aqg_groupby_offsets"
+        return DevBuf(self, p, np.uint32, gb.ngroups + 1, owned=False).to_host()
+
+    def grouped_flatten(self, gb, x, keep=False):
+        xd = self._dev(x)
+        out = self.empty(xd.n, xd.dtype)
+        self._chk(self.lib.aqg_grouped_flatten(self.ctx, gb.h, xd.tag, C.c_void_p(xd.ptr), C.c_void_p(out.ptr)), "aqg_grouped_flatten")
+        return out if keep else out.to_host()
+
+    def grouped_scan(self, gb, op, x, w=0, flat=False, keep=False, out=None):
+        """per-group scan of a column: `x` in row layout (flat=False: flatten + scan in one call) or already flat"""
+        xd = self._dev(x)
+        ot = self.lib.aqg_scan_out_dtype(op, xd.tag)
+        out = out if out is not None else self.empty(xd.n, TAG2NP[ot])
+        fn = self.lib.aqg_grouped_scan_flat if flat else self.lib.aqg_grouped_scan
+        self._chk(fn(self.ctx, gb.h, op, xd.tag, C.c_void_p(xd.ptr), C.c_uint32(w), C.c_void_p(out.ptr)), "aqg_grouped_scan")
+        return out if keep else out.to_host()
+
+    def grouped_reduce_flat(self, gb, op, xflat):
+        xd = self._dev(xflat)
+        ot = self.lib.aqg_reduce_out_dtype(op, xd.tag)
+        out = self.empty(gb.ngroups, TAG2NP[ot])
+        self._chk(self.lib.aqg_grouped_reduce_flat(self.ctx, gb.h, op, xd.tag, C.c_void_p(xd.ptr), C.c_void_p(out.ptr)), "aqg_grouped_reduce_flat")
+        self.sync()
+        return out.to_host()
+
+    def grouped_corr(self, gb, x, y):
+        xd, yd = self._dev(x), self._dev(y)
+        out = self.empty(gb.ngroups, np.float64)
+        self._chk(self.lib.aqg_grouped_corr(self.ctx, gb.h, xd.tag, C.c_void_p(xd.ptr), yd.tag, C.c_void_p(yd.ptr), C.c_void_p(out.ptr)), "aqg_grouped_corr")
+        self.sync()
+        return out.to_host()
+
     # -- join
     def join_pairs(self, build, probe):
         bd, pd = self._dev(build), self._dev(probe)

@@ -111,6 +111,16 @@ int aqg_host_stage(aqg_ctx* ctx, size_t bytes, void** out);
 // in-place exclusive scan of `count` uint32 words; bsum: scratch of ceil(count/2048) words (postproc.hip)
 int aqg_exclusive_scan_u32(aqg_ctx* ctx, uint32_t* d, uint64_t count, uint32_t* bsum);
 
+// postproc.hip: the stable radix passes over a build's group-id column.  x == nullptr: descending row ids per group -> row_ids_dev; else the
+// `esz`-byte elements of column x in the flat row-list layout -> xout.  ws_managed: the caller reset the workspace and sized it with
+// aqg_postproc_ws_bytes (so that its own sub-allocations survive)
+struct aqg_groupby;
+size_t aqg_postproc_ws_bytes(uint32_t n, uint32_t G, int esz);
+int aqg_radix_by_group(aqg_ctx* ctx, aqg_groupby* g, uint32_t* row_ids_dev, const void* x, int esz, void* xout, bool ws_managed);
+int aqg_group_offsets(aqg_ctx* ctx, const aqg_groupby* g, uint32_t* offsets_dev, uint32_t* bsum);
+// groupby.hip: out[g] = op(x[rows whose id in gid_col is g]) through the group-by plans (gid_col: n dense ids in first-occurrence order)
+extern "C" int aqg_grouped_reduce_keyed(aqg_ctx* ctx, aqg_groupby* g, const uint32_t* gid_col, int op, int t, const void* x, void* out_dev);
+
 // internal aggregate of aqg_groupby_agg (not in aqg.h): the sum of squares, typed like SUM -- the second moment the sharded call ships for VAR / STDDEV
 constexpr int AQG_RED_SUMSQ = 64;
 

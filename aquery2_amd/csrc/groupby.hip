@@ -1695,6 +1695,10 @@ void aqg_groupby_destroy(aqg_groupby* g) {
     aqg_pool_give(ctx, g->counts, g->cap_counts);
     aqg_pool_give(ctx, g->reversemap, g->cap_rows * 4);
     if (g->scratch) aqg_groupby_destroy(g->scratch);
+    aqg_pool_give(ctx, g->flat_off, g->cap_flat_off);
+    aqg_pool_give(ctx, g->flat_heads, g->cap_flat_heads);
+    aqg_pool_give(ctx, g->flat_short, g->cap_flat_short);
+    aqg_pool_give(ctx, g->flat_gid, g->cap_flat_gid);
     if (g->first_rows64) hipFree(g->first_rows64);
     for (int i = 0; i < 2 * MAXKEYS; ++i) if (g->norm_buf[i]) hipFree(g->norm_buf[i]);
     if (g->xkeys) hipFree(g->xkeys);
@@ -1862,6 +1866,7 @@ int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void
     memset(&plan, 0, sizeof plan);
     aqg_groupby* h = *out ? *out : new aqg_groupby();
     h->ctx = ctx; h->n = n; h->sharded = false;
+    h->flat_valid = h->flat_gid_valid = false; h->flat_short_w = 0;
     GTable gt; uint32_t* slot_gid = nullptr; uint32_t* occ_dev = nullptr;
     DenseOut dn;
     dn.used = false;
@@ -1907,10 +1912,42 @@ int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void
 
 
 namespace {
+// corr(x, y) of every group from its five sums (server/aggregations.h:401-406): all of them __int128 in the reference (InnerType there is
+// the Coercion STRUCT, so GetLongType<InnerType> is __int128 whatever the inputs are), len * s wraps in 128 bits, FPType = double
+__global__ void __launch_bounds__(256) corr_final_kernel(const aqg_i128* __restrict__ sx, const aqg_i128* __restrict__ sx2, const aqg_i128* __restrict__ sy,
+                                                        const aqg_i128* __restrict__ sy2, const aqg_i128* __restrict__ sxy, const uint32_t* __restrict__ counts,
+                                                        uint32_t G, double* __restrict__ out) {
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x) {
+        const aqg_i128 len = i128_from_u64(counts[g]);
+        const double a = i128_to_double(mul_128(len, sxy[g])) - i128_to_double(mul_128(sx[g], sy[g]));
+        const double b = i128_to_double(mul_128(len, sx2[g])) - i128_to_double(mul_128(sx[g], sx[g]));
+        const double c = i128_to_double(mul_128(len, sy2[g])) - i128_to_double(mul_128(sy[g], sy[g]));
+        out[g] = a / sqrt(b * c);
+    }
+}
 __global__ void __launch_bounds__(256) take_rows_kernel(const uint64_t* __restrict__ acc_rows, uint32_t G, uint32_t* __restrict__ rows) {
     for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x) rows[g] = (uint32_t)acc_rows[g];
 }
 } // namespace
+
+// the core of aqg_grouped_reduce: groups by a column of dense group ids (the build's reversemap, or the group index of every position
+// of the flat layout -- segscan.hip) through the ordinary group-by plans; ids appear in first-occurrence order, so group g is result g
+int aqg_grouped_reduce_keyed(aqg_ctx* ctx, aqg_groupby* g, const uint32_t* gid_col, int op, int t, const void* x, void* out_dev) {
+    const uint32_t G = g->ngroups, n = g->n;
+    const int kdt = AQG_UINT32;
+    const void* kcol = gid_col;
+    KeySpec ks;
+    AQG_TRY(make_keyspec(ctx, 1, &kdt, &kcol, n, &ks));
+    if (!g->scratch) g->scratch = new aqg_groupby();
+    aqg_groupby* h = g->scratch;
+    h->ctx = ctx; h->n = n; h->has_reversemap = false;
+    Plan plan;
+    AQG_TRY(make_plan(ctx, 1, &op, &t, &x, n, &plan));
+    AQG_TRY(run_with_retry(ctx, ks, plan, n, G, false, h, nullptr, nullptr));
+    if (h->ngroups != G) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_reduce: group ids are not dense");
+    AQG_HIP(ctx, hipMemcpyAsync(out_dev, h->results[0], (size_t)G * aqg_dtype_size(aqg_reduce_out_dtype(op, t)), hipMemcpyDeviceToDevice, ctx->stream));
+    return AQG_OK;
+}
 
 // out[g] = op(col[vecs[g]]) for every group in one pass (generated loop engine/ast.py:722-789).
 // The group id column (reversemap) is itself a dense first-occurrence key, so grouping by it
@@ -1944,12 +1981,52 @@ int aqg_grouped_reduce(aqg_ctx* ctx, const aqg_groupby* gc, int op, int t, const
         hipLaunchKernelGGL(take_rows_kernel, dim3(aqg_grid(ctx, G, 256, 1, 8)), dim3(256), 0, ctx->stream, (const uint64_t*)h->results[0], G, rows);
         return aqg_gather(ctx, t, x, rows, G, out_dev);
     }
-    Plan plan;
-    AQG_TRY(make_plan(ctx, 1, &op, &t, &x, n, &plan));
-    AQG_TRY(run_with_retry(ctx, ks, plan, n, G, false, h, nullptr, nullptr));
-    if (h->ngroups != G) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_reduce: group ids are not dense");
-    AQG_HIP(ctx, hipMemcpyAsync(out_dev, h->results[0], (size_t)G * aqg_dtype_size(aqg_reduce_out_dtype(op, t)), hipMemcpyDeviceToDevice, ctx->stream));
-    return AQG_OK;
+    return aqg_grouped_reduce_keyed(ctx, g, g->reversemap, op, t, x, out_dev);
+}
+
+// out[g] = corr(x[vecs[g]], y[vecs[g]]) for every group (h2o Q9 `pow(corr(v1, v2), 2) BY id2, id4`, benchmark/h2o/groupby.sql:20; the generated
+// loop engine/ast.py:749-784 emits `corr(v1[val], v2[val])`): the product column x * y (evaluated in the C++ type of the operands like the
+// reference's `x[i] * y[i]`, aggregations.h:397), then ONE grouped pass with five accumulators -- sum x, sum x*x, sum y, sum y*y, sum xy --
+// and the reference's formula per group.  Integer columns of up to four bytes (every sum then fits a 64-bit accumulator exactly).
+int aqg_grouped_corr(aqg_ctx* ctx, aqg_groupby* g, int tx, const void* x, int ty, const void* y, double* out_dev) {
+    if (!ctx || !g || ((!x || !y) && g->n) || !out_dev) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_corr: bad argument");
+    if (!g->has_reversemap || !g->has_counts) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_corr: handle has no reversemap (use aqg_groupby_build)");
+    auto small_int = [](int dt) { return dt == AQG_INT8 || dt == AQG_INT16 || dt == AQG_INT32 || dt == AQG_UINT8 || dt == AQG_UINT16 || dt == AQG_UINT32; };
+    if (!small_int(tx) || !small_int(ty)) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_grouped_corr: integer columns of up to four bytes (others: aqg_corr per group)");
+    const uint32_t G = g->ngroups, n = g->n;
+    if (G == 0) return AQG_OK;
+    const int pt = (tx == AQG_UINT32 || ty == AQG_UINT32) ? AQG_UINT32 : AQG_INT32;      // usual arithmetic conversions of the two operands
+    size_t cap = 0;
+    void* xy = aqg_pool_take(ctx, (size_t)n * 4 + 64, &cap);
+    if (!xy) {
+        cap = (size_t)n * 4 + 64;
+        hipError_t e = hipMalloc(&xy, cap);
+        if (e != hipSuccess) { (void)hipGetLastError(); return aqg_fail(ctx, AQG_ERR_NOMEM, "aqg_grouped_corr: product column"); }
+    }
+    int rc = aqg_ewise(ctx, AQG_OP_MUL, AQG_VEC_VEC, tx, x, ty, y, pt, xy, n);
+    if (rc == AQG_OK) {
+        const int kdt = AQG_UINT32;
+        const void* kcol = g->reversemap;
+        KeySpec ks;
+        rc = make_keyspec(ctx, 1, &kdt, &kcol, n, &ks);
+        if (!g->scratch) g->scratch = new aqg_groupby();
+        aqg_groupby* h = g->scratch;
+        h->ctx = ctx; h->n = n; h->has_reversemap = false;
+        const int ops[5] = {AQG_RED_SUM, AQG_RED_SUMSQ, AQG_RED_SUM, AQG_RED_SUMSQ, AQG_RED_SUM};
+        const int dts[5] = {tx, tx, ty, ty, pt};
+        const void* vals[5] = {x, x, y, y, xy};
+        Plan plan;
+        if (rc == AQG_OK) rc = make_plan(ctx, 5, ops, dts, vals, n, &plan);
+        if (rc == AQG_OK) rc = run_with_retry(ctx, ks, plan, n, G, false, h, nullptr, nullptr);
+        if (rc == AQG_OK && h->ngroups != G) rc = aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_corr: group ids are not dense");
+        if (rc == AQG_OK) {
+            hipLaunchKernelGGL(corr_final_kernel, dim3(aqg_grid(ctx, G, 256, 1, 8)), dim3(256), 0, ctx->stream, (const aqg_i128*)h->results[0], (const aqg_i128*)h->results[1],
+                               (const aqg_i128*)h->results[2], (const aqg_i128*)h->results[3], (const aqg_i128*)h->results[4], g->counts, G, out_dev);
+            rc = aqg_check_launch(ctx, "corr_final_kernel");
+        }
+    }
+    aqg_pool_give(ctx, xy, cap);           // (stream-ordered reuse: every later user of the buffer runs on this stream)
+    return rc;
 }
 
 } // extern "C"

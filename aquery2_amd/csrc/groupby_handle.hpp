@@ -45,6 +45,12 @@ struct aqg_groupby {
     bool range_valid = false; int range_nkeys = 0; uint32_t range_n = 0;
     const void* range_col[MAXKEYS] = {}; int range_dt[MAXKEYS] = {}; long long range_min[MAXKEYS] = {}, range_max[MAXKEYS] = {};
     aqg_groupby* scratch = nullptr;   // reusable handle for aqg_grouped_reduce
+    // the flat row-list layout of a build (segscan.hip): group g owns positions [flat_off[g], flat_off[g+1]) -- ht_postproc's offsets --
+    // and `flat_heads` is a bitmap over positions, bit p set = a group starts at p (bit n is set too: the end).  Made on first use.
+    uint32_t* flat_off = nullptr; uint32_t* flat_heads = nullptr; uint32_t* flat_short = nullptr; uint32_t* flat_gid = nullptr;
+    size_t cap_flat_off = 0, cap_flat_heads = 0, cap_flat_short = 0, cap_flat_gid = 0;
+    bool flat_valid = false, flat_gid_valid = false;
+    uint32_t flat_short_w = 0;        // flat_short marks the heads of groups with at most this many rows (ratiow's degenerate window); 0: not made
     // aqg_groupby_merge_packed: the concatenated shard tables (keys / values), owned by the merged handle
     void* xkeys = nullptr; void* xvals = nullptr;
     size_t cap_xkeys = 0, cap_xvals = 0;

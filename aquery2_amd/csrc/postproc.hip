@@ -119,10 +119,17 @@ __global__ void __launch_bounds__(RB) radix_hist_kernel(const uint32_t* __restri
 // (round, wavefront) cells + its rank inside its own wavefront (match-any by 8 ballots).  The tile is then laid out digit-major
 // in LDS and streamed out, so consecutive lanes write consecutive addresses of a digit's run (direct 4-byte scatters from
 // registers ran at 15 % of the HBM roofline: h2o Q1 groups, 1e9 rows, 10.2 ms).
-template <bool FIRST, bool LAST>
+// PAY: the value that travels with a row.  0: its row id (ht_postproc).  1: the row's element of a value column `x` (aqg_grouped_flatten:
+// the column in the flat row-list layout, x[vecs[g][i]] for every group) -- read coalesced in the FIRST pass (the rows are walked
+// backwards, like the group ids), carried as one dword plane (two for 8-byte elements: `vals2`), written with its own element
+// size in the LAST pass.  Carrying the value costs what carrying the row id costs, and saves the gather through the row ids
+// afterwards: 64 B of line per row for a few hundred groups (a group's rows lie ~G rows apart).
+struct PayIO { const void* x; void* xout; int esz; const uint32_t* vals2; uint32_t* vals2_out; };
+template <bool FIRST, bool LAST, int PAY>
 __global__ void __launch_bounds__(RB) radix_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n, uint32_t shift,
                                                            uint32_t ntiles, const uint32_t* __restrict__ hist_scanned,
-                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int nbits /* significant bits of this pass's digit */) {
+                                                           uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int nbits /* significant bits of this pass's digit */,
+                                                           PayIO io) {
     constexpr int CELLS = ROUNDS * NW;                 // (round, wavefront) cells in rank order
     __shared__ uint16_t cell[CELLS][256];              // rows of each digit per cell, then their exclusive prefix over the cells
     __shared__ uint32_t gbase[256], lbase[256], wsum[4];
@@ -135,9 +142,22 @@ __global__ void __launch_bounds__(RB) radix_scatter_kernel(const uint32_t* __res
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     for (uint32_t i = threadIdx.x; i < CELLS * 256 / 2; i += RB) reinterpret_cast<uint32_t*>(&cell[0][0])[i] = 0;
     if (threadIdx.x < 256) gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * ntiles + tile];
-    uint32_t k[ROUNDS], v[ROUNDS], d[ROUNDS], rank[ROUNDS];
+    uint32_t k[ROUNDS], v[ROUNDS], v2[ROUNDS], d[ROUNDS], rank[ROUNDS];
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) load_pair<FIRST>(keys, vals, n, tbase + r * RB + threadIdx.x, k[r], v[r]);
+    for (int r = 0; r < ROUNDS; ++r) {
+        load_pair<FIRST>(keys, vals, n, tbase + r * RB + threadIdx.x, k[r], v[r]);
+        v2[r] = 0;
+        if constexpr (PAY != 0) {
+            const uint32_t p = tbase + r * RB + threadIdx.x, q = p < n ? p : n - 1;
+            if constexpr (FIRST) {                      // v[r] is the row id here: fetch the row's element (wave-uniform size switch)
+                const uint32_t row = v[r];
+                if (io.esz == 4) v[r] = static_cast<const uint32_t*>(io.x)[row];
+                else if (io.esz == 8) { const uint2 t = static_cast<const uint2*>(io.x)[row]; v[r] = t.x; v2[r] = t.y; }
+                else if (io.esz == 2) v[r] = static_cast<const uint16_t*>(io.x)[row];
+                else v[r] = static_cast<const uint8_t*>(io.x)[row];
+            } else if (io.esz == 8) v2[r] = io.vals2[q];
+        }
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -184,10 +204,48 @@ __global__ void __launch_bounds__(RB) radix_scatter_kernel(const uint32_t* __res
         }
     }
     __syncthreads();
+    if constexpr (PAY != 0 && LAST) {                   // the flat column itself, in its own element size
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t j = r * RB + threadIdx.x;
+            if (j < nrows) {
+                const size_t o = (size_t)j + delta[j];
+                if (io.esz == 4) static_cast<uint32_t*>(io.xout)[o] = stage[j];
+                else if (io.esz == 8) static_cast<uint32_t*>(io.xout)[2 * o] = stage[j];
+                else if (io.esz == 2) static_cast<uint16_t*>(io.xout)[o] = (uint16_t)stage[j];
+                else static_cast<uint8_t*>(io.xout)[o] = (uint8_t)stage[j];
+            }
+        }
+        if (io.esz == 8) {                              // (uniform) the high halves take the staging buffer next
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) if (r * RB + threadIdx.x < nrows) stage[pos[r]] = v2[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const uint32_t j = r * RB + threadIdx.x;
+                if (j < nrows) static_cast<uint32_t*>(io.xout)[2 * ((size_t)j + delta[j]) + 1] = stage[j];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const uint32_t j = r * RB + threadIdx.x;
         if (j < nrows) vals_out[j + delta[j]] = stage[j];
+    }
+    if constexpr (PAY != 0) {
+        if (io.esz == 8) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) if (r * RB + threadIdx.x < nrows) stage[pos[r]] = v2[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                const uint32_t j = r * RB + threadIdx.x;
+                if (j < nrows) io.vals2_out[j + delta[j]] = stage[j];
+            }
+        }
     }
     if constexpr (!LAST) {
         __syncthreads();
@@ -208,51 +266,85 @@ __global__ void __launch_bounds__(256) copy_counts_kernel(const uint32_t* __rest
 
 } // namespace
 
-extern "C" int aqg_groupby_postproc(aqg_groupby* g, uint32_t* offsets_dev, uint32_t* row_ids_dev) {
-    if (!g || !offsets_dev || (!row_ids_dev && g->n)) return AQG_ERR_ARG;
-    aqg_ctx* ctx = g->ctx;
-    if (!g->has_reversemap || !g->has_counts) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_postproc: handle was not made by aqg_groupby_build");
+// The radix passes over the group-id column of a build.  `x == nullptr`: row ids -> row_ids_dev (ht_postproc); else the value column
+// `x` of `esz`-byte elements -> xout in the flat layout.  `ws_managed`: the caller has reset and sized the workspace (aqg_postproc_ws_bytes).
+size_t aqg_postproc_ws_bytes(uint32_t n, uint32_t G, int esz) {
+    const uint32_t ntiles = aqg_ceil_div(n, RT);
+    uint32_t bits = 0;
+    while (bits < 32 && (1ull << bits) < G) ++bits;
+    const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;
+    const uint64_t hcount = (uint64_t)256 * ntiles;
+    size_t need = hcount * 4 + ((hcount + 2047) / 2048 + (G + 2048) / 2048 + 16) * 4 + 8192;
+    if (passes > 1) need += (size_t)n * (esz == 8 ? 24 : 16) + 8192;
+    return need;
+}
+int aqg_radix_by_group(aqg_ctx* ctx, aqg_groupby* g, uint32_t* row_ids_dev, const void* x, int esz, void* xout, bool ws_managed) {
     const uint32_t n = g->n, G = g->ngroups;
+    if (n == 0) return AQG_OK;
     const uint32_t ntiles = aqg_ceil_div(n, RT);
     uint32_t bits = 0;
     while (bits < 32 && (1ull << bits) < G) ++bits;
     const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;
     const uint64_t hcount = (uint64_t)256 * ntiles;
     const uint32_t grid8 = (ntiles + 7) / 8 * 8;                 // xcd_tile: eight interleaved walks over the tiles
-
-    AQG_TRY(aqg_ws_reset(ctx));
-    size_t need = hcount * 4 + ((hcount + 2047) / 2048 + (G + 2048) / 2048 + 16) * 4 + 8192;
-    if (passes > 1) need += (size_t)n * 16 + 4096;
-    AQG_TRY(aqg_ws_ensure(ctx, need));
-    uint32_t *hist, *bsum, *k0 = nullptr, *v0 = nullptr, *k1 = nullptr, *v1 = nullptr;
+    if (!ws_managed) { AQG_TRY(aqg_ws_reset(ctx)); AQG_TRY(aqg_ws_ensure(ctx, aqg_postproc_ws_bytes(n, G, esz))); }
+    uint32_t *hist, *bsum, *k0 = nullptr, *v0 = nullptr, *k1 = nullptr, *v1 = nullptr, *w0 = nullptr, *w1 = nullptr;
     AQG_TRY(aqg_ws_get(ctx, hcount ? hcount : 1, &hist));
     AQG_TRY(aqg_ws_get(ctx, (hcount + 2047) / 2048 + (G + 2048) / 2048 + 16, &bsum));
     if (passes > 1) {
         AQG_TRY(aqg_ws_get(ctx, n, &k0)); AQG_TRY(aqg_ws_get(ctx, n, &v0));
         AQG_TRY(aqg_ws_get(ctx, n, &k1)); AQG_TRY(aqg_ws_get(ctx, n, &v1));
+        if (x && esz == 8) { AQG_TRY(aqg_ws_get(ctx, n, &w0)); AQG_TRY(aqg_ws_get(ctx, n, &w1)); }
     }
-    // offsets = exclusive scan of counts, offsets[G] = n
-    hipLaunchKernelGGL(copy_counts_kernel, dim3(aqg_grid(ctx, G + 1, 256, 1, 8)), dim3(256), 0, ctx->stream, g->counts, G, offsets_dev);
-    AQG_TRY(aqg_exclusive_scan_u32(ctx, offsets_dev, (uint64_t)G + 1, bsum));
-    if (n == 0) return AQG_OK;
-
     const uint32_t* kin = g->reversemap;
     const uint32_t* vin = nullptr;
+    const uint32_t* win = nullptr;
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const bool first = pass == 0, last = pass + 1 == passes;
         const uint32_t shift = pass * 8;
         const int nbits = bits <= shift ? 1 : (int)(bits - shift < 8 ? bits - shift : 8);
         uint32_t* kout = last ? nullptr : ((pass & 1) ? k1 : k0);
         uint32_t* vout = last ? row_ids_dev : ((pass & 1) ? v1 : v0);
+        uint32_t* wout = last ? nullptr : ((pass & 1) ? w1 : w0);
+        PayIO io{x, xout, esz, win, wout};
         if (first) hipLaunchKernelGGL((radix_hist_kernel<true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
         else hipLaunchKernelGGL((radix_hist_kernel<false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
         AQG_TRY(aqg_exclusive_scan_u32(ctx, hist, hcount, bsum));
-        if (first && last) { aqg_kernel_timer_begin(ctx); hipLaunchKernelGGL((radix_scatter_kernel<true, true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout, nbits); aqg_kernel_timer_end(ctx); }
-        else if (first) hipLaunchKernelGGL((radix_scatter_kernel<true, false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout, nbits);
-        else if (last) hipLaunchKernelGGL((radix_scatter_kernel<false, true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout, nbits);
-        else hipLaunchKernelGGL((radix_scatter_kernel<false, false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout, nbits);
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout, nbits, io); };
+        if (first && last) aqg_kernel_timer_begin(ctx);
+        if (x) {
+            if (first && last) go(&radix_scatter_kernel<true, true, 1>);
+            else if (first) go(&radix_scatter_kernel<true, false, 1>);
+            else if (last) go(&radix_scatter_kernel<false, true, 1>);
+            else go(&radix_scatter_kernel<false, false, 1>);
+        } else {
+            if (first && last) go(&radix_scatter_kernel<true, true, 0>);
+            else if (first) go(&radix_scatter_kernel<true, false, 0>);
+            else if (last) go(&radix_scatter_kernel<false, true, 0>);
+            else go(&radix_scatter_kernel<false, false, 0>);
+        }
+        if (first && last) aqg_kernel_timer_end(ctx);
         AQG_TRY(aqg_check_launch(ctx, "radix pass"));
-        kin = kout; vin = vout;
+        kin = kout; vin = vout; win = wout;
     }
     return AQG_OK;
+}
+// offsets[G+1] = exclusive scan of the group sizes (ht_base after ht_postproc, hasher.h:186-190); bsum: (G + 2048) / 2048 + 16 words
+int aqg_group_offsets(aqg_ctx* ctx, const aqg_groupby* g, uint32_t* offsets_dev, uint32_t* bsum) {
+    const uint32_t G = g->ngroups;
+    hipLaunchKernelGGL(copy_counts_kernel, dim3(aqg_grid(ctx, G + 1, 256, 1, 8)), dim3(256), 0, ctx->stream, g->counts, G, offsets_dev);
+    return aqg_exclusive_scan_u32(ctx, offsets_dev, (uint64_t)G + 1, bsum);
+}
+
+extern "C" int aqg_groupby_postproc(aqg_groupby* g, uint32_t* offsets_dev, uint32_t* row_ids_dev) {
+    if (!g || !offsets_dev || (!row_ids_dev && g->n)) return AQG_ERR_ARG;
+    aqg_ctx* ctx = g->ctx;
+    if (!g->has_reversemap || !g->has_counts) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_postproc: handle was not made by aqg_groupby_build");
+    const uint32_t n = g->n, G = g->ngroups;
+    AQG_TRY(aqg_ws_reset(ctx));
+    AQG_TRY(aqg_ws_ensure(ctx, aqg_postproc_ws_bytes(n, G, 4) + ((size_t)(G + 2048) / 2048 + 16) * 4 + 256));
+    uint32_t* bsum0;
+    AQG_TRY(aqg_ws_get(ctx, (G + 2048) / 2048 + 16, &bsum0));
+    AQG_TRY(aqg_group_offsets(ctx, g, offsets_dev, bsum0));      // offsets = exclusive scan of counts, offsets[G] = n
+    return aqg_radix_by_group(ctx, g, row_ids_dev, nullptr, 4, nullptr, /*ws_managed=*/true);
 }

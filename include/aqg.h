@@ -207,6 +207,29 @@ int aqg_str_encode(aqg_ctx* ctx, const char* const* strs_host, uint32_t n, uint3
  * (engine/ast.py:722-789, mem_opt.cpp:50-65).  Output dtype as aqg_reduce.     */
 int aqg_grouped_reduce(aqg_ctx* ctx, const aqg_groupby* g, int op, int t, const void* x, void* out_dev);
 
+/* ---- per-group scans / windows / two-column aggregates: what the reference's own queries put inside the generated group loop -------
+ * `SELECT sym, avgs(5, price) ... ASSUMING ASC time GROUP BY sym` (benchmark/quries/Aquery/q7.a), `mins(2, sales) ... group by Mont`
+ * (tests/moving_avg.a:13), `max(ratios(x)) ... group by ID` (tests/q4.a:23), `pow(corr(v1, v2), 2) BY id2, id4`
+ * (benchmark/h2o/groupby.sql:20) are emitted as  for g: out[g] = f(col[vecs[g]], ...)  (engine/ast.py:722-789); the frozen sample
+ * mem_opt.cpp:53-63 writes vector results into ONE flat buffer sliced by the group offsets: `col[i].init_from(vecs[i].size, buf + offsets[i])`.
+ * The FLAT LAYOUT of a build is that buffer's: position offsets[g] + i <-> element i of vecs[g] (ht_postproc order: DESCENDING row id
+ * inside a group, hasher.h:192-196).  Every call below handles ALL groups in a number of launches that does not depend on the group count.
+ *   aqg_groupby_offsets      device offsets[G+1] (exclusive scan of the group sizes; owned by the handle)
+ *   aqg_grouped_flatten      out_flat[offsets[g] + i] = x[vecs[g][i]]: a column (1-, 2-, 4-, 8-byte elements) brought into the flat layout by
+ *                            value-carrying radix passes over the group ids (no row lists, no gather)
+ *   aqg_grouped_scan_flat    out_flat = the scan `op` (aqg_scan's ops, window w) of every group's slice of xflat, restarted at every
+ *                            group start; result dtype aqg_scan_out_dtype.  Integer results are exact, as for aqg_scan.
+ *   aqg_grouped_scan         flatten + scan_flat in one call (x in row layout)
+ *   aqg_grouped_reduce_flat  out[g] = op(xflat[offsets[g] .. offsets[g+1])): reductions OF scan results (aqg_reduce's ops and dtypes)
+ *   aqg_grouped_corr         out[g] = corr(x[vecs[g]], y[vecs[g]]) (aggregations.h:383-407: five 128-bit sums, the products in the C++ type
+ *                            of the operands), x / y in ROW layout, integer columns of up to four bytes; doubles in out_dev[G]           */
+const uint32_t* aqg_groupby_offsets(aqg_groupby* g);
+int aqg_grouped_flatten(aqg_ctx* ctx, aqg_groupby* g, int t, const void* x, void* out_flat);
+int aqg_grouped_scan_flat(aqg_ctx* ctx, aqg_groupby* g, int op, int t, const void* xflat, uint32_t w, void* out_flat);
+int aqg_grouped_scan(aqg_ctx* ctx, aqg_groupby* g, int op, int t, const void* x, uint32_t w, void* out_flat);
+int aqg_grouped_reduce_flat(aqg_ctx* ctx, aqg_groupby* g, int op, int t, const void* xflat, void* out_dev);
+int aqg_grouped_corr(aqg_ctx* ctx, aqg_groupby* g, int tx, const void* x, int ty, const void* y, double* out_dev);
+
 /* fused single-pass group-by + aggregates (h2o Q1..Q5 shape): reads each key and value
  * column exactly once.  Group order = first occurrence, as aqg_groupby_build.  Result j
  * (aqg_groupby_agg_result) has ngroups elements of aqg_reduce_out_dtype(ops[j], val_dtypes[j])

@@ -202,6 +202,7 @@ private:
     aq::GroupTable& table() { return tp_ ? *tp_ : empty_; }
     void drop_table() {
         if (!tp_) return;
+        aq::dev::Runtime::get().free_vcols(tp_);
         if (tp_->row_ids) { aq::dev::Runtime::get().forget(tp_->row_ids); std::free(tp_->row_ids); }
         if (tp_->handle) aqg_groupby_destroy(tp_->handle);
         std::free(tp_->offsets); std::free(tp_->counts);
