@@ -38,6 +38,16 @@ template <class T, template <typename...> class VT, class Ret> inline void devic
     if (n == 0) return;
     const int want = aqg_scan_out_dtype(op, dev::tag_of<T>::value);
     if (want != dev::tag_of<RT>::value) { std::fprintf(stderr, "[aquery-mi355x] scan result element type mismatch (op %d)\n", op); std::abort(); }
+    // a per-group temporary of the generated loop (`avgw(10, sales[vecs[i]], col[i])`, mem_opt.cpp:61; engine/ast.py:749-784): the scan
+    // runs ONCE for all groups over the flat layout (aqg_grouped_scan_flat) and `ret` becomes this group's slice of that result
+    if (dev::Entry* e = rt.deferred_at(arr.container)) {
+        dev::GroupCtx* gc = e->dgroup;
+        const uint32_t g = e->dg;
+        const int r = rt.vcol_scan(gc, e->dv, op, w);
+        rt.defer_slice(ret.container, (size_t)n * sizeof(RT), gc, g, r);
+        if (ret.capacity == 0 && GC::scratch_space == nullptr) rt.touch(ret.container);
+        return;
+    }
     void* dout = rt.result(ret.container, (size_t)n * sizeof(RT));
     dev::In in(arr.container, (size_t)n * sizeof(T), arr.capacity == 0);
     dev::check(aqg_scan(rt.ctx(), op, dev::tag_of<T>::value, in.d, n, w, dout), "aqg_scan");
@@ -76,8 +86,9 @@ template <class T, template <typename...> class VT, class T2, template <typename
           std::enable_if_t<aq::is_vt<VT, T> && aq::is_vt<VT2, T2>>* = nullptr>
 double corr(const VT<T>& x, const VT2<T2>& y) {
     auto& rt = aq::dev::Runtime::get();
-    aq::dev::In a(x.container, (size_t)x.size * sizeof(T), x.capacity == 0), b(y.container, (size_t)y.size * sizeof(T2), y.capacity == 0);
     double r = 0;
+    if (rt.deferred_corr(x.container, y.container, &r)) return r;      // `corr(v1[val], v2[val])` (h2o Q9): one grouped pass for all groups
+    aq::dev::In a(x.container, (size_t)x.size * sizeof(T), x.capacity == 0), b(y.container, (size_t)y.size * sizeof(T2), y.capacity == 0);
     aq::dev::check(aqg_corr(rt.ctx(), aq::dev::tag_of<T>::value, a.d, aq::dev::tag_of<T2>::value, b.d, x.size, &r), "aqg_corr");
     return r;
 }

@@ -273,6 +273,38 @@ inline void device_binary(int op, const L& l, const R& r, vector_type<RT>& ret) 
     constexpr int ot = tag_of<RT>::value;
     static_assert(ot != AQG_ERROR, "result element type is not a device dtype");
     if (n == 0) return;
+    // operands that are per-group temporaries of the generated loop (engine/ast.py:749-784 rewrites every column to `col[val]`): the operator
+    // runs ONCE over the whole columns -- gather commutes with it, f(a[val], b[val]) = f(a, b)[val] -- and `ret` is this group's slice
+    if constexpr (is_column<L>::value && is_column<R>::value) {
+        using TL = std::remove_cv_t<std::remove_pointer_t<decltype(l.container)>>;
+        using TR = std::remove_cv_t<std::remove_pointer_t<decltype(r.container)>>;
+        Entry *el = rt.deferred_at(l.container), *er = rt.deferred_at(r.container);
+        if (el && er && el->dgroup == er->dgroup && el->dg == er->dg && l.size == r.size &&
+            el->dgroup->vcols[el->dv].tag == tag_of<TL>::value && er->dgroup->vcols[er->dv].tag == tag_of<TR>::value) {
+            GroupCtx* gc = el->dgroup;
+            const uint32_t g = el->dg;
+            const int v = rt.vcol_ewise(gc, op, el->dv, er->dv, ot);
+            rt.defer_slice(ret.container, (size_t)n * sizeof(RT), gc, g, v);
+            if (ret.capacity == 0 && GC::scratch_space == nullptr) rt.touch(ret.container);
+            return;
+        }
+    } else {
+        constexpr bool lcol = is_column<L>::value;
+        const void* cp;
+        if constexpr (lcol) cp = l.container; else cp = r.container;
+        if (Entry* e = rt.deferred_at(cp)) {
+            GroupCtx* gc = e->dgroup;
+            const uint32_t g = e->dg;
+            int v;
+            if constexpr (lcol) { using TS = std::remove_cv_t<R>; TS sc = r; v = rt.vcol_ewise_scalar(gc, op, AQG_VEC_SCALAR, e->dv, tag_of<TS>::value, &sc, sizeof(TS), ot); }
+            else { using TS = std::remove_cv_t<L>; TS sc = l; v = rt.vcol_ewise_scalar(gc, op, AQG_SCALAR_VEC, e->dv, tag_of<TS>::value, &sc, sizeof(TS), ot); }
+            if (v >= 0) {
+                rt.defer_slice(ret.container, (size_t)n * sizeof(RT), gc, g, v);
+                if (ret.capacity == 0 && GC::scratch_space == nullptr) rt.touch(ret.container);
+                return;
+            }
+        }
+    }
     void* dout = rt.result(ret.container, (size_t)n * sizeof(RT));
     if constexpr (is_column<L>::value && is_column<R>::value) {
         using TL = std::remove_cv_t<std::remove_pointer_t<decltype(l.container)>>;

@@ -50,6 +50,23 @@ static std::vector<std::vector<int>> dataset(const std::string& name) {
         }
         return t;
     }
+    // counter-based columns (splitmix64 of seed + row; the same in tests/test_gpu_emitted.py) for the at-size group-loop modules
+    auto mix = [](unsigned long long z) { z += 0x9E3779B97F4A7C15ULL; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return z ^ (z >> 31); };
+    if (name == "trade" || name == "trade_small") {   // stocksymbol, price: 1e7 rows over 1e5 symbols (small: 5e4 rows over 300)
+        const int n = name == "trade" ? 10000000 : 50000, S = name == "trade" ? 100000 : 300;
+        std::vector<std::vector<int>> t(2, std::vector<int>(n));
+        for (int i = 0; i < n; ++i) { t[0][i] = (int)(mix(1000 + (unsigned long long)i) % S); t[1][i] = 50 + (int)(mix(77000000000ULL + i) % 451); }
+        return t;
+    }
+    if (name == "h2o9") {                             // id2, id4 in 1..100, v1 in 1..5, v2 in 1..15 (h2o G1_1e7_1e2 shapes): 1e4 groups
+        const int n = 10000000;
+        std::vector<std::vector<int>> t(4, std::vector<int>(n));
+        for (int i = 0; i < n; ++i) {
+            t[0][i] = 1 + (int)(mix(1ULL * i) % 100); t[1][i] = 1 + (int)(mix(5000000000ULL + i) % 100);
+            t[2][i] = 1 + (int)(mix(9000000000ULL + i) % 5); t[3][i] = 1 + (int)(mix(13000000000ULL + i) % 15);
+        }
+        return t;
+    }
     return {};
 }
 

@@ -25,7 +25,7 @@ def run(module, dataset, *funcs, cwd=None):
 def test_emitted_modules_compile():
     """CPU: the generated-shape translation units compile and link against the new library"""
     build()
-    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "distinct_orderby.so", "funcs_udf.so", "mutate_reuse.so", "stats_factory.so", "string_keys.so", "host_main"):
+    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "distinct_orderby.so", "funcs_udf.so", "mutate_reuse.so", "stats_factory.so", "string_keys.so", "group_scans.so", "host_main"):
         assert os.path.exists(os.path.join(EM, "build", m))
 
 
@@ -294,3 +294,110 @@ def test_config0_end_to_end_through_the_product_host(tmp_path):
     # the O message prints the data source's current result set (the DESC select), 4 rows
     assert out.stdout.strip().splitlines()[-4:] == ["5 130", "4 140", "3 140", "2 120"]
     assert "post-processing" in out.stderr
+
+
+# ---- what the reference's own queries put inside the group loop, at size (tests/emitted/group_scans.cpp) --------------------------------
+def _mix(z):
+    """splitmix64 of an array of counters (the generator of host_main's `trade` / `h2o9` datasets)"""
+    import numpy as np
+    with np.errstate(over="ignore"):
+        z = z.astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _trade(n, S):
+    import numpy as np
+    i = np.arange(n, dtype=np.uint64)
+    return (_mix(np.uint64(1000) + i) % np.uint64(S)).astype(np.int32), (50 + (_mix(np.uint64(77000000000) + i) % np.uint64(451))).astype(np.int32)
+
+
+def _compose(oracle, ogb, x, fn, dtype):
+    import numpy as np
+    out = np.zeros(x.size, dtype=dtype)
+    rows = ogb["row_ids"]
+    off = np.concatenate([[0], np.cumsum(ogb["counts"].astype(np.int64))])
+    for g in range(ogb["ngroups"]):
+        s, e = int(off[g]), int(off[g + 1])
+        out[s:e] = fn(x[rows[s:e]])
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dataset,n,S", [("trade_small", 50_000, 300), ("trade", 10_000_000, 100_000)])
+def test_per_group_windows_into_the_flat_buffer(tmp_path, oracle, dataset, n, S):
+    """benchmark/quries/Aquery/q7.a (HashTableFactory shape) and the frozen sample mem_opt.cpp:53-63 (AQHashTable shape):
+    avgw(w, price[vecs[g]], col[g]) for 1e5 symbols over 1e7 rows through the UNCHANGED generated loops -- one segmented scan for all
+    groups -- bit for bit against oracle.groupby + oracle.scan per group"""
+    import time
+    import numpy as np
+    import checker as ck
+    build()
+    sym, price = _trade(n, S)
+    ogb = oracle.groupby([sym])
+    t0 = time.time()
+    run("group_scans.so", dataset, "dll_q7", "dll_memopt", cwd=str(tmp_path))
+    dt = time.time() - t0
+    assert np.array_equal(np.fromfile(tmp_path / "q7.out.0", np.int32), sym[ogb["first_rows"]])            # groups in first-occurrence order
+    assert np.array_equal(np.fromfile(tmp_path / "memopt.out.0", np.int32), sym[ogb["first_rows"]])
+    for name, w in (("q7", 5), ("memopt", 10)):
+        got = np.fromfile(tmp_path / f"{name}.out.1", np.float64)
+        want = _compose(oracle, ogb, price, lambda v: oracle.scan(ck.SCAN_AVGW, v, w), np.float64)
+        # the device value is the exact window mean rounded once; the reference's recurrence drifts by a few ulp (DESIGN.md section 2)
+        assert got.size == n and np.all(np.abs(got - want) <= 1e-12 * np.abs(want) + 1e-12), name
+        exact = _compose(oracle, ogb, price, lambda v: np.convolve(v.astype(np.int64), np.ones(w, np.int64))[:v.size] / np.minimum(np.arange(v.size) + 1, w), np.float64)
+        assert np.array_equal(got, exact), name                                                              # integer window sums are exact: one rounding
+    assert dt < 120, f"{dt:.1f} s: the per-group scans must not cost a launch per group"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dataset,n,S", [("trade_small", 50_000, 300), ("trade", 10_000_000, 100_000)])
+def test_reductions_of_per_group_scans_and_expressions(tmp_path, oracle, dataset, n, S):
+    """tests/q4.a:23 `max(ratios(x)), min(ratios(x)) GROUP BY ID` and per-symbol forms of tests/stock.a's expressions
+    (`max(price - mins(price))`, `sum(price + price)`, `sum(price - 100)`, mins(2, price) into the flat buffer)"""
+    import numpy as np
+    import checker as ck
+    build()
+    sym, price = _trade(n, S)
+    ogb = oracle.groupby([sym])
+    run("group_scans.so", dataset, "dll_q4", "dll_expr", cwd=str(tmp_path))
+    rows = ogb["row_ids"]
+    off = np.concatenate([[0], np.cumsum(ogb["counts"].astype(np.int64))])
+    flat_gb = dict(ngroups=ogb["ngroups"], offsets=ogb["offsets"], counts=ogb["counts"], row_ids=np.arange(n, dtype=np.uint32))
+    ratios = _compose(oracle, ogb, price, lambda v: oracle.scan(ck.SCAN_RATIOW, v, 1), np.float32)
+    assert np.fromfile(tmp_path / "q4.out.1", np.float32).tobytes() == oracle.grouped_reduce(ck.RED_MAX, ratios, flat_gb).tobytes()
+    assert np.fromfile(tmp_path / "q4.out.2", np.float32).tobytes() == oracle.grouped_reduce(ck.RED_MIN, ratios, flat_gb).tobytes()
+    drawup = price[rows] - _compose(oracle, ogb, price, lambda v: oracle.scan(ck.SCAN_MINS, v), np.int32)
+    assert np.array_equal(np.fromfile(tmp_path / "expr.out.1", np.int32), oracle.grouped_reduce(ck.RED_MAX, drawup, flat_gb))
+    sums = np.add.reduceat(price[rows].astype(np.int64), off[:-1])
+    got2 = np.fromfile(tmp_path / "expr.out.2", ck.I128)
+    assert np.array_equal(got2["lo"].astype(np.int64), 2 * sums) and np.all(got2["hi"] == 0)
+    got3 = np.fromfile(tmp_path / "expr.out.3", ck.I128)
+    want3 = sums - 100 * ogb["counts"].astype(np.int64)
+    assert np.array_equal(got3["lo"].view(np.int64), want3) and np.array_equal(got3["hi"], np.where(want3 < 0, -1, 0))
+    assert np.array_equal(np.fromfile(tmp_path / "expr.out.4", np.int32), _compose(oracle, ogb, price, lambda v: oracle.scan(ck.SCAN_MINW, v, 2), np.int32))
+
+
+@pytest.mark.gpu
+def test_h2o_q9_corr_by_two_keys(tmp_path, oracle):
+    """benchmark/h2o/groupby.sql:20 `SELECT id2, id4, pow(corr(v1, v2), 2) AS r2 FROM source GROUP BY id2, id4` at 1e7 rows / 1e4 groups:
+    `corr(v1[val], v2[val])` inside the generated loop is ONE grouped pass (five sums per group); bit for bit against the oracle's corr"""
+    import numpy as np
+    build()
+    n = 10_000_000
+    i = np.arange(n, dtype=np.uint64)
+    id2 = (1 + _mix(i) % np.uint64(100)).astype(np.int32)
+    id4 = (1 + _mix(np.uint64(5000000000) + i) % np.uint64(100)).astype(np.int32)
+    v1 = (1 + _mix(np.uint64(9000000000) + i) % np.uint64(5)).astype(np.int32)
+    v2 = (1 + _mix(np.uint64(13000000000) + i) % np.uint64(15)).astype(np.int32)
+    ogb = oracle.groupby([id2, id4])
+    run("group_scans.so", "h2o9", "dll_q9", cwd=str(tmp_path))
+    assert np.array_equal(np.fromfile(tmp_path / "q9.out.0", np.int32), id2[ogb["first_rows"]])
+    assert np.array_equal(np.fromfile(tmp_path / "q9.out.1", np.int32), id4[ogb["first_rows"]])
+    rows = ogb["row_ids"]
+    off = np.concatenate([[0], np.cumsum(ogb["counts"].astype(np.int64))])
+    r = np.array([oracle.corr(v1[rows[off[g]:off[g + 1]]], v2[rows[off[g]:off[g + 1]]]) for g in range(ogb["ngroups"])])
+    want = r * r                  # pow(r, 2) as the compiler evaluates it (x * x: exactly rounded; libm's pow is not on every input)
+    got = np.fromfile(tmp_path / "q9.out.2", np.float64)
+    assert got.tobytes() == want.tobytes()
