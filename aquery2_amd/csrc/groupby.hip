@@ -1695,6 +1695,7 @@ void aqg_groupby_destroy(aqg_groupby* g) {
     aqg_pool_give(ctx, g->counts, g->cap_counts);
     aqg_pool_give(ctx, g->reversemap, g->cap_rows * 4);
     if (g->scratch) aqg_groupby_destroy(g->scratch);
+    if (g->scratch2) aqg_groupby_destroy(g->scratch2);
     aqg_pool_give(ctx, g->flat_off, g->cap_flat_off);
     aqg_pool_give(ctx, g->flat_heads, g->cap_flat_heads);
     aqg_pool_give(ctx, g->flat_short, g->cap_flat_short);
@@ -2012,16 +2013,25 @@ int aqg_grouped_corr(aqg_ctx* ctx, aqg_groupby* g, int tx, const void* x, int ty
         if (!g->scratch) g->scratch = new aqg_groupby();
         aqg_groupby* h = g->scratch;
         h->ctx = ctx; h->n = n; h->has_reversemap = false;
-        const int ops[5] = {AQG_RED_SUM, AQG_RED_SUMSQ, AQG_RED_SUM, AQG_RED_SUMSQ, AQG_RED_SUM};
-        const int dts[5] = {tx, tx, ty, ty, pt};
-        const void* vals[5] = {x, x, y, y, xy};
-        Plan plan;
-        if (rc == AQG_OK) rc = make_plan(ctx, 5, ops, dts, vals, n, &plan);
+        // two passes through the fast LDS plan (at most four accumulators each) instead of one through the generic five-accumulator kernel:
+        // {sum x, sum x*x, sum y, sum y*y} over the two columns, then {sum xy} over the product column
+        if (!g->scratch2) g->scratch2 = new aqg_groupby();
+        aqg_groupby* h2 = g->scratch2;
+        h2->ctx = ctx; h2->n = n; h2->has_reversemap = false;
+        const int ops[4] = {AQG_RED_SUM, AQG_RED_SUMSQ, AQG_RED_SUM, AQG_RED_SUMSQ};
+        const int dts[4] = {tx, tx, ty, ty};
+        const void* vals[4] = {x, x, y, y};
+        const int op5 = AQG_RED_SUM;
+        const void* v5 = xy;
+        Plan plan, plan2;
+        if (rc == AQG_OK) rc = make_plan(ctx, 4, ops, dts, vals, n, &plan);
         if (rc == AQG_OK) rc = run_with_retry(ctx, ks, plan, n, G, false, h, nullptr, nullptr);
-        if (rc == AQG_OK && h->ngroups != G) rc = aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_corr: group ids are not dense");
+        if (rc == AQG_OK) rc = make_plan(ctx, 1, &op5, &pt, &v5, n, &plan2);
+        if (rc == AQG_OK) rc = run_with_retry(ctx, ks, plan2, n, G, false, h2, nullptr, nullptr);
+        if (rc == AQG_OK && (h->ngroups != G || h2->ngroups != G)) rc = aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_corr: group ids are not dense");
         if (rc == AQG_OK) {
             hipLaunchKernelGGL(corr_final_kernel, dim3(aqg_grid(ctx, G, 256, 1, 8)), dim3(256), 0, ctx->stream, (const aqg_i128*)h->results[0], (const aqg_i128*)h->results[1],
-                               (const aqg_i128*)h->results[2], (const aqg_i128*)h->results[3], (const aqg_i128*)h->results[4], g->counts, G, out_dev);
+                               (const aqg_i128*)h->results[2], (const aqg_i128*)h->results[3], (const aqg_i128*)h2->results[0], g->counts, G, out_dev);
             rc = aqg_check_launch(ctx, "corr_final_kernel");
         }
     }

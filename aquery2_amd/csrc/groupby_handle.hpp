@@ -45,6 +45,7 @@ struct aqg_groupby {
     bool range_valid = false; int range_nkeys = 0; uint32_t range_n = 0;
     const void* range_col[MAXKEYS] = {}; int range_dt[MAXKEYS] = {}; long long range_min[MAXKEYS] = {}, range_max[MAXKEYS] = {};
     aqg_groupby* scratch = nullptr;   // reusable handle for aqg_grouped_reduce
+    aqg_groupby* scratch2 = nullptr;  // second one (aqg_grouped_corr: two passes whose results are read together)
     // the flat row-list layout of a build (segscan.hip): group g owns positions [flat_off[g], flat_off[g+1]) -- ht_postproc's offsets --
     // and `flat_heads` is a bitmap over positions, bit p set = a group starts at p (bit n is set too: the end).  Made on first use.
     uint32_t* flat_off = nullptr; uint32_t* flat_heads = nullptr; uint32_t* flat_short = nullptr; uint32_t* flat_gid = nullptr;

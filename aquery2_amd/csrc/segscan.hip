@@ -37,6 +37,26 @@ template <class T> struct var2_alg {          // running sum and sum of squares 
     __device__ static dpair lift(T v) { const double d = (double)v; return {d, d * d}; }
     __device__ static dpair op(dpair a, dpair b) { return {a.s + b.s, a.q + b.q}; }
 };
+struct ipair { int64_t s, q; };
+// sum and sum of squares of a group for var / stddev (aggregations.h:332-348): exact for integer columns of up to four bytes -- x * x in the
+// C++ type of the operands, like the reference's `arr[i] * arr[i]` -- and in double for floating columns (the square in the column's type)
+template <class T> struct varred_alg {
+    using A = std::conditional_t<std::is_floating_point_v<T>, dpair, ipair>;
+    __device__ static A identity() { A r; r.s = 0; r.q = 0; return r; }
+    __device__ static A lift(T v) {
+        A r;
+        if constexpr (std::is_floating_point_v<T>) { r.s = (double)v; r.q = (double)(T)(v * v); }
+        else {
+            using P = decltype(v * v);
+            using UP = std::make_unsigned_t<P>;
+            const P sq = (P)((UP)(P)v * (UP)(P)v);
+            r.s = (int64_t)v;
+            r.q = (int64_t)sq;
+        }
+        return r;
+    }
+    __device__ static A op(A a, A b) { A r; r.s = a.s + b.s; r.q = a.q + b.q; return r; }
+};
 struct none_alg {                              // position-only scans (group index / distance to the group start of every position)
     using A = uint32_t;
     __device__ static uint32_t identity() { return 0; }
@@ -94,10 +114,10 @@ __global__ void __launch_bounds__(SB) seg_tile_reduce_kernel(const T* __restrict
     if (threadIdx.x == 0) tile_carry[blockIdx.x] = total;
 }
 
-enum : int { SW_SUMS = 0, SW_AVGS, SW_MINS, SW_MAXS, SW_MAXP, SW_VARS, SW_STDDEVS, SW_RAW, SW_DIST, SW_GID, SW_RED_SUM, SW_RED_AVG, SW_RED_MIN, SW_RED_MAX };
+enum : int { SW_SUMS = 0, SW_AVGS, SW_MINS, SW_MAXS, SW_MAXP, SW_VARS, SW_STDDEVS, SW_RAW, SW_DIST, SW_GID, SW_RED_SUM, SW_RED_AVG, SW_RED_MIN, SW_RED_MAX, SW_RED_VAR, SW_RED_STDDEV };
 template <class T, int WR> struct seg_out {
     using type = std::conditional_t<WR == SW_SUMS || WR == SW_RED_SUM, std::conditional_t<std::is_floating_point_v<T>, double, aqg_i128>,
-                 std::conditional_t<WR == SW_AVGS || WR == SW_VARS || WR == SW_STDDEVS || WR == SW_RED_AVG, double,
+                 std::conditional_t<WR == SW_AVGS || WR == SW_VARS || WR == SW_STDDEVS || WR == SW_RED_AVG || WR == SW_RED_VAR || WR == SW_RED_STDDEV, double,
                  std::conditional_t<WR == SW_RAW, typename sum_alg<T>::A,
                  std::conditional_t<WR == SW_DIST || WR == SW_GID, uint32_t, T>>>>;
 };
@@ -149,6 +169,15 @@ __global__ void __launch_bounds__(SB) seg_tile_scan_kernel(const T* __restrict__
             double var = (run.q - run.s * run.s / rows) / rows;
             if (var < 0) var = 0;
             o[j] = WR == SW_STDDEVS ? sqrt(var) : var;
+        } else if constexpr (WR == SW_RED_VAR || WR == SW_RED_STDDEV) {          // (ssq - s * s / (FPType)(len + 1)) / (FPType)(len + 1): D9 kept
+            const double np1 = (double)(uint32_t)(p - s + 3);
+            double d;
+            if constexpr (std::is_floating_point_v<T>) d = (run.q - run.s * run.s / np1) / np1;
+            else {
+                const __int128 ss = (__int128)run.s * (__int128)run.s;                   // the reference's 128-bit LongType product (|s| < 2^63: no wrap)
+                d = ((double)run.q - i128_to_double(aqg_i128{(uint64_t)ss, (uint64_t)(ss >> 64)}) / np1) / np1;
+            }
+            o[j] = WR == SW_RED_STDDEV ? sqrt(d) : d;
         } else if constexpr (WR == SW_RAW) o[j] = run;
         else if constexpr (WR == SW_DIST) o[j] = p - (s - 1);
         else o[j] = c - 1;
@@ -186,6 +215,54 @@ __global__ void __launch_bounds__(SB) seg_shift_kernel(const T* __restrict__ x, 
     }
 }
 
+// four consecutive positions per lane (vector load / store, the start bits of the four as one nibble); ratios = ratiow(1) included.
+// Needs 16-byte aligned columns (sub-views of columns take the scalar kernel above).  1e9 rows: deltas 2.7 -> see DESIGN.md
+template <class T, int OP>
+__global__ void __launch_bounds__(SB) seg_shift4_kernel(const T* __restrict__ x, uint32_t n, const uint32_t* __restrict__ heads, void* __restrict__ out) {
+    using FP = std::conditional_t<sizeof(T) == 4, float, double>;
+    using O = std::conditional_t<OP == AQG_SCAN_RATIOW, FP, T>;
+    constexpr int V = 4;
+    const uint32_t nv = n / V;
+    const uint32_t q = blockIdx.x * SB + threadIdx.x;
+    if (q < nv) {
+        const uint32_t p = q * V;
+        const pack<T, V> c = *reinterpret_cast<const pack<T, V>*>(x + p);
+        const uint32_t hw = heads[p >> 5] >> (p & 31);                 // bits of p .. p+3 (p is a multiple of 4: they share a word)
+        pack<O, V> o;
+        if constexpr (OP == AQG_SCAN_NEXT) {
+            const T right = head_bit(heads, p + V) ? c.v[V - 1] : x[p + V];   // (bit n is set: no read beyond the column)
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const bool last = j + 1 < V ? ((hw >> (j + 1)) & 1u) : head_bit(heads, p + V);
+                o.v[j] = last ? c.v[j] : (j + 1 < V ? c.v[j + 1] : right);
+            }
+        } else {
+            const T left = (hw & 1u) ? c.v[0] : x[p - 1];               // (position 0 starts a group: no read in front of the column)
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const bool h = (hw >> j) & 1u;
+                const T prv = j ? c.v[j - 1] : left;
+                if constexpr (OP == AQG_SCAN_DELTAS) o.v[j] = h ? (T)0 : (T)(c.v[j] - prv);
+                else if constexpr (OP == AQG_SCAN_PREV) o.v[j] = h ? c.v[j] : prv;
+                else o.v[j] = (FP)(c.v[j] / (FP)(h ? c.v[j] : prv));
+            }
+        }
+        *reinterpret_cast<pack<O, V>*>(static_cast<O*>(out) + p) = o;
+    }
+    if (q == 0) {                                                       // the last n % 4 positions
+        for (uint32_t i = nv * V; i < n; ++i) {
+            const T cur = x[i];
+            const bool h = head_bit(heads, i);
+            O r;
+            if constexpr (OP == AQG_SCAN_DELTAS) r = h ? (T)0 : (T)(cur - x[i - 1]);
+            else if constexpr (OP == AQG_SCAN_PREV) r = h ? cur : x[i - 1];
+            else if constexpr (OP == AQG_SCAN_NEXT) r = head_bit(heads, i + 1) ? cur : x[i + 1];
+            else r = (FP)(cur / (FP)(h ? cur : x[i - 1]));
+            static_cast<O*>(out)[i] = r;
+        }
+    }
+}
+
 // ---- sliding sums (sumw / avgw / varw / stddevw): window_sum_kernel of scan.hip with every window clamped at its group's start ----------
 template <class T, int MODE>
 __global__ void __launch_bounds__(SB) seg_window_sum_kernel(const T* __restrict__ x, uint32_t n, uint32_t w, const uint8_t* __restrict__ heads8, void* __restrict__ out) {
@@ -201,8 +278,7 @@ __global__ void __launch_bounds__(SB) seg_window_sum_kernel(const T* __restrict_
     const uint32_t L = H + TS, nblk = L / IT;
     A* S = reinterpret_cast<A*>(smem_raw);
     A* Q = S + (MODE >= 2 ? L : 0);
-    uint32_t* LH = reinterpret_cast<uint32_t*>(Q + L);            // per block of IT positions: position + 1 of the last group start BEFORE the block (0: none in this tile)
-    uint8_t* HB = reinterpret_cast<uint8_t*>(LH + nblk);          // per block: its start bits
+    uint32_t* LH = reinterpret_cast<uint32_t*>(Q + L);            // per block of IT positions: {position + 1 of the last group start BEFORE the block (0: none in this tile), the block's start bits : 8}
     A carry = ALG::identity(), carry2 = ALG::identity();
     uint32_t carry_m = 0;
     for (uint32_t blk0 = 0; blk0 < nblk; blk0 += SB) {
@@ -235,8 +311,7 @@ __global__ void __launch_bounds__(SB) seg_window_sum_kernel(const T* __restrict_
         if (blk < nblk) {
 #pragma unroll
             for (int j = 0; j < IT; ++j) { S[blk * IT + j] = ALG::op(excl, loc[j]); if constexpr (MODE >= 2) Q[blk * IT + j] = ALG::op(excl2, loc2[j]); }
-            LH[blk] = before;
-            HB[blk] = (uint8_t)hb;
+            LH[blk] = (before << 8) | hb;
         }
         carry = ALG::op(carry, tot);
         if constexpr (MODE >= 2) carry2 = ALG::op(carry2, tot2);
@@ -245,8 +320,8 @@ __global__ void __launch_bounds__(SB) seg_window_sum_kernel(const T* __restrict_
     __syncthreads();
     for (uint32_t i = tile_start + threadIdx.x; i < tile_end; i += SB) {
         const uint32_t idx = i - tile_start + H, blk = idx >> 3, j = idx & 7;
-        const uint32_t m = HB[blk] & ((2u << j) - 1u);
-        const uint32_t st = m ? blk * IT + (31 - __clz((int)m)) + 1 : LH[blk];     // position + 1 of the group's start (0: further back than the halo)
+        const uint32_t lhb = LH[blk], m = lhb & ((2u << j) - 1u);
+        const uint32_t st = m ? blk * IT + (31 - __clz((int)m)) + 1 : (lhb >> 8);  // position + 1 of the group's start (0: further back than the halo)
         uint32_t lower = idx + 1 - w;                             // idx >= H >= w - 1
         if (st && st - 1 > lower) lower = st - 1;
         const uint32_t len = idx - lower + 1;
@@ -532,6 +607,13 @@ int scan_flat(aqg_ctx* ctx, aqg_groupby* g, int op, int t, const void* xv, uint3
             aqg_kernel_timer_end(ctx);
             return aqg_check_launch(ctx, what);
         };
+        const bool al16 = ((reinterpret_cast<uintptr_t>(xv) | reinterpret_cast<uintptr_t>(out)) & 15) == 0 && n >= 4;
+        auto shift4 = [&](auto kern, const char* what) -> int {
+            aqg_kernel_timer_begin(ctx);
+            hipLaunchKernelGGL(kern, dim3(aqg_ceil_div(n / 4, SB)), dim3(SB), 0, ctx->stream, x, n, heads, out);
+            aqg_kernel_timer_end(ctx);
+            return aqg_check_launch(ctx, what);
+        };
         switch (op) {
         case AQG_SCAN_SUMS: return seg_prefix<T, sum_alg<T>, SW_SUMS>(ctx, g, x, n, out);
         case AQG_SCAN_AVGS: return seg_prefix<T, sum_alg<T>, SW_AVGS>(ctx, g, x, n, out);
@@ -539,10 +621,10 @@ int scan_flat(aqg_ctx* ctx, aqg_groupby* g, int op, int t, const void* xv, uint3
         case AQG_SCAN_MAXS: return seg_prefix<T, max_alg<T>, SW_MAXS>(ctx, g, x, n, out);
         case AQG_SCAN_VARS: return seg_prefix<T, var2_alg<T>, SW_VARS>(ctx, g, x, n, out);
         case AQG_SCAN_STDDEVS: return seg_prefix<T, var2_alg<T>, SW_STDDEVS>(ctx, g, x, n, out);
-        case AQG_SCAN_DELTAS: return shift(&seg_shift_kernel<T, AQG_SCAN_DELTAS>, "deltas (grouped)");
-        case AQG_SCAN_PREV: return shift(&seg_shift_kernel<T, AQG_SCAN_PREV>, "prev (grouped)");
-        case AQG_SCAN_NEXT: return shift(&seg_shift_kernel<T, AQG_SCAN_NEXT>, "aggnext (grouped)");
-        case AQG_SCAN_RATIOW: return shift(&seg_shift_kernel<T, AQG_SCAN_RATIOW>, "ratiow (grouped)");
+        case AQG_SCAN_DELTAS: return al16 ? shift4(&seg_shift4_kernel<T, AQG_SCAN_DELTAS>, "deltas (grouped)") : shift(&seg_shift_kernel<T, AQG_SCAN_DELTAS>, "deltas (grouped)");
+        case AQG_SCAN_PREV: return al16 ? shift4(&seg_shift4_kernel<T, AQG_SCAN_PREV>, "prev (grouped)") : shift(&seg_shift_kernel<T, AQG_SCAN_PREV>, "prev (grouped)");
+        case AQG_SCAN_NEXT: return al16 ? shift4(&seg_shift4_kernel<T, AQG_SCAN_NEXT>, "aggnext (grouped)") : shift(&seg_shift_kernel<T, AQG_SCAN_NEXT>, "aggnext (grouped)");
+        case AQG_SCAN_RATIOW: return (al16 && w == 1) ? shift4(&seg_shift4_kernel<T, AQG_SCAN_RATIOW>, "ratios (grouped)") : shift(&seg_shift_kernel<T, AQG_SCAN_RATIOW>, "ratiow (grouped)");
         case AQG_SCAN_SUMW: case AQG_SCAN_AVGW: case AQG_SCAN_VARW: case AQG_SCAN_STDDEVW: {
             using A = typename sum_alg<T>::A;
             const uint32_t ww = w > n ? n : w;                                          // (a window is clamped by its group anyway)
@@ -557,7 +639,7 @@ int scan_flat(aqg_ctx* ctx, aqg_groupby* g, int op, int t, const void* xv, uint3
                 }
             }
             const size_t ext = (size_t)TS + (ww - 1 + IT - 1) / IT * IT;
-            const size_t lds = (var ? ext * sizeof(double) * 2 : ext * sizeof(A)) + ext / IT * 5 + 16;
+            const size_t lds = (var ? ext * sizeof(double) * 2 : ext * sizeof(A)) + ext / IT * 4 + 16;
             if (lds <= HALO_MAX_BYTES) {
                 auto go = [&](auto kern) -> int {
                     AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
@@ -720,6 +802,15 @@ int aqg_grouped_reduce_flat(aqg_ctx* ctx, aqg_groupby* g, int op, int t, const v
             case AQG_RED_MIN: return seg_prefix<T, min_alg<T>, SW_RED_MIN>(ctx, g, x, n, out_dev);
             default: return seg_prefix<T, max_alg<T>, SW_RED_MAX>(ctx, g, x, n, out_dev);
             }
+        });
+    }
+    if ((op == AQG_RED_VAR || op == AQG_RED_STDDEV) && (aqg_dtype_size(t) <= 4 || dt_is_fp(t))) {
+        return aqg_dispatch_num(t, [&](auto tt) -> int {
+            using T = typename decltype(tt)::type;
+            if constexpr (sizeof(T) <= 4 || std::is_floating_point_v<T>) {
+                const T* x = static_cast<const T*>(xflat);
+                return op == AQG_RED_VAR ? seg_prefix<T, varred_alg<T>, SW_RED_VAR>(ctx, g, x, n, out_dev) : seg_prefix<T, varred_alg<T>, SW_RED_STDDEV>(ctx, g, x, n, out_dev);
+            } else return AQG_ERR_DTYPE;
         });
     }
     // VAR / STDDEV: through the group-by plans, keyed by the group index of every flat position

@@ -108,6 +108,32 @@ def secondary_entries(dev, n, ck, aq, id1, v1):
         ms = timed(lambda: dev.scan(op, price, w, keep=True, out=o), reps=5)
         entry(name, ms, bpr * n, kernel_ms=round(dev.last_kernel_ms(), 4))
     big.free(); price.free()
+    # ---- the reference's flagship shape: per-group windows inside the generated group loop (benchmark/quries/Aquery/q7.a
+    # `SELECT stocksymbol, avgs(5, price) FROM trade ASSUMING ASC time GROUP BY stocksymbol`, mem_opt.cpp:53-63): the grouping is built once
+    # (aqg_groupby_build), then ONE aqg_grouped_scan call answers every symbol -- price into the flat layout (value-carrying radix passes
+    # over the group ids) + the segmented window kernel.  Algorithmic bytes: 4 price + 4 group id + 8 out per row.
+    try:
+        for label, Ksym in (("1e5_symbols", max(n // 100_000, 1)), ("100_symbols", None)):
+            sym = dev.gen_column(ck.GEN_ID1, 42, 0, n, n, K) if Ksym is None else dev.gen_column(ck.GEN_ID3, 42, 0, n, n, Ksym)
+            price = dev.gen_column(ck.GEN_PRICE, 42, 0, n, n, K)
+            o = dev.empty(n, np.float64)
+            t_b = timed(lambda: h.__setitem__("q7", dev.groupby_build([sym])), reps=1)
+            gbq = h["q7"]
+            ms = timed(lambda: dev.grouped_scan(gbq, ck.SCAN_AVGW, price, 5, keep=True, out=o))
+            xf = dev.grouped_flatten(gbq, price, keep=True)
+            ms_scan = timed(lambda: dev.grouped_scan(gbq, ck.SCAN_AVGW, xf, 5, flat=True, keep=True, out=o))
+            entry("q7_avgs5_by_symbol" if Ksym is not None else "q7_avgs5_by_symbol_100_symbols", ms, 16 * n, groups=int(gbq.ngroups), symbols=label,
+                  build_ms=round(t_b, 3), scan_only_ms=round(ms_scan, 4), scan_only_frac=round(12 * n / (ms_scan * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                  kernel_ms=round(dev.last_kernel_ms(), 4))
+            gbq.destroy(); xf.free(); o.free(); price.free(); sym.free()
+        # h2o Q9 `pow(corr(v1, v2), 2) BY id2, id4` (benchmark/h2o/groupby.sql:20): build over two keys + ONE aqg_grouped_corr
+        id2, id4, v2 = (dev.gen_column(c, 42, 0, n, n, K) for c in (ck.GEN_ID2, ck.GEN_ID4, ck.GEN_V2))
+        t_b = timed(lambda: h.__setitem__("q9", dev.groupby_build([id2, id4])), reps=1)
+        ms = timed(lambda: dev.grouped_corr(h["q9"], v1, v2))
+        entry("h2o_q9_corr_v1_v2_by_id2_id4", ms, 12 * n, groups=int(h["q9"].ngroups), build_ms=round(t_b, 3))
+        h["q9"].destroy(); id2.free(); id4.free(); v2.free()
+    except Exception as e:                                    # noqa: BLE001 -- a secondary entry never costs the line
+        out.append({"name": "q7_q9", "error": str(e)[:300]})
     # ---- config 4 (one shard of it): fact JOIN small(id4, w), sum(v1 * w) by id1, fused
     id4 = dev.gen_column(ck.GEN_ID4, 42, 0, n, n, K)
     rng = np.random.default_rng(4)
