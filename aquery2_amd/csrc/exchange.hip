@@ -17,6 +17,8 @@
 #include <dlfcn.h>
 
 #include "aqg_internal.hpp"
+#include <mutex>
+
 #include "dev_common.hpp"
 #include "groupby_handle.hpp"
 
@@ -35,9 +37,15 @@ struct Rccl {
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
+// opened once per process, under a mutex: a host with one thread per GPU calls aqg_comm_unique_id / aqg_comm_init_rccl from several
+// threads at the same time, and a half-filled table must never be visible.  A failed load is retried by the next caller.
 Rccl* rccl(std::string* err) {
-    static Rccl r;
-    if (r.lib) return &r;
+    static std::mutex mu;
+    static Rccl ready;
+    static bool ok = false;
+    std::lock_guard<std::mutex> lock(mu);
+    if (ok) return &ready;
+    Rccl r;
     // The RCCL that sits NEXT TO the HIP runtime this library is bound to: a process may hold two ROCm stacks (PyTorch wheels bundle
     // their own libamdhip64 / libhsa-runtime64 / librccl), and an RCCL from the other one opens its own, uninitialised HSA runtime and
     // reports "no ROCm-capable device" (seen when torch was imported after this library and before the first communicator).
@@ -59,8 +67,10 @@ Rccl* rccl(std::string* err) {
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.lib, "ncclAllGather"));
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
-    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { if (err) *err = "librccl lacks an expected symbol"; dlclose(r.lib); r.lib = nullptr; return nullptr; }
-    return &r;
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy) { if (err) *err = "librccl lacks an expected symbol"; dlclose(r.lib); return nullptr; }
+    ready = r;                                 // published complete, under the lock
+    ok = true;
+    return &ready;
 }
 
 // one partial of the local group-by.  `wide`: its result is a 128-bit integer that does not fit 64 bits per shard (sums of 8-byte
@@ -143,11 +153,12 @@ struct PackSpec {
     const void* src[MAXKEYS + 1 + MAXPART];
     int src_dt[MAXKEYS + 1 + MAXPART];
     uint64_t row_base;
+    uint32_t status;                  // this rank's failure before the exchange (AQG_ERR_*, 0 = fine): it ships no groups and every rank returns it
 };
-// word (c, g) of the payload: column c of group g (column nkeys = the global first row)
+// word (c, g) of the payload: column c of group g (column nkeys = the global first row); header = {groups, status}
 __global__ void __launch_bounds__(256) xpack_kernel(PackSpec ps, uint32_t G, uint32_t gcap, uint64_t* __restrict__ out) {
     const size_t total = (size_t)ps.ncols * G;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = G; out[1] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = G; out[1] = ps.status; }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i / G);
         const uint32_t g = (uint32_t)(i - (size_t)c * G);
@@ -251,7 +262,7 @@ struct SmallMerge {
     void* out[XS_MAXCOL];
     void* keys_out; int key_size;
     long long* first_out;
-    uint32_t* info;                    // [0] groups, [1] bad header
+    uint32_t* info;                    // [0] groups, [1] bad header, [2] the first non-zero status word of a shard header (a rank that failed before the exchange)
 };
 __global__ void __launch_bounds__(1024) xmerge_small_kernel(const uint64_t* __restrict__ gathered, uint32_t world, uint32_t gcap, size_t words_per_rank, SmallMerge sm) {
     __shared__ unsigned long long tkey[XS_CAP + 1];          // (last: the key equal to the empty mark)
@@ -263,15 +274,18 @@ __global__ void __launch_bounds__(1024) xmerge_small_kernel(const uint64_t* __re
     __shared__ uint32_t off[65];
     __shared__ uint32_t s_bad;
     if (threadIdx.x == 0) {
-        uint32_t o = 0, bad = 0;
+        uint32_t o = 0, bad = 0, st = 0;
         for (uint32_t r = 0; r < world; ++r) {
             const uint64_t c = gathered[(size_t)r * words_per_rank];
+            const uint32_t rs = (uint32_t)gathered[(size_t)r * words_per_rank + 1];
+            if (rs && !st) st = rs;
             if (c > gcap) bad = 1;
             off[r] = o;
             o += bad ? 0u : (uint32_t)c;
         }
         off[world] = o;
-        s_bad = bad;
+        s_bad = bad | (st ? 2u : 0u);
+        sm.info[2] = st;
     }
     for (uint32_t t = threadIdx.x; t <= XS_CAP; t += 1024) { tkey[t] = XS_EMPTY; tlead[t] = 0xFFFFFFFFu; }
     if (threadIdx.x < XS_ROWS / 64) lead_bits[threadIdx.x] = 0;
@@ -359,21 +373,31 @@ __global__ void __launch_bounds__(1024) xmerge_small_kernel(const uint64_t* __re
     if (threadIdx.x == 0) { sm.info[0] = G; sm.info[1] = s_bad; }
 }
 
+// every rank's return when some rank failed before the exchange (its own message stays on the rank that failed)
+int remote_failure(aqg_ctx* ctx, int status, bool mine = false) {
+    if (!mine || ctx->err.empty()) ctx->err = status == AQG_ERR_OVERFLOW ? "sharded call: a rank's group table exceeded its capacity (gmax / table overflow)" :
+                                              status == AQG_ERR_NOMEM ? "sharded call: a rank ran out of device memory" : "sharded call: a rank failed before the exchange";
+    return status;
+}
+
 // steps 2-4 of the sharded group-by over an existing shard table L (keys, 32-bit first rows, one result column per partial):
 // sizes the payload, packs, ONE all-gather, concatenates, re-aggregates into comm->merged (aggregate 0 = MIN of the global first rows)
 // payload column p reads result column src_res[p] of L (null: p itself), its high 8 bytes when src_hi[p]
 int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtypes, int nparts, const int* part_dt, const int* merge_op,
-                  uint64_t row_base, uint32_t max_groups_hint, uint32_t gmax, const int* src_res = nullptr, const int* src_hi = nullptr) {
+                  uint64_t row_base, uint32_t max_groups_hint, uint32_t gmax, const int* src_res = nullptr, const int* src_hi = nullptr, int local_status = AQG_OK) {
     aqg_ctx* ctx = comm->ctx;
-    const uint32_t G = L->ngroups;
+    // A failure of THIS rank's part (its group-by ran out of table or memory, its table exceeds gmax) must not keep it out of the
+    // collective: the other ranks would wait in the all-gather for ever.  The rank ships an empty table whose header carries the status,
+    // and EVERY rank returns that status after the all-gather (the first failed rank's, in rank order).
+    uint32_t G = local_status == AQG_OK ? L->ngroups : 0;
     // ---- 2. capacity of the exchange: the caller's bound, or the largest shard table (one 8-byte all-gather and a host read) -------
     const uint32_t world = (uint32_t)comm->world;
     uint32_t gcap = gmax;
-    if (gmax) { if (G > gmax) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: a shard has more groups than gmax"); }
+    if (gmax) { if (G > gmax) { local_status = AQG_ERR_OVERFLOW; ctx->err = "aqg_groupby_agg_sharded: a shard has more groups than gmax"; G = 0; } }
     else {
         AQG_TRY(grow(ctx, &comm->hdr, &comm->hdr_cap, 8 * ((size_t)world + 1)));
         uint64_t* h = static_cast<uint64_t*>(comm->hdr);
-        const uint64_t mine = G;
+        const uint64_t mine = (uint64_t)G | ((uint64_t)(uint32_t)local_status << 32);
         AQG_HIP(ctx, hipMemcpyAsync(h + world, &mine, 8, hipMemcpyHostToDevice, ctx->stream));
         AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));                    // (`mine` is a stack variable)
         AQG_TRY(allgather(comm, h + world, h, 8));
@@ -381,7 +405,8 @@ int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtyp
         AQG_HIP(ctx, hipMemcpyAsync(all, h, 8 * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
         AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         uint64_t mx = 1;
-        for (uint32_t r = 0; r < world; ++r) mx = all[r] > mx ? all[r] : mx;
+        for (uint32_t r = 0; r < world; ++r) if (all[r] >> 32) return remote_failure(ctx, (int)(all[r] >> 32), (int)r == comm->rank);   // (the same on every rank)
+        for (uint32_t r = 0; r < world; ++r) mx = (all[r] & 0xFFFFFFFFull) > mx ? (all[r] & 0xFFFFFFFFull) : mx;
         gcap = (uint32_t)mx;
     }
     const int ncols = nkeys + 1 + nparts;
@@ -392,7 +417,7 @@ int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtyp
     // ---- 3. pack, ONE all-gather, concatenate ----------------------------------------------------------------------------------------
     PackSpec ps;
     memset(&ps, 0, sizeof ps);
-    ps.ncols = ncols; ps.nkeys = nkeys; ps.row_base = row_base;
+    ps.ncols = ncols; ps.nkeys = nkeys; ps.row_base = row_base; ps.status = (uint32_t)local_status;
     for (int k = 0; k < nkeys; ++k) { ps.src[k] = L->keys_out[k]; ps.src_dt[k] = key_dtypes[k]; }
     ps.src[nkeys] = L->first_rows; ps.src_dt[nkeys] = AQG_UINT32;
     for (int p = 0; p < nparts; ++p) {
@@ -432,9 +457,10 @@ int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtyp
             sm.info = reinterpret_cast<uint32_t*>(static_cast<char*>(comm->hdr) + 8 * ((size_t)world + 1));
             hipLaunchKernelGGL(xmerge_small_kernel, dim3(1), dim3(1024), 0, ctx->stream, static_cast<const uint64_t*>(comm->recv), world, gcap, words, sm);
             AQG_TRY(aqg_check_launch(ctx, "xmerge_small_kernel"));
-            uint32_t info[2] = {0, 0};
-            AQG_HIP(ctx, hipMemcpyAsync(info, sm.info, 8, hipMemcpyDeviceToHost, ctx->stream));
+            uint32_t info[3] = {0, 0, 0};
+            AQG_HIP(ctx, hipMemcpyAsync(info, sm.info, 12, hipMemcpyDeviceToHost, ctx->stream));
             AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (info[2]) return remote_failure(ctx, (int)info[2]);
             if (info[1]) return aqg_fail(ctx, AQG_ERR_ARG, "exchange: corrupt shard header");
             M->ngroups = info[0]; M->n = info[0];
             for (int a = 0; a <= nparts; ++a) { comm->mres[a] = M->results[a]; comm->mres_dt[a] = M->res_dt[a]; }
@@ -455,16 +481,17 @@ int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtyp
     memset(&us, 0, sizeof us);
     us.ncols = ncols;
     for (int c = 0; c < ncols; ++c) { us.dst[c] = static_cast<char*>(comm->cat) + col_off[c]; us.dst_dt[c] = col_dt[c]; }
-    hipLaunchKernelGGL(xunpack_kernel, dim3(aqg_grid(ctx, (uint64_t)ncols * gcap + 1, 256, 2, 4)), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(comm->recv), world, gcap, words, us);
-    AQG_TRY(aqg_check_launch(ctx, "xunpack_kernel"));
-    // the number of concatenated rows: sum of the headers (one small copy)
+    // the shard headers {groups, status}: a failed rank fails the call on every rank; counts are checked before anything trusts them
     uint64_t total = 0;
     {
-        uint64_t hd[64];
-        for (uint32_t r = 0; r < world; ++r) AQG_HIP(ctx, hipMemcpyAsync(&hd[r], static_cast<const uint64_t*>(comm->recv) + (size_t)r * words, 8, hipMemcpyDeviceToHost, ctx->stream));
+        uint64_t hd[64][2];
+        for (uint32_t r = 0; r < world; ++r) AQG_HIP(ctx, hipMemcpyAsync(&hd[r][0], static_cast<const uint64_t*>(comm->recv) + (size_t)r * words, 16, hipMemcpyDeviceToHost, ctx->stream));
         AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (uint32_t r = 0; r < world; ++r) total += hd[r];
+        for (uint32_t r = 0; r < world; ++r) if ((uint32_t)hd[r][1]) return remote_failure(ctx, (int)(uint32_t)hd[r][1], (int)r == comm->rank);
+        for (uint32_t r = 0; r < world; ++r) { if (hd[r][0] > gcap) return aqg_fail(ctx, AQG_ERR_ARG, "exchange: corrupt shard header"); total += hd[r][0]; }
     }
+    hipLaunchKernelGGL(xunpack_kernel, dim3(aqg_grid(ctx, (uint64_t)ncols * gcap + 1, 256, 2, 4)), dim3(256), 0, ctx->stream, static_cast<const uint64_t*>(comm->recv), world, gcap, words, us);
+    AQG_TRY(aqg_check_launch(ctx, "xunpack_kernel"));
     if (total > AQG_MAX_ROWS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "aqg_groupby_agg_sharded: more shard groups than AQG_MAX_ROWS");
     // ---- 4. re-aggregate the concatenation (first occurrence in it = global first occurrence) ------------------------------------------
     const void* mkeys[MAXKEYS];
@@ -609,7 +636,7 @@ int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, co
         if (lop == AQG_RED_SUM || lop == AQG_RED_SUMSQ) {
             P.merge_op = AQG_RED_SUM;
             if (is_fp(dt)) P.part_dt = AQG_DOUBLE;
-            else if (lop == AQG_RED_SUM && small_int(dt)) P.part_dt = AQG_INT64;       // a shard's sum of <= 4-byte integers over < 2^32 rows fits 64 bits
+            else if (lop == AQG_RED_SUM && small_int(dt)) P.part_dt = is_unsigned(dt) ? AQG_UINT64 : AQG_INT64;   // a shard's sum of <= 4-byte integers over < 2^32 rows fits 64 bits (unsigned ones: uint64 -- 2^31 rows of 0xFFFFFFFF pass 2^63)
             else { P.part_dt = is_unsigned(dt) ? AQG_UINT64 : AQG_INT64; P.wide = 1; }  // (dtype of the HIGH halves; the low ones are uint64)
         }
         else if (lop == AQG_RED_COUNT) { P.part_dt = AQG_UINT32; P.merge_op = AQG_RED_SUM; }   // a shard has < 2^32 rows: one accumulator in the merge
@@ -639,16 +666,18 @@ int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, co
     int lops[MAXAGG], ldts[MAXAGG];
     const void* lvals[MAXAGG];
     for (int p = 0; p < nparts; ++p) { lops[p] = parts[p].local_op; ldts[p] = parts[p].val_dt; lvals[p] = vals[parts[p].val_index]; }
-    AQG_TRY(aqg_groupby_agg(ctx, nkeys, key_dtypes, keys, nparts, lops, ldts, lvals, n, max_groups_hint, &comm->local));
+    // (argument errors above are the same on every rank; from here on a failure is this rank's alone and travels through the exchange)
+    int lrc = aqg_groupby_agg(ctx, nkeys, key_dtypes, keys, nparts, lops, ldts, lvals, n, max_groups_hint, &comm->local);
+    if (!comm->local) { comm->local = new aqg_groupby(); comm->local->ctx = ctx; }
     aqg_groupby* L = comm->local;
-    if (L->nuser) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: plain integer key columns only (dates / times / 128-bit / floating keys: single-GPU calls)");
+    if (lrc == AQG_OK && L->nuser) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: plain integer key columns only (dates / times / 128-bit / floating keys: single-GPU calls)");
     int pdt[MAXPART], mop[MAXPART], sres[MAXPART], shi[MAXPART];
     for (int p = 0; p < nparts; ++p) {
         int c = parts[p].col0;
         if (parts[p].wide) { pdt[c] = AQG_UINT64; mop[c] = AQG_RED_SUM; sres[c] = p; shi[c] = 0; ++c; }      // low halves
         pdt[c] = parts[p].part_dt; mop[c] = parts[p].merge_op; sres[c] = p; shi[c] = parts[p].wide;
     }
-    AQG_TRY(exchange_core(comm, L, nkeys, key_dtypes, ncols, pdt, mop, row_base, max_groups_hint, gmax, sres, shi));
+    AQG_TRY(exchange_core(comm, L, nkeys, key_dtypes, ncols, pdt, mop, row_base, max_groups_hint, gmax, sres, shi, lrc));
     aqg_groupby* M = comm->merged;
     // ---- 5. the result handle: keys and global first rows of the merged table, every aggregate in its own result dtype --------------
     aqg_groupby* H = *out ? *out : new aqg_groupby();

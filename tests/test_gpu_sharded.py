@@ -143,6 +143,40 @@ def test_group_order_is_global_first_occurrence(oracle):
     check(4, [k], [ck.RED_MAX, ck.RED_COUNT], [v, v], oracle)
 
 
+@pytest.mark.parametrize("two_keys", [False, True])
+def test_a_shard_over_gmax_fails_the_call_on_every_rank_instead_of_hanging(two_keys):
+    """one skewed shard holds more groups than gmax: that rank still joins the all-gather (with an empty table and its status in the
+    header) and EVERY rank returns AQG_ERR_OVERFLOW -- before, the rank returned alone and the others waited in the collective for ever.
+    One key column takes the one-launch merge, two the concatenation path; both read the status words."""
+    import aquery2_amd
+    world, per = 3, 4000
+    rng = np.random.default_rng(5)
+    def shard_keys(rank):
+        k = rng.integers(0, 8, per).astype(np.int32)
+        if rank == 1:
+            k = rng.integers(0, 500, per).astype(np.int32)            # 500 groups against gmax = 16
+        return [k, (k % 3).astype(np.int32)] if two_keys else [k]
+    data = [(shard_keys(r), rng.integers(1, 9, per).astype(np.int32)) for r in range(world)]
+    tr = aquery2_amd.ThreadRanks(world)
+    def body(rank, dev, comm):
+        k, v = data[rank]
+        codes = []
+        for _ in range(2):                                             # the communicator stays usable after a failed call
+            try:
+                comm.groupby_agg_sharded(k, [ck.RED_SUM], [v], row_base=rank * per, hint=64, gmax=16)
+                codes.append(0)
+            except aquery2_amd.capi.AqgError as e:
+                codes.append(e.code)
+        ok = comm.groupby_agg_sharded([c % 4 for c in k], [ck.RED_SUM], [v], row_base=rank * per, hint=64, gmax=16)   # every shard within bounds again
+        return codes, ok.ngroups
+    try:
+        out = tr.run(body)
+    finally:
+        tr.close()
+    assert [c for c, _ in out] == [[6, 6]] * world, out                # AQG_ERR_OVERFLOW everywhere, twice
+    assert len({g for _, g in out}) == 1 and out[0][1] >= 4
+
+
 def test_rccl_transport_world_of_one(gpu_dev, oracle):
     """the RCCL path itself (librccl opened with dlopen, ncclGetUniqueId / ncclCommInitRank / ncclAllGather on the context's stream)
     with the only world a one-GPU box allows; the sharded call then equals the plain one"""
