@@ -374,6 +374,12 @@ class Device:
         buf._host = a
         return buf
 
+    def col_pin_last(self):
+        """(registered, staged, pageable) chunk counts of the most recent col_pin upload"""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.lib.aqg_col_pin_last(self.ctx, C.byref(a), C.byref(b), C.byref(c)), "aqg_col_pin_last")
+        return a.value, b.value, c.value
+
     def col_unpin_all(self):
         self._chk(self.lib.aqg_col_unpin_all(self.ctx), "aqg_col_unpin_all")
 

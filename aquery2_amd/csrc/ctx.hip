@@ -1,6 +1,8 @@
 // ctx.hip -- context, stream, device memory, column pins, type rules, HIP-event timer.
 #include <string_view>
 
+#include <mutex>
+
 #include "aqg_internal.hpp"
 
 extern "C" {
@@ -175,15 +177,51 @@ int aqg_memset(aqg_ctx* ctx, void* dst, int byte, size_t bytes) {
 // pointers into MonetDB's memory).  The upload is ASYNCHRONOUS and stream-ordered: the host range is page-locked chunk by chunk
 // (hipHostRegister) and copied by DMA on a copy stream of its own while this call returns; the context's stream waits for the
 // completion event, so every later call of this library sees the data.  Measured on the MI355X box (4 GB column): 56-57 GB/s
-// including the registration (PCIe line rate) against 21 GB/s for a first pageable hipMemcpy; chunks whose registration fails
-// (ranges sharing a page with an earlier registration, read-only mappings) go through the runtime's pageable path.
+// including the registration (PCIe line rate) against 21 GB/s for a first pageable hipMemcpy.
+//
+// Page-locked ranges must never overlap (profiles/r3_hostregister_abort.md: the runtime keeps registered ranges in a map keyed by
+// their start address; overlapping registrations are accepted, cannot all be undone, and a later hipHostUnregister aborts the
+// process), whoever locked them: every range this LIBRARY has registered is in one process-wide list (several contexts of a process
+// -- one per GPU thread, the header layer's next to a harness's -- see each other's), and pages somebody ELSE has page-locked (the
+// host application, a pinned torch tensor, the data source itself) are found by asking the runtime about the chunk's first and last
+// page and every 2 MB in between.  A chunk that touches either kind is never registered and never copied directly -- a direct copy
+// that starts in page-locked memory and runs past its end faults on the device -- but staged through two pinned buffers of our own.
+namespace {
+struct RegRange { char* b; size_t len; };
+std::mutex g_reg_mu;
+std::vector<RegRange> g_regs;                       // every range registered through aqg_col_pin, all contexts of the process
+bool lib_registered(const char* b, const char* e) {  // (g_reg_mu held)
+    for (const auto& r : g_regs) if (b < r.b + r.len && r.b < e) return true;
+    return false;
+}
+// is any probed page of [b, e) page-locked by somebody else?
+bool foreign_registered(const char* b, const char* e) {
+    constexpr size_t STEP = (size_t)2 << 20;
+    auto probe = [](const char* p) {
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof at);
+        const hipError_t rc = hipPointerGetAttributes(&at, p);
+        if (rc != hipSuccess) { (void)hipGetLastError(); return false; }     // (older runtimes: "invalid value" for pageable memory)
+        return at.type == hipMemoryTypeHost || at.type == hipMemoryTypeManaged;
+    };
+    if (e <= b) return false;
+    if (probe(b) || probe(e - 1)) return true;
+    for (const char* p = b + STEP; p < e; p += STEP) if (probe(p)) return true;
+    return false;
+}
+} // namespace
 static void pin_release(aqg_ctx* ctx, aqg_pin& p) {
-    // every upload in flight first, not only this column's: a LATER column whose host range overlaps pages registered for this one is
-    // copied by DMA straight out of them (test_col_pin_async_upload_is_stream_ordered pins overlapping slices; unlocking the pages
-    // under such a copy aborted the process once in ~7 runs)
+    // no page is unlocked while a DMA of this context may still read it (every upload in flight, not only this column's: chunks are
+    // issued back to back on the one copy stream)
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     if (p.ev) { hipEventSynchronize(p.ev); hipEventDestroy(p.ev); p.ev = nullptr; }
-    for (auto& r : p.regs) (void)hipHostUnregister(r.first);
+    {
+        std::lock_guard<std::mutex> lock(g_reg_mu);
+        for (auto& r : p.regs) {
+            (void)hipHostUnregister(r.first);
+            for (size_t i = 0; i < g_regs.size(); ++i) if (g_regs[i].b == static_cast<char*>(r.first)) { g_regs[i] = g_regs.back(); g_regs.pop_back(); break; }
+        }
+    }
     p.regs.clear();
     (void)hipGetLastError();
 }
@@ -195,11 +233,11 @@ int aqg_col_pin(aqg_ctx* ctx, const void* host_ptr, size_t bytes, void** dptr) {
     void* d = nullptr;
     AQG_TRY(aqg_malloc(ctx, bytes, &d));
     aqg_pin pin{d, bytes, {}, nullptr};
-    if (!ctx->copy_stream) AQG_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    // every exit below this line releases what the call has locked and allocated so far
+    auto fail = [&](int rc) { if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream); pin_release(ctx, pin); (void)hipFree(d); (void)hipGetLastError(); return rc; };
+    if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "aqg_col_pin: hipStreamCreateWithFlags failed"; return fail(AQG_ERR_HIP); }
     static const bool no_register = getenv("AQG_PIN_PAGEABLE") != nullptr;    // A/B measurements only
     constexpr size_t CHUNK = (size_t)256 << 20, PAGE = 4096;
-    // fallback: through two pinned staging buffers of our own (a source range that straddles memory somebody else registered is
-    // refused by the runtime with "invalid argument")
     auto staged = [&](size_t off, size_t len) -> bool {
         constexpr size_t SB = (size_t)32 << 20;
         for (int k = 0; k < 2; ++k) if (!ctx->up_buf[k]) {
@@ -227,6 +265,7 @@ int aqg_col_pin(aqg_ctx* ctx, const void* host_ptr, size_t bytes, void** dptr) {
         return staged(off, len);
     };
     bool ok = true;
+    ctx->pin_chunks[0] = ctx->pin_chunks[1] = ctx->pin_chunks[2] = 0;
     for (size_t o = 0; o < bytes && ok; o += CHUNK) {
         const size_t c = bytes - o < CHUNK ? bytes - o : CHUNK;
         const char* src = static_cast<const char*>(host_ptr) + o;
@@ -235,31 +274,38 @@ int aqg_col_pin(aqg_ctx* ctx, const void* host_ptr, size_t bytes, void** dptr) {
         // and a copy that starts in registered memory and runs past its end faults on the device (found by bench.py, 4 GB column).
         char* rb = reinterpret_cast<char*>(((uintptr_t)src + PAGE - 1) & ~(uintptr_t)(PAGE - 1));
         char* re = reinterpret_cast<char*>(((uintptr_t)src + c) & ~(uintptr_t)(PAGE - 1));
-        bool reg = false;
-        // never a range that touches pages this context has already page-locked (overlapping columns: slices of one array).  The runtime
-        // accepts some such registrations, cannot undo them ("Cannot unregister host_ptr") and aborts the process on a later
-        // unregistration ("Memobj map does not have ptr"): seen once in ~6 runs of the overlapping-slices test.  Such a chunk goes
-        // through the staging buffers instead.
-        bool overlaps = false;
-        auto hits = [&](const std::vector<std::pair<void*, size_t>>& regs) {
-            for (const auto& r : regs) if (rb < static_cast<char*>(r.first) + r.second && static_cast<char*>(r.first) < re) return true;
-            return false;
-        };
-        if (re > rb) { overlaps = hits(pin.regs); for (const auto& kv : ctx->pins) overlaps = overlaps || hits(kv.second.regs); }
-        if (!no_register && c >= ((size_t)1 << 20) && re > rb && !overlaps) {
-            if (hipHostRegister(rb, (size_t)(re - rb), hipHostRegisterDefault) == hipSuccess) { pin.regs.emplace_back(rb, (size_t)(re - rb)); reg = true; }
-            else (void)hipGetLastError();
+        // the pages the chunk TOUCHES (its partial first and last page included): a direct copy must not start or end in locked memory either
+        const char* tb = reinterpret_cast<const char*>((uintptr_t)src & ~(uintptr_t)(PAGE - 1));
+        const char* te = reinterpret_cast<const char*>(((uintptr_t)src + c + PAGE - 1) & ~(uintptr_t)(PAGE - 1));
+        bool reg = false, locked_by_others;
+        {
+            std::lock_guard<std::mutex> lock(g_reg_mu);        // check and register in one step: two GPU threads pinning slices of one array
+            locked_by_others = lib_registered(tb, te) || foreign_registered(tb, te);
+            if (!locked_by_others && !no_register && c >= ((size_t)1 << 20) && re > rb) {
+                if (hipHostRegister(rb, (size_t)(re - rb), hipHostRegisterDefault) == hipSuccess) {
+                    pin.regs.emplace_back(rb, (size_t)(re - rb));
+                    g_regs.push_back(RegRange{rb, (size_t)(re - rb)});
+                    reg = true;
+                } else (void)hipGetLastError();
+            }
         }
-        if (overlaps) { ok = staged(o, c); continue; }          // (a direct copy that starts in someone else's locked pages and runs past them faults)
+        ++ctx->pin_chunks[locked_by_others ? 1 : reg ? 0 : 2];
+        if (locked_by_others) { ok = staged(o, c); continue; }
         if (reg) ok = copy(o, (size_t)(rb - src)) && copy(o + (size_t)(rb - src), (size_t)(re - rb)) && copy(o + (size_t)(re - src), (size_t)(src + c - re));
         else ok = copy(o, c);
     }
-    if (!ok) { hipStreamSynchronize(ctx->copy_stream); pin_release(ctx, pin); hipFree(d); return AQG_ERR_HIP; }
-    AQG_HIP(ctx, hipEventCreateWithFlags(&pin.ev, hipEventDisableTiming));
-    AQG_HIP(ctx, hipEventRecord(pin.ev, ctx->copy_stream));
-    AQG_HIP(ctx, hipStreamWaitEvent(ctx->stream, pin.ev, 0));
+    if (!ok) return fail(AQG_ERR_HIP);
+    if (hipEventCreateWithFlags(&pin.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(pin.ev, ctx->copy_stream) != hipSuccess ||
+        hipStreamWaitEvent(ctx->stream, pin.ev, 0) != hipSuccess) { ctx->err = "aqg_col_pin: completion event"; return fail(AQG_ERR_HIP); }
     ctx->pins[host_ptr] = pin;
     *dptr = d;
+    return AQG_OK;
+}
+int aqg_col_pin_last(aqg_ctx* ctx, uint32_t* registered, uint32_t* staged, uint32_t* pageable) {
+    if (!ctx) return AQG_ERR_ARG;
+    if (registered) *registered = ctx->pin_chunks[0];
+    if (staged) *staged = ctx->pin_chunks[1];
+    if (pageable) *pageable = ctx->pin_chunks[2];
     return AQG_OK;
 }
 int aqg_col_unpin(aqg_ctx* ctx, const void* host_ptr) {

@@ -98,6 +98,10 @@ int aqg_memset(aqg_ctx* ctx, void* dst_dev, int byte, size_t bytes);
  * of this library (and aqg_sync) is ordered behind it.  The host memory must stay valid and unchanged until then -- the
  * reference's borrowed columns live as long as the query.  PCIe line rate (56-57 GB/s measured on the MI355X box).          */
 int aqg_col_pin(aqg_ctx* ctx, const void* host_ptr, size_t bytes, void** dptr);
+/* how the chunks of the most recent upload of this context travelled: page-locked + DMA; staged through the library's own pinned buffers
+ * (the chunk touches pages that are already page-locked -- by another column or context of this library, or by somebody else, which a
+ * direct copy or a second registration must not touch: profiles/r3_hostregister_abort.md); plain pageable copy (short columns)       */
+int aqg_col_pin_last(aqg_ctx* ctx, uint32_t* registered_chunks, uint32_t* staged_chunks, uint32_t* pageable_chunks);
 int aqg_col_unpin(aqg_ctx* ctx, const void* host_ptr);
 int aqg_col_unpin_all(aqg_ctx* ctx);
 

@@ -184,6 +184,66 @@ def test_col_pin_async_upload_is_stream_ordered(gpu, oracle):
     gpu.col_unpin_all()
 
 
+def test_col_pin_of_memory_somebody_else_has_page_locked(gpu, oracle):
+    """pages the HOST APPLICATION has page-locked (here: the test, through hipHostRegister) are neither registered again nor copied
+    from directly -- the runtime keeps registrations in a map keyed by their start, overlapping ones cannot be undone, and a direct copy
+    that starts in locked memory and runs past its end faults (profiles/r3_hostregister_abort.md): such chunks are staged.  Whole
+    column, a slice that starts inside the locked part and ends behind it, one that ends inside it; then Q1 over the mirrors."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    rng = np.random.default_rng(23)
+    base = rng.integers(-1000, 1000, 10_000_000).astype(np.int32)
+    addr = base.ctypes.data
+    lo = (addr + (8 << 20) + 4095) & ~4095                       # [lo, lo + 16 MB): locked by "the application"
+    assert hip.hipHostRegister(ctypes.c_void_p(lo), ctypes.c_size_t(16 << 20), ctypes.c_uint(0)) == 0
+    try:
+        i_lo = (lo - addr) // 4
+        alive = []
+        for off, n in ((0, 10_000_000), (i_lo + 1000, 6_000_000), (5, i_lo + 2_000_000), (i_lo, 1 << 20)):
+            a = base[off:off + n]
+            d = gpu.col_pin(a)
+            assert gpu.col_pin_last() == (0, 1, 0), gpu.col_pin_last()       # the one chunk touches foreign locked pages: staged
+            assert int(gpu.reduce(ck.RED_SUM, d)) == int(a.sum(dtype=np.int64)), (off, n)
+            hk = np.ascontiguousarray(a % 7)
+            alive.append(hk)
+            gb = gpu.groupby_agg([gpu.col_pin(hk)], [ck.RED_SUM], [d], hint=0)
+            assert gpu.col_pin_last()[1] == 0                                  # (the key column is memory of its own)
+            o = oracle.groupby([hk])
+            assert gb.ngroups == o["ngroups"] and np.array_equal(gb.first_rows(), o["first_rows"])
+            gb.destroy()
+        gpu.col_unpin_all()
+    finally:
+        assert hip.hipHostUnregister(ctypes.c_void_p(lo)) == 0   # the application's registration is still its own to undo
+
+
+def test_two_contexts_pin_overlapping_slices_of_one_array(oracle):
+    """two contexts of one process (one per GPU thread; the header layer's runtime next to a harness's) page-lock through ONE registry:
+    the second context's overlapping slice is staged instead of being registered over the first's pages; unpinning in either order
+    and pinning again works (before: each context only knew its own registrations)"""
+    import threading
+    import aquery2_amd
+    rng = np.random.default_rng(29)
+    base = rng.integers(-1000, 1000, 12_000_000).astype(np.int32)
+    devs = [aquery2_amd.Device(0), aquery2_amd.Device(0)]
+    slices = [base[0:8_000_000], base[2_000_000:11_000_000]]
+    try:
+        for order in ((0, 1), (1, 0)):
+            out, how = [None, None], [None, None]
+            def body(r):
+                d = devs[r].col_pin(slices[r])
+                how[r] = devs[r].col_pin_last()
+                out[r] = int(devs[r].reduce(ck.RED_SUM, d))
+            th = [threading.Thread(target=body, args=(r,)) for r in range(2)]
+            for t in th: t.start()
+            for t in th: t.join()
+            assert out == [int(s.sum(dtype=np.int64)) for s in slices]
+            assert sorted(how) == [(0, 1, 0), (1, 0, 0)], how               # whoever came second found the first's pages and staged its chunk
+            for r in order:
+                devs[r].col_unpin_all()
+    finally:
+        for d in devs: d.close()
+
+
 @pytest.mark.parametrize("off", [0, 1])
 def test_long_window_minmax(gpu, oracle, off):
     """minw / maxw with w >= 128 (the van Herk / Gil-Werman kernel): every element type, windows around the segment and tile
