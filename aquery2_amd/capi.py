@@ -25,6 +25,7 @@ TAG2NP = {
 NP2TAG = {v: k for k, v in TAG2NP.items() if k != BOOL}
 NP2TAG[np.dtype(np.bool_)] = BOOL
 VEC_VEC, VEC_SCALAR, SCALAR_VEC = 0, 1, 2
+PLAN_FAST_LDS, PLAN_SMALL_LDS, PLAN_BIG_LDS, PLAN_DENSE, PLAN_PART_ONE, PLAN_PART_TWO, PLAN_PART_ROUND1, PLAN_PART_WIDE, PLAN_SORTED_TAIL, PLAN_HBM_TABLE, PLAN_BUILD_PARTITIONED = (1 << i for i in range(11))
 
 
 class AqgError(RuntimeError):
@@ -113,6 +114,12 @@ class GroupBy:
     @property
     def ngroups(self):
         return self.dev.lib.aqg_groupby_ngroups(self.h)
+
+    @property
+    def plan(self):
+        """AQG_PLAN_* bits of the plan the last call through this handle took"""
+        self.dev.lib.aqg_groupby_plan.restype = C.c_uint32
+        return self.dev.lib.aqg_groupby_plan(self.h)
 
     def _view(self, fn, dtype, n):
         p = getattr(self.dev.lib, fn)(self.h)

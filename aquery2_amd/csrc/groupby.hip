@@ -1211,7 +1211,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     const uint32_t p2_parts = parts && !p1_bins && parts <= AQG_P2_MAXPARTS ? parts : 0;
     // tuples wider than 8 bytes with many groups (h2o Q10): hash-partitioned rows, every partition grouped inside LDS
     const bool use_wpart = !part_off && !p1_off && !dense && !use_lds && ks.wide && !for_build && !plan.sj && n >= (1u << 20) && hint > (1u << 20) && as.nacc <= 4 &&
-                           !h->no_wide_part && aqg_partitionw_applies(ks, as, n);
+                           !h->no_wide_part && aqg_partitionw_applies(ks, as, n, hint);
     if (use_wpart) gcap = (uint32_t)((uint64_t)hint + hint / 4 + 4096 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : (uint64_t)hint + hint / 4 + 4096);
 
     // more than ~1.6e7 groups expected out of a partition plan: the records are ORDERED (aqg_sorted_tail) instead of ranked through a
@@ -1228,7 +1228,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     const bool ordered_emit = !small_rank && hint >= (1u << 20) && !sorted_tail;
     if (ordered_emit) need += slots * 4 + 4096;
     size_t part_need = 0;
-    if (use_wpart) part_need = aqg_partitionw_ws_bytes(ctx, ks, n, as) + 65536;
+    if (use_wpart) part_need = aqg_partitionw_ws_bytes(ctx, ks, n, as, hint) + 65536;
     else if (p1_bins) part_need = aqg_partition1_ws_bytes(ctx, ks, n, as, p1_bins) + 65536;
     else if (p2_parts) part_need = aqg_partition2_ws_bytes(ctx, ks, n, as, p2_parts) + 65536;
     else if (use_part) part_need = aqg_partition_ws_bytes(n, ks.total_bytes <= 4 ? 4 : 8, as, pbits) + 65536;
@@ -1333,13 +1333,16 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         unsigned grid = aqg_grid(ctx, n / 8 + 1, block, 2, bpc);
         // (more workgroups than fit the chip cost more in table merges than they gain: 8192 -> +3 %, 32768 -> +30 % on Q1)
         const uint32_t* khi = fast_k64 && !fast_key8 ? static_cast<const uint32_t*>(ks.col[1]) : nullptr;
+        h->plan_bits = AQG_PLAN_FAST_LDS;
         const int rc = aqg_fast_aggregate(ctx, static_cast<const uint32_t*>(ks.col[0]), khi, fast_k64, fast_v8, as.nacc, plan.need_count != 0, fv, gt, n, lcap, lds, grid, block);
         AQG_TRY(rc);
     } else if (n && dense) {
+        h->plan_bits = AQG_PLAN_DENSE;
         AQG_TRY(aqg_dense_aggregate(ctx, ks, dspec, as, n, plan.need_count, gt));
     } else if (n && (use_wpart || use_part)) {
         const size_t mark = ctx->ws_off;
-        if (use_wpart) AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed));
+        h->plan_bits = (use_wpart ? AQG_PLAN_PART_WIDE : p1_bins ? AQG_PLAN_PART_ONE : p2_parts ? AQG_PLAN_PART_TWO : AQG_PLAN_PART_ROUND1) | (sorted_tail ? AQG_PLAN_SORTED_TAIL : 0u);
+        if (use_wpart) AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed, hint));
         else if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap));
         else if (p2_parts) AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap));
         else AQG_TRY(aqg_partition_aggregate(ctx, ks, as, n, pbits, part_lcap, plan.need_count, gt, gcap));
@@ -1354,6 +1357,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         }
         size_t lds = use_lds ? (size_t)lrep * (lcap + 1) * (8 + 8 * (size_t)as.nacc + (k32 ? 0 : 4) + (plan.need_count ? 4 : 0)) + 4 * 64 : 0;
         unsigned bpc = !use_lds ? 8 : lds <= 20 * 1024 ? 8 : lds <= 40 * 1024 ? 4 : lds <= 80 * 1024 ? 2 : 1;
+        h->plan_bits = big_lds ? AQG_PLAN_BIG_LDS : use_lds ? AQG_PLAN_SMALL_LDS : AQG_PLAN_HBM_TABLE;
         const unsigned block = big_lds ? (as.nacc <= 2 ? 1024 : 512) : 256;
         unsigned grid = big_lds ? (unsigned)ctx->num_cu : aqg_grid(ctx, n / 4 + 1, 256, 2, bpc);
         auto launch = [&](auto kern) -> int {
@@ -1395,7 +1399,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
             // ONE more try with another seed of the partition hash; far over, or over again: a tuple that dominates the input, which no
             // seed spreads -- the HBM table, same hint
             if (getenv("AQG_DEBUG_FLAGS")) fprintf(stderr, "aqg: wide partition plan gave up: flags %u %u %u %u, partition %u holds %u rows (n %u, hint %u, seed %u)\n", fl[0], fl[1], fl[2], fl[3], fl[4], fl[5], n, hint, h->wide_seed);
-            const uint32_t rcap = aqg_partitionw_rows(ks, as, n);
+            const uint32_t rcap = aqg_partitionw_rows(ks, as, n, hint);
             if (h->wide_seed == 0 && fl[5] && fl[5] <= rcap + rcap / 2) h->wide_seed = 0x5BD1E995u; else h->no_wide_part = true;
             return AQG_ERR_RANGE_MISS;
         }
@@ -1711,6 +1715,7 @@ uint32_t aqg_groupby_nrows(const aqg_groupby* g) { return g ? g->n : 0; }
 const uint32_t* aqg_groupby_reversemap(const aqg_groupby* g) { return g && g->has_reversemap ? g->reversemap : nullptr; }
 const uint32_t* aqg_groupby_counts(const aqg_groupby* g) { return g && g->has_counts ? g->counts : nullptr; }
 const uint32_t* aqg_groupby_first_rows(const aqg_groupby* g) { return g && !g->sharded ? g->first_rows : nullptr; }
+uint32_t aqg_groupby_plan(const aqg_groupby* g) { return g ? g->plan_bits : 0; }
 const void* aqg_groupby_agg_result(const aqg_groupby* g, int j) { return g && j >= 0 && j < g->nagg ? g->results[j] : nullptr; }
 
 int aqg_groupby_keys(aqg_groupby* g, int k, void* out_dev) {

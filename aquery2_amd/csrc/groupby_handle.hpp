@@ -24,6 +24,7 @@ struct aqg_groupby {
     // the small merge path, which keeps one) while others are already large
     size_t cap_keys[MAXKEYS] = {0}, cap_first = 0, cap_counts = 0, cap_rows = 0, cap_results[MAXAGG] = {0};
     uint32_t hint_used = 0;
+    uint32_t plan_bits = 0;                     // AQG_PLAN_*: the plan the last call through this handle took (diagnostic: aqg_groupby_plan)
     // aqg_groupby_agg_sharded: rows of a sharded table are numbered globally (64 bits); the 32-bit first rows are not filled
     int64_t* first_rows64 = nullptr;
     size_t cap_first64 = 0;

@@ -1151,7 +1151,10 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
 // ---- wide tuples: host ----------------------------------------------------------------------------------------------------------------
 struct WidePlan { uint32_t R, P, B1; int L, nkd, low[3], nt; size_t lds; bool ok; };   // low[l]: bits of level l + 1 (the levels below the first)
 static size_t pw_row_lds(int nkd, int nacc) { return 4 * (size_t)nkd + 4 + 4 + 8 * (size_t)nacc + 4 + 2; }
-static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n) {
+// `hint` = the expected number of groups: with m = n / hint rows per tuple the rows of a partition are not independent -- the tuples are --
+// and the spread of a partition's ROW count grows to sqrt(mean * m) (every tuple brings its m rows along); sizing by sqrt(mean) alone sent
+// every table of multi-row tuples through two overflowing attempts to the HBM table (3.2e6 rows, 1.26e6 tuples: partitions at mean + 7 sigma)
+static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t hint) {
     WidePlan best;
     memset(&best, 0, sizeof best);
     int nkd = 0;
@@ -1169,7 +1172,8 @@ static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n) {
         R &= ~7u;
         double mu = (double)R;
         static const double sigmas = getenv("AQG_PW_SIGMA") ? atof(getenv("AQG_PW_SIGMA")) : 6.0;     // (tests: a small value makes partitions overflow by chance)
-        for (int it = 0; it < 8; ++it) mu = (double)R - sigmas * sqrt(mu);       // (a million partitions: five sigma leave a quarter of the calls with one partition over)
+        const double mult = hint && hint < n ? (double)n / (double)hint : 1.0;
+        for (int it = 0; it < 8; ++it) mu = (double)R - sigmas * sqrt((mu > 1 ? mu : 1) * mult);   // (a million partitions: five sigma leave a quarter of the calls with one partition over)
         if (mu < 64) continue;
         const uint64_t P = (uint64_t)((double)n / mu) + 1;
         w.R = R;
@@ -1186,11 +1190,11 @@ static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n) {
     }
     return best;
 }
-bool aqg_partitionw_applies(const KeySpec& ks, const AccSpec& as, uint32_t n) { return ks.wide && pw_plan(ks, as, n).ok; }
-uint32_t aqg_partitionw_rows(const KeySpec& ks, const AccSpec& as, uint32_t n) { return pw_plan(ks, as, n).R; }
+bool aqg_partitionw_applies(const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t hint) { return ks.wide && pw_plan(ks, as, n, hint).ok; }
+uint32_t aqg_partitionw_rows(const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t hint) { return pw_plan(ks, as, n, hint).R; }
 
-size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as) {
-    const WidePlan w = pw_plan(ks, as, n);
+size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t hint) {
+    const WidePlan w = pw_plan(ks, as, n, hint);
     ValCols vc;
     p1_val_cols(as, &vc);
     size_t per_row = 4 + 2 * (4 + 4 + 4 * (size_t)w.nkd);                    // the hash column; two sets of {hash, row, key dwords}
@@ -1199,8 +1203,8 @@ size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
     return ((size_t)n + 64) * per_row + 256 * (16 + 8 * MAXACC + 8 * MAXKEYS) + ((size_t)w.P + 4096) * 24 + ((size_t)n / P2_PT + (size_t)w.P + 64) * 8 + 65536;
 }
 
-int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap, uint32_t seed) {
-    const WidePlan w = pw_plan(ks, as, n);
+int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap, uint32_t seed, uint32_t hint) {
+    const WidePlan w = pw_plan(ks, as, n, hint);
     if (!w.ok) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "wide-tuple partitioned group-by: the input does not fit 128 x 128 x 128 partitions");
     ValCols vc;
     p1_val_cols(as, &vc);

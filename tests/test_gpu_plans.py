@@ -1,0 +1,132 @@
+"""Every group-by plan of DESIGN.md section 4.1 pinned in the committed -m gpu suite: the plans only large inputs reach at default
+thresholds (the two-level partition plan, the round-1 pipeline, the ordering tail over packed keys and over wide tuples) are FORCED
+by their measurement switches in a fresh process (the switches are read once per process), the plan actually taken is read back
+(aqg_groupby_plan) and every output is compared with the oracle.  Groups have several rows each, so merging inside the partition
+aggregation and inside the ordering tail's partitions is exercised, not only one-row groups.  The last test is h2o Q10 at 1e8 rows at
+DEFAULT thresholds (wide-tuple partitions + the ordering tail), checked against its own input."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import checker as ck
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+PRELUDE = r'''
+import sys
+import numpy as np
+sys.path.insert(0, "tests")
+import aquery2_amd, checker as ck, golden_util as gu
+from aquery2_amd import capi
+gpu, oracle = aquery2_amd.Device(0), ck.load_oracle()
+def check(keys, ops, vals, hint, want_plan):
+    o = oracle.groupby(keys)
+    gb = gpu.groupby_agg(keys, ops, vals, hint=hint)
+    assert gb.plan == want_plan, ("plan", gb.plan, want_plan)
+    assert gb.ngroups == o["ngroups"], (gb.ngroups, o["ngroups"])
+    assert np.array_equal(gb.first_rows(), o["first_rows"])
+    for k, c in enumerate(keys):
+        assert np.array_equal(gb.keys(k, c.dtype), c[o["first_rows"]]), k
+    for j, (op, v) in enumerate(zip(ops, vals)):
+        got, want = gb.result(j, op, ck.tag_of(v)), oracle.grouped_reduce(op, v, o)
+        if v.dtype.kind == "f" and op in (ck.RED_SUM, ck.RED_AVG):
+            assert np.allclose(got, want, rtol=1e-12, atol=1e-9), j
+        else:
+            assert gu.same_bits(got, want), j
+    print("OK", gb.ngroups, flush=True)
+rng = np.random.default_rng(41)
+'''
+
+
+def run_forced(env, body):
+    out = subprocess.run([sys.executable, "-c", PRELUDE + body], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env), cwd=ROOT)
+    assert out.returncode == 0 and "OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+PACKED = r'''
+n = 3_000_017
+key = rng.integers(0, 300_000, n).astype(np.int32)           # ~10 rows per group
+v1, v3 = rng.integers(-9, 10, n).astype(np.int32), np.round(rng.uniform(0, 100, n), 3).astype(np.float32)
+check([key], [ck.RED_SUM, ck.RED_COUNT, ck.RED_MIN, ck.RED_SUM], [v1, v1, v1, v3], 400_000, %s)
+key8 = (key.astype(np.int64) << 33) | 5                        # an 8-byte packed key takes the same plans
+check([key8], [ck.RED_SUM, ck.RED_MAX], [v1, v3], 400_000, %s)
+'''
+
+
+def test_two_level_partition_plan_forced():
+    """AQG_P1_MAX=1: every partition plan takes two levels (what h2o Q3 / Q5 / Q7 take at 1e9 rows): p2_hist, p2_scatter x 2, p1_agg"""
+    run_forced({"AQG_P1_MAX": "1"}, PACKED % ("capi.PLAN_PART_TWO", "capi.PLAN_PART_TWO"))
+
+
+def test_round1_partition_pipeline_forced():
+    """AQG_DISABLE_P1=1: the round-1 pipeline of partition.hip (packed keys beyond 4096 partitions at default thresholds): part_* kernels"""
+    run_forced({"AQG_DISABLE_P1": "1"}, PACKED % ("capi.PLAN_PART_ROUND1", "capi.PLAN_PART_ROUND1"))
+
+
+def test_one_level_partition_plan_is_what_mid_cardinality_takes():
+    run_forced({}, PACKED % ("capi.PLAN_PART_ONE", "capi.PLAN_PART_ONE"))
+
+
+def test_ordering_tail_over_packed_keys_forced():
+    """AQG_SORTED_TAIL_MIN=1: the records of a partition plan are ORDERED by first row (pn_level_hist, p2_scatter, sorted_emit_kernel) instead
+    of ranked through a bitmap -- what any partition plan takes from 2^24 groups on; here with ~10 rows per group"""
+    run_forced({"AQG_SORTED_TAIL_MIN": "1"}, PACKED % ("capi.PLAN_PART_ONE | capi.PLAN_SORTED_TAIL", "capi.PLAN_PART_ONE | capi.PLAN_SORTED_TAIL"))
+    run_forced({"AQG_SORTED_TAIL_MIN": "1", "AQG_P1_MAX": "1"}, PACKED % ("capi.PLAN_PART_TWO | capi.PLAN_SORTED_TAIL", "capi.PLAN_PART_TWO | capi.PLAN_SORTED_TAIL"))
+
+
+WIDE = r'''
+n = 3_200_011
+r = rng.integers(0, 1_400_000, n)                              # ~2.3 rows per tuple, 1.2e6 distinct tuples of 16 bytes
+ids = [(r %% 100 + 1).astype(np.int32), (r // 100 %% 1000).astype(np.int32), (r // 100_000 + 7).astype(np.int32), ((r * 7) %% 13).astype(np.int32)]
+v1, v3 = rng.integers(-9, 10, n).astype(np.int32), np.round(rng.uniform(0, 100, n), 3).astype(np.float32)
+check(ids, [ck.RED_SUM, ck.RED_COUNT, ck.RED_SUM], [v1, v1, v3], 1_300_000, %s)      # (2.5 rows per tuple: the partitions are sized for the wider spread)
+'''
+
+
+def test_wide_tuple_partition_plan_with_and_without_the_ordering_tail():
+    """tuples wider than 8 bytes with more than 2^20 groups expected (h2o Q10's plan): pw_hash, the hashed tile scatters, pw_agg -- at
+    default thresholds with the bitmap tail, and with the ordering tail forced (wide tuples fetch their key columns through first rows)"""
+    run_forced({}, WIDE % "capi.PLAN_PART_WIDE")
+    run_forced({"AQG_SORTED_TAIL_MIN": "1"}, WIDE % "capi.PLAN_PART_WIDE | capi.PLAN_SORTED_TAIL")
+
+
+def test_h2o_q10_at_1e8_rows_default_thresholds_groups_of_two():
+    """h2o Q10 `sum(v3), count(*) BY id1 .. id6` (benchmark/h2o/groupby.sql:23) at 1e8 rows with the DEFAULT thresholds: hint 1e8 >= 2^24, so
+    the call takes the wide-tuple partitions AND the ordering tail.  The table is the first 5e7 rows of the seed-42 columns (all tuples
+    distinct) twice over, so every group has exactly two rows and the result is known from the input alone: groups = 5e7, group g = row g,
+    count 2, sum(v3) = 2 * v3[g] (exact in double).  tools/q10_check.py is the 1e9-row form (every group one row)."""
+    import aquery2_amd
+    from aquery2_amd import capi
+    d = aquery2_amd.Device(0)
+    try:
+        half, n = 50_000_000, 100_000_000
+        def doubled(col, dtype):
+            a = d.gen_column(col, 42, 0, half, 1_000_000_000, 100)
+            b = d.empty(n, dtype)
+            for k in range(2):
+                d._chk(d.lib.aqg_d2d(d.ctx, C.c_void_p(b.ptr + k * half * 4), C.c_void_p(a.ptr), C.c_size_t(half * 4)), "aqg_d2d")
+            d.sync(); a.free()
+            return b
+        ids = [doubled(c, np.int32) for c in (ck.GEN_ID1, ck.GEN_ID2, ck.GEN_ID3, ck.GEN_ID4, ck.GEN_ID5, ck.GEN_ID6)]
+        v3 = doubled(ck.GEN_V3, np.float32)
+        gb = d.groupby_agg(ids, [ck.RED_SUM, ck.RED_COUNT], [v3, v3], hint=n)
+        assert gb.plan == capi.PLAN_PART_WIDE | capi.PLAN_SORTED_TAIL, gb.plan
+        assert gb.ngroups == half, gb.ngroups                         # (seed 42: the first 5e7 tuples are all distinct)
+        tmp = d.empty(half, np.int32)
+        for k in range(6):
+            d._chk(d.lib.aqg_groupby_keys(gb.h, k, C.c_void_p(tmp.ptr)), "aqg_groupby_keys")
+            first_half = aquery2_amd.DevBuf(d, ids[k].ptr, np.int32, half, owned=False)
+            assert int(d.reduce(ck.RED_SUM, d.ewise(ck.OP_NE, tmp, first_half, keep=True))) == 0, k
+        assert np.array_equal(gb.first_rows(), np.arange(half, dtype=np.uint32))
+        cnt = gb.result(1, ck.RED_COUNT, ck.FLOAT)
+        assert int(cnt.min()) == 2 and int(cnt.max()) == 2
+        s = gb.result(0, ck.RED_SUM, ck.FLOAT)
+        h3 = aquery2_amd.DevBuf(d, v3.ptr, np.float32, half, owned=False).to_host()
+        assert np.array_equal(s, 2.0 * h3.astype(np.float64))
+    finally:
+        d.close()
