@@ -242,6 +242,35 @@ class Comm:
             return gb
         return run, gb
 
+    def reduce_sharded(self, op, x):
+        """aqg_reduce over a column sharded by row range (`x`: this rank's rows); the whole column's result on every rank"""
+        d = self.dev
+        xd = d._dev(x)
+        buf = (C.c_ubyte * 16)()
+        d._chk(d.lib.aqg_reduce_sharded(self.h, op, xd.tag, C.c_void_p(xd.ptr), C.c_uint32(xd.n), buf), "aqg_reduce_sharded")
+        ot = d.lib.aqg_reduce_out_dtype(op, xd.tag)
+        v = np.frombuffer(bytes(buf), dtype=TAG2NP[ot], count=1)[0]
+        if ot in (INT128, UINT128):
+            lo, hi = int(v["lo"]), int(v["hi"])
+            return (hi << 64) + lo if ot == INT128 else (hi << 64) | lo
+        return v
+
+    def corr_sharded(self, x, y):
+        d = self.dev
+        xd, yd = d._dev(x), d._dev(y)
+        out = C.c_double()
+        d._chk(d.lib.aqg_corr_sharded(self.h, xd.tag, C.c_void_p(xd.ptr), yd.tag, C.c_void_p(yd.ptr), C.c_uint32(xd.n), C.byref(out)), "aqg_corr_sharded")
+        return out.value
+
+    def scan_sharded(self, op, x, w=0):
+        d = self.dev
+        xd = d._dev(x)
+        ot = d.lib.aqg_scan_out_dtype(op, xd.tag)
+        out = d.empty(xd.n, TAG2NP[ot])
+        d._chk(d.lib.aqg_scan_sharded(self.h, op, xd.tag, C.c_void_p(xd.ptr), C.c_uint32(xd.n), C.c_uint32(w), C.c_void_p(out.ptr)), "aqg_scan_sharded")
+        d.sync()
+        return out.to_host()
+
     def groupby_exchange(self, local, merge_ops, row_base, gmax=0, handle=None):
         """the exchange alone over an existing shard table (aqg_groupby_exchange): partial p = aggregate p of `local`"""
         d = self.dev

@@ -122,6 +122,19 @@ int aqg_group_offsets(aqg_ctx* ctx, const aqg_groupby* g, uint32_t* offsets_dev,
 // groupby.hip: out[g] = op(x[rows whose id in gid_col is g]) through the group-by plans (gid_col: n dense ids in first-occurrence order)
 extern "C" int aqg_grouped_reduce_keyed(aqg_ctx* ctx, aqg_groupby* g, const uint32_t* gid_col, int op, int t, const void* x, void* out_dev);
 
+// exchange.hip: the all-gather of a communicator (`bytes` bytes of every rank, rank order, on / ordered behind the context's stream)
+struct aqg_comm;
+int aqg_comm_allgather_internal(aqg_comm* c, const void* send_dev, void* recv_dev, size_t bytes);
+aqg_ctx* aqg_comm_ctx(aqg_comm* c);
+// scan.hip: running min / max of one row-range shard, seeded with the fold of the earlier shards
+extern "C" int aqg_scan_minmax_seeded(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, const void* seed_host, void* out);
+
+// reduce.hip: raw moments of a column / of a pair of columns left in device memory (the sharded reductions ship them)
+extern "C" int aqg_stats_dev(aqg_ctx* ctx, int t, const void* x, uint32_t n, int flags, void* out_dev48);
+extern "C" int aqg_corr_sums_dev(aqg_ctx* ctx, int tx, const void* x, int ty, const void* y, uint32_t n, void* out_dev80);
+// exchange.hip: grow-only device scratch of a communicator (send / receive sides of its small exchanges)
+int aqg_comm_scratch(aqg_comm* c, size_t send_bytes, size_t recv_bytes, void** send, void** recv);
+
 // internal aggregate of aqg_groupby_agg (not in aqg.h): the sum of squares, typed like SUM -- the second moment the sharded call ships for VAR / STDDEV
 constexpr int AQG_RED_SUMSQ = 64;
 

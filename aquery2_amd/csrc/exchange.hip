@@ -88,6 +88,7 @@ struct aqg_comm {
     void* user = nullptr;
     // grow-only device buffers
     void *send = nullptr, *recv = nullptr, *cat = nullptr, *hdr = nullptr;
+    void *xsend = nullptr, *xrecv = nullptr; size_t xsend_cap = 0, xrecv_cap = 0;   // aqg_reduce_sharded / aqg_scan_sharded
     size_t send_cap = 0, recv_cap = 0, cat_cap = 0, hdr_cap = 0;
     aqg_groupby *local = nullptr, *merged = nullptr;
     aqg_groupby* merged_x[3] = {nullptr, nullptr, nullptr};     // further merge calls when one cannot hold all payload columns (8 accumulators per call)
@@ -529,6 +530,16 @@ int exchange_core(aqg_comm* comm, aqg_groupby* L, int nkeys, const int* key_dtyp
 
 } // namespace
 
+// internal (reduce.hip / sharded.hip): the communicator's all-gather and context
+int aqg_comm_allgather_internal(aqg_comm* c, const void* send_dev, void* recv_dev, size_t bytes) { return allgather(c, send_dev, recv_dev, bytes); }
+aqg_ctx* aqg_comm_ctx(aqg_comm* c) { return c ? c->ctx : nullptr; }
+int aqg_comm_scratch(aqg_comm* c, size_t send_bytes, size_t recv_bytes, void** send, void** recv) {
+    AQG_TRY(grow(c->ctx, &c->xsend, &c->xsend_cap, send_bytes));
+    AQG_TRY(grow(c->ctx, &c->xrecv, &c->xrecv_cap, recv_bytes));
+    *send = c->xsend; *recv = c->xrecv;
+    return AQG_OK;
+}
+
 extern "C" {
 
 int aqg_comm_unique_id(void* id_out) {
@@ -570,7 +581,7 @@ void aqg_comm_destroy(aqg_comm* c) {
     if (!c) return;
     if (c->ctx) hipStreamSynchronize(c->ctx->stream);
     if (c->nccl) { if (Rccl* r = rccl(nullptr)) r->CommDestroy(c->nccl); }
-    for (void* p : {c->send, c->recv, c->cat, c->hdr}) if (p) hipFree(p);
+    for (void* p : {c->send, c->recv, c->cat, c->hdr, c->xsend, c->xrecv}) if (p) hipFree(p);
     if (c->local) aqg_groupby_destroy(c->local);
     if (c->merged) aqg_groupby_destroy(c->merged);
     for (aqg_groupby* m : c->merged_x) if (m) aqg_groupby_destroy(m);

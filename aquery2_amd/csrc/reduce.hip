@@ -347,6 +347,50 @@ int aqg_reduce_dev(aqg_ctx* ctx, int op, int t, const void* x, uint32_t n, void*
     });
 }
 
+// internal (sharded.hip): {sum 16 B | sum of squares 16 B | min 8 B | max 8 B} of a column (the representation of aqg_reduce's epilogue:
+// integer sums two's complement 128-bit, floating ones a double in the low word; min / max the element's bits) copied to `out_dev48`.
+// flags: 1 sum, 2 sum of squares, 4 min / max.  n > 0.
+int aqg_stats_dev(aqg_ctx* ctx, int t, const void* x, uint32_t n, int flags, void* out_dev48) {
+    return aqg_dispatch_num(t, [&](auto tt) -> int {
+        using T = typename decltype(tt)::type;
+        stats_raw* fin = nullptr;
+        AQG_TRY(run_stats<T>(ctx, static_cast<const T*>(x), n, flags, nullptr, &fin));
+        AQG_HIP(ctx, hipMemcpyAsync(out_dev48, fin, sizeof(stats_raw), hipMemcpyDeviceToDevice, ctx->stream));
+        return AQG_OK;
+    });
+}
+// internal (sharded.hip): the five 128-bit sums of corr (sx, sy, sxy, sx2, sy2) copied to `out_dev80`; integer columns, n > 0
+int aqg_corr_sums_dev(aqg_ctx* ctx, int tx, const void* x, int ty, const void* y, uint32_t n, void* out_dev80) {
+    auto int_only = [&](int dt, auto&& f) -> int {
+        switch (dt) {
+        case AQG_INT8: return f(aqg_tag<int8_t>{});
+        case AQG_INT16: return f(aqg_tag<int16_t>{});
+        case AQG_INT32: return f(aqg_tag<int32_t>{});
+        case AQG_INT64: return f(aqg_tag<int64_t>{});
+        case AQG_UINT8: return f(aqg_tag<uint8_t>{});
+        case AQG_UINT16: return f(aqg_tag<uint16_t>{});
+        case AQG_UINT32: return f(aqg_tag<uint32_t>{});
+        }
+        return aqg_fail(ctx, AQG_ERR_DTYPE, "corr: integer columns (floating inputs are accumulated with per-step truncation in the reference; not offered on device)");
+    };
+    return int_only(tx, [&](auto ta) -> int {
+        return int_only(ty, [&](auto tb) -> int {
+            using TX = typename decltype(ta)::type; using TY = typename decltype(tb)::type;
+            unsigned grid = aqg_grid(ctx, n, 256, 8, 8);
+            AQG_TRY(aqg_ws_reset(ctx));
+            AQG_TRY(aqg_ws_ensure(ctx, (size_t)(grid + 2) * sizeof(corr_raw) + 1024));
+            corr_raw *parts, *fin;
+            AQG_TRY(aqg_ws_get(ctx, grid, &parts));
+            AQG_TRY(aqg_ws_get(ctx, 1, &fin));
+            hipLaunchKernelGGL((corr_kernel<TX, TY>), dim3(grid), dim3(256), 0, ctx->stream, (const TX*)x, (const TY*)y, n, parts);
+            hipLaunchKernelGGL(corr_final_kernel, dim3(1), dim3(64), 0, ctx->stream, parts, grid, fin);
+            AQG_TRY(aqg_check_launch(ctx, "corr_kernel"));
+            AQG_HIP(ctx, hipMemcpyAsync(out_dev80, fin, sizeof(corr_raw), hipMemcpyDeviceToDevice, ctx->stream));
+            return AQG_OK;
+        });
+    });
+}
+
 int aqg_corr(aqg_ctx* ctx, int tx, const void* x, int ty, const void* y, uint32_t n, double* out_host) {
     if (!ctx || !out_host || ((!x || !y) && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_corr: bad argument");
     AQG_CHECK_ROWS(ctx, n, "aqg_corr");

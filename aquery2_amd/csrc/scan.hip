@@ -121,7 +121,7 @@ template <class T> constexpr int chain_m() { return sizeof(T) <= 4 ? 8 : 4; }   
 
 template <class T, class ALG, int WR, int M>
 __global__ void __launch_bounds__(SB) chained_scan_kernel(const T* __restrict__ x, uint32_t n, uint32_t* __restrict__ ctrl /* [0] link counter, [1] error */,
-                                                          uint64_t* __restrict__ slots, void* __restrict__ out) {
+                                                          uint64_t* __restrict__ slots, void* __restrict__ out, typename ALG::A seed /* fold of the rows of earlier shards (identity: none) */) {
     using A = typename ALG::A;
     constexpr int NW = flagged_words<A>();
     __shared__ A lds_w[8];
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(SB) chained_scan_kernel(const T* __restrict__ 
     }
     // the link's aggregate goes out before the sub-tile scans: by the time a successor looks back it is there
     const A total = block_fold<ALG>(mine, lds_r);
-    if (threadIdx.x == 0) publish_flagged<A>(slots + (size_t)tile * NW, tile == 0 ? ST_PREFIX : ST_AGG, total);
+    if (threadIdx.x == 0) publish_flagged<A>(slots + (size_t)tile * NW, tile == 0 ? ST_PREFIX : ST_AGG, tile == 0 ? ALG::op(seed, total) : total);
     A run = ALG::identity();
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(SB) chained_scan_kernel(const T* __restrict__ 
         if (lane_id() == 0) s_prefix = prefix;
     }
     __syncthreads();
-    const A link_prefix = s_prefix;
+    const A link_prefix = tile == 0 ? seed : s_prefix;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const uint64_t tb = link_base + (uint64_t)m * TS;
@@ -640,8 +640,12 @@ __global__ void __launch_bounds__(SB) vars_kernel(const T* __restrict__ x, uint3
         out[base + j] = SD ? sqrt(var) : var;
     }
 }
+// out[i] = better(out[i], seed): the three-kernel fallback of a seeded running min / max
+template <class T, bool IS_MAX> __global__ void __launch_bounds__(SB) apply_seed_kernel(T* __restrict__ out, uint32_t n, T seed) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const T v = out[i]; out[i] = IS_MAX ? (seed > v ? seed : v) : (seed < v ? seed : v); }
+}
 template <class T, class ALG, int WR>
-int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out, const ScanSeed& seed = ScanSeed{{0, 0}, -0.0, 0}) {
+int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out, const ScanSeed& seed = ScanSeed{{0, 0}, -0.0, 0}, const T* mm_seed = nullptr) {
     using A = typename ALG::A;
     uint32_t ntiles = aqg_ceil_div(n, TS);
     constexpr int M = chain_m<T>();
@@ -676,8 +680,13 @@ int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out, const ScanSeed& 
     AQG_HIP(ctx, hipMemsetAsync(ctrl, 0, 64, ctx->stream));
     AQG_HIP(ctx, hipMemsetAsync(slots, 0, (size_t)nlinks * NW * 8, ctx->stream));
     aqg_kernel_timer_begin(ctx);
-    if constexpr (use_chain)
-        hipLaunchKernelGGL((chained_scan_kernel<T, ALG, WR, M>), dim3(nlinks), dim3(SB), (size_t)TS * osz, ctx->stream, x, n, ctrl, slots, out);
+    if constexpr (use_chain) {
+        T none;                                              // the algebra's identity, spelled on the host
+        if constexpr (WR == W_MINS) none = dlimits<T>::max();
+        else if constexpr (std::is_floating_point_v<T>) none = -dlimits<T>::max();
+        else none = dlimits<T>::min();
+        hipLaunchKernelGGL((chained_scan_kernel<T, ALG, WR, M>), dim3(nlinks), dim3(SB), (size_t)TS * osz, ctx->stream, x, n, ctrl, slots, out, mm_seed ? *mm_seed : none);
+    }
     aqg_kernel_timer_end(ctx);
     AQG_TRY(aqg_check_launch(ctx, "chained_scan_kernel"));
     uint32_t h[2] = {0, 0};
@@ -690,6 +699,9 @@ int run_prefix(aqg_ctx* ctx, const T* x, uint32_t n, void* out, const ScanSeed& 
     hipLaunchKernelGGL((tile_reduce_kernel<T, ALG>), dim3(ntiles), dim3(SB), 0, ctx->stream, x, n, agg);
     hipLaunchKernelGGL((agg_scan_kernel<ALG>), dim3(1), dim3(SB), 0, ctx->stream, agg, ntiles);
     hipLaunchKernelGGL((tile_scan_kernel<T, ALG, WR>), dim3(ntiles), dim3(SB), (size_t)TS * osz, ctx->stream, x, n, agg, out, seed);
+    if constexpr (use_chain) {
+        if (mm_seed) hipLaunchKernelGGL((apply_seed_kernel<T, WR != W_MINS>), dim3(aqg_grid(ctx, n, SB, 4, 8)), dim3(SB), 0, ctx->stream, static_cast<T*>(out), n, *mm_seed);
+    }
     return aqg_check_launch(ctx, "prefix scan");
 }
 
@@ -724,6 +736,29 @@ int aqg_scan_resume(aqg_ctx* ctx, int op, int t, const void* xv, uint32_t n, con
         const T* x = static_cast<const T*>(xv);
         if (op == AQG_SCAN_SUMS) return run_prefix<T, sum_alg<T>, W_SUMS>(ctx, x, n, out, seed);
         return run_prefix<T, sum_alg<T>, W_AVGS>(ctx, x, n, out, seed);
+    });
+}
+
+// mins / maxs of one row-range shard (aqg_scan_sharded): `seed_host` = the fold (min / max, of the column's element type) of every row
+// of the earlier shards, NULL when there is none; op AQG_SCAN_MINS / AQG_SCAN_MAXS, or AQG_SCAN_MINW / AQG_SCAN_MAXW for the running
+// form a window at least as long as the whole column degrades to (no numeric_limits seed on the max)
+int aqg_scan_minmax_seeded(aqg_ctx* ctx, int op, int t, const void* xv, uint32_t n, const void* seed_host, void* out) {
+    if (!ctx || (!xv && n) || (!out && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_scan_minmax_seeded: bad argument");
+    AQG_CHECK_ROWS(ctx, n, "aqg_scan_minmax_seeded");
+    if (n == 0) return AQG_OK;
+    if (!dt_is_num(t)) return aqg_fail(ctx, AQG_ERR_DTYPE, "scan: the column dtype is not numeric");
+    return aqg_dispatch_num(t, [&](auto tt) -> int {
+        using T = typename decltype(tt)::type;
+        const T* x = static_cast<const T*>(xv);
+        T sd;
+        if (seed_host) memcpy(&sd, seed_host, sizeof(T));
+        const T* sp = seed_host ? &sd : nullptr;
+        switch (op) {
+        case AQG_SCAN_MINS: case AQG_SCAN_MINW: return run_prefix<T, min_alg<T>, W_MINS>(ctx, x, n, out, ScanSeed{{0, 0}, -0.0, 0}, sp);
+        case AQG_SCAN_MAXS: return run_prefix<T, max_alg<T>, W_MAXS>(ctx, x, n, out, ScanSeed{{0, 0}, -0.0, 0}, sp);
+        case AQG_SCAN_MAXW: return run_prefix<T, max_alg<T>, W_MAXP>(ctx, x, n, out, ScanSeed{{0, 0}, -0.0, 0}, sp);
+        }
+        return AQG_ERR_ARG;
     });
 }
 

@@ -331,6 +331,21 @@ const int64_t* aqg_groupby_first_rows64(const aqg_groupby* g);
  * merged table in global first-occurrence order, as aqg_groupby_agg_sharded.                                                      */
 int aqg_groupby_exchange(aqg_comm* comm, aqg_groupby* local, int nparts, const int* merge_ops, uint64_t row_base, uint32_t gmax, aqg_groupby** out);
 
+/* ---- reductions and scans of a column sharded by ROW RANGE ---------------------------------------------------------
+ * This rank holds `n` rows (0 allowed) of a column whose shards, laid end to end in rank order, are the whole column.  Every call
+ * makes ONE all-gather of a small record per rank -- raw moments, first / last row, the shard's last w rows -- and answers as the
+ * single-GPU call over the whole column would (server/aggregations.h:19-32,71-86,332-407; :89-281,439-485):
+ *   aqg_reduce_sharded   SUM / MIN / MAX / COUNT / AVG / VAR / STDDEV / FIRST / LAST; the same 16 bytes on every rank; integer results
+ *                        bit-identical to aqg_reduce over the whole column, floating sums = the rank-order sum of the shards' sums
+ *   aqg_corr_sharded     corr(x, y): the five 128-bit sums folded exactly (integer columns, as aqg_corr)
+ *   aqg_scan_sharded     out = this rank's rows of aqg_scan over the whole column: sums / avgs resume from the earlier shards' exact
+ *                        total and row count, mins / maxs from their min / max, windows and shifts take the last rows of the shards
+ *                        before them (neighbour rows for deltas / prev / aggnext).  vars / stddevs are not offered.
+ * A rank whose local part fails still joins the all-gather and EVERY rank returns its status.                                      */
+int aqg_reduce_sharded(aqg_comm* comm, int op, int t, const void* x, uint32_t n, void* out_host16);
+int aqg_corr_sharded(aqg_comm* comm, int tx, const void* x, int ty, const void* y, uint32_t n, double* out_host);
+int aqg_scan_sharded(aqg_comm* comm, int op, int t, const void* x, uint32_t n, uint32_t w, void* out);
+
 /* Fused star join + grouped sum (BASELINE config 4: `fact JOIN small(key, w) ON fact.fk = small.key`, then
  * `sum(fact.val * small.w) BY fact.gkey`): one pass over fk, gkey and val (12 B/row) instead of lookup -> gather ->
  * multiply -> group-by (44 B/row).  The reference emits this as SQL for MonetDB (engine/ast.py:874-1085) followed by

@@ -177,6 +177,107 @@ def test_a_shard_over_gmax_fails_the_call_on_every_rank_instead_of_hanging(two_k
     assert len({g for _, g in out}) == 1 and out[0][1] >= 4
 
 
+def _cuts(n, world, rng, empty=None, tiny=None):
+    c = [0] + sorted(rng.integers(0, n + 1, world - 1).tolist()) + [n]
+    if tiny is not None and world > 2:                           # a shard of a few rows in the middle: halos reach across it
+        c[tiny + 1] = min(n, c[tiny] + 3)
+        c = [0] + sorted(c[1:-1]) + [n]
+    sh = [(c[r], c[r + 1]) for r in range(world)]
+    if empty is not None:
+        lo, hi = sh[empty]
+        sh[empty] = (lo, lo)
+        if empty + 1 < world: sh[empty + 1] = (lo, sh[empty + 1][1])
+        else: sh[empty - 1] = (sh[empty - 1][0], hi)
+    return sh
+
+
+@pytest.mark.parametrize("world,empty,tiny", [(2, None, None), (3, 1, None), (4, None, 1), (5, 0, 2)])
+def test_reductions_over_row_range_shards(oracle, world, empty, tiny):
+    """aqg_reduce_sharded / aqg_corr_sharded: every reduction of the WHOLE column from its shards with ONE all-gather of raw moments;
+    integer results bit for bit, floating sums within the summation-order bound (server/aggregations.h:19-32,71-86,332-407)"""
+    import aquery2_amd
+    rng = np.random.default_rng(100 * world + (empty or 0))
+    n = 200_003
+    cols = {dt: (np.round(rng.uniform(-1000, 1000, n), 3).astype(dt) if np.dtype(dt).kind == "f" else rng.integers(-120 if np.dtype(dt).kind == "i" else 0, 121, n).astype(dt))
+            for dt in (np.int8, np.int32, np.uint32, np.int64, np.uint64, np.float32, np.float64)}
+    cols[np.int64] = cols[np.int64] * (1 << 40)                   # sums that need more than 64 bits per shard pair
+    y = rng.integers(-30000, 30000, n).astype(np.int32)
+    sh = _cuts(n, world, rng, empty, tiny)
+    tr = aquery2_amd.ThreadRanks(world)
+    def body(rank, dev, comm):
+        lo, hi = sh[rank]
+        out = {}
+        for dt, x in cols.items():
+            xs = dev.to_device(np.ascontiguousarray(x[lo:hi]))
+            out[dt] = {name: comm.reduce_sharded(op, xs) for name, op in ck.RED_NAMES.items() if not (name == "avg" and n == 0)}
+        out["corr"] = comm.corr_sharded(np.ascontiguousarray(cols[np.int32][lo:hi]), np.ascontiguousarray(y[lo:hi]))
+        return out
+    try:
+        res = tr.run(body)
+    finally:
+        tr.close()
+    for r in res:
+        for dt, x in cols.items():
+            fp = np.dtype(dt).kind == "f"
+            for name, op in ck.RED_NAMES.items():
+                want, got = oracle.reduce(op, x), r[dt][name]
+                if fp and name in ("sum", "avg", "var", "stddev"):
+                    scale = float(np.sum(np.abs(x.astype(np.float64)))) if name in ("sum", "avg") else float(np.sum(x.astype(np.float64) ** 2))
+                    tol = n * 2.0 ** -52 * scale / (n if name == "avg" else 1) + 1e-9
+                    if name in ("var", "stddev"):
+                        tol = max(tol, abs(float(want)) * 1e-9)
+                    assert abs(float(got) - float(want)) <= tol, (dt, name, got, want)
+                else:
+                    assert gu.scalar_same(got, want), (dt, name, got, want)
+        assert r["corr"] == oracle.corr(cols[np.int32], y)
+
+
+@pytest.mark.parametrize("world,empty,tiny", [(2, None, None), (3, 2, None), (4, None, 1), (5, 0, 3)])
+def test_scans_windows_and_shifts_over_row_range_shards_inside_the_library(oracle, world, empty, tiny):
+    """aqg_scan_sharded: every rank's rows of the scan of the WHOLE column -- sums / avgs resume from the exact totals of the earlier
+    shards, mins / maxs from their min / max, windows take the last w rows of the shards before (across a 3-row shard and an empty
+    one), shifts their neighbour rows; windows shorter and longer than the shards and than the column (aggregations.h:89-281,439-485)"""
+    import aquery2_amd
+    rng = np.random.default_rng(7 * world + (tiny or 0))
+    n = 60_013
+    sh = _cuts(n, world, rng, empty, tiny)
+    cases = []
+    for dt in (np.int32, np.int16, np.uint32, np.int64, np.float32, np.float64):
+        fp = np.dtype(dt).kind == "f"
+        x = np.round(rng.uniform(-1000, 1000, n), 3).astype(dt) if fp else rng.integers(1, 90, n).astype(dt)
+        ops = [("sums", 0), ("avgs", 0), ("mins", 0), ("maxs", 0), ("deltas", 0), ("prev", 0), ("aggnext", 0), ("ratiow", 1), ("ratiow", 7), ("ratiow", n + 5),
+               ("sumw", 3), ("avgw", 100), ("minw", 2), ("maxw", 50), ("minw", 20_000), ("maxw", 0), ("sumw", n + 10), ("minw", n + 1)]
+        if dt in (np.uint32,):
+            ops = [o for o in ops if o[0] != "avgw"]              # the reference wraps arr[i] - arr[i-w] for unsigned 4/8-byte inputs (DESIGN.md section 2)
+        cases.append((dt, x, ops))
+    neg = -np.abs(np.round(rng.uniform(1, 1000, n), 3)).astype(np.float64)    # all negative: the running max a window degrades to has no seed
+    cases.append((np.float64, neg, [("maxw", 0), ("maxs", 0)]))
+    tr = aquery2_amd.ThreadRanks(world)
+    def body(rank, dev, comm):
+        lo, hi = sh[rank]
+        out = []
+        for dt, x, ops in cases:
+            xs = dev.to_device(np.ascontiguousarray(x[lo:hi]))
+            out.append([comm.scan_sharded(ck.SCAN_NAMES[name], xs, w) for name, w in ops])
+        return out
+    try:
+        res = tr.run(body)
+    finally:
+        tr.close()
+    for ci, (dt, x, ops) in enumerate(cases):
+        fp = np.dtype(dt).kind == "f"
+        for oi, (name, w) in enumerate(ops):
+            want = oracle.scan(ck.SCAN_NAMES[name], x, w)
+            got = np.concatenate([res[r][ci][oi] for r in range(world)])
+            assert got.size == n
+            if name in ("mins", "maxs", "minw", "maxw", "deltas", "prev", "aggnext", "ratiow") or (not fp and name in ("sums", "sumw", "avgs")):
+                assert gu.same_bits(got, want), (dt, name, w)
+            else:
+                eps_in = float(np.finfo(dt).eps) if fp else 2.0 ** -52
+                bound = 4 * eps_in * float(np.max(np.abs(x.astype(np.float64)))) * (np.arange(n) + 2) + 1e-9
+                assert np.all(np.abs(got.astype(np.float64) - want.astype(np.float64)) <= bound), (dt, name, w)
+
+
 def test_rccl_transport_world_of_one(gpu_dev, oracle):
     """the RCCL path itself (librccl opened with dlopen, ncclGetUniqueId / ncclCommInitRank / ncclAllGather on the context's stream)
     with the only world a one-GPU box allows; the sharded call then equals the plain one"""
