@@ -46,6 +46,25 @@ def gather_group_tables(dist, cols, ngroups, gmax=None):
 #  gather_group_tables above remains the torch-level form the gloo tests drive with the oracle's kernels.)
 
 
+# ---- reductions and scans over row-range shards: the product path is the LIBRARY's (round 3) -----------------------------------
+# aqg_reduce_sharded / aqg_corr_sharded / aqg_scan_sharded (include/aqg.h, csrc/sharded.hip): one all-gather of moments / neighbours /
+# halos on the communicator, every fold in C++ -- a C++ host shards them without Python.  These are the thin callers; the functions
+# further down are the torch-level forms of the same exchanges that the CPU (gloo) tests drive and that feed halos by hand on one GPU.
+
+def reduce_sharded(comm, op, x_local):
+    """op over the whole column from this rank's rows (aquery2_amd.Comm.reduce_sharded -> aqg_reduce_sharded)"""
+    return comm.reduce_sharded(op, x_local)
+
+
+def corr_sharded(comm, x_local, y_local):
+    return comm.corr_sharded(x_local, y_local)
+
+
+def scan_sharded(comm, op, x_local, w=0):
+    """this rank's rows of the scan / window / shift over the whole column (aqg_scan_sharded)"""
+    return comm.scan_sharded(op, x_local, w)
+
+
 # ---- scans and windows over row-range shards (SURVEY 8e: "windows need a fixed halo") ---------------------------------------
 # A shard needs the last w - 1 rows of the shard before it (sliding windows), its last row (deltas / prev / ratios), or one
 # value folded over everything before it (running min / max).  `exchange_tails` is the one collective; the functions below
