@@ -41,6 +41,9 @@ struct aqg_ctx {
     bool evk_valid = false;
     bool evk_frozen = false;                     // the exchange's re-aggregation must not replace the row pass as "the dominant kernel"
     std::unordered_map<const void*, aqg_pin> pins;
+    std::vector<std::pair<void*, size_t>> fetch_regs;   // host ranges page-locked for egress in flight (aqg_col_fetch), released by aqg_col_fetch_wait
+    bool fetch_pending = false;
+    hipEvent_t ev_fetch = nullptr;
     uint32_t pin_chunks[3] = {0, 0, 0};          // chunks of the last aqg_col_pin upload: page-locked + DMA / staged through pinned buffers / plain pageable copy
     std::unordered_map<const void*, int> max_lds;   // largest dynamic LDS size already granted per kernel (aqg_allow_lds)
     // pinned host staging for small results

@@ -113,6 +113,8 @@ void aqg_ctx_destroy(aqg_ctx* ctx) {
     if (ctx->evk0) hipEventDestroy(ctx->evk0);
     if (ctx->evk1) hipEventDestroy(ctx->evk1);
     if (ctx->ev_flags) hipEventDestroy(ctx->ev_flags);
+    (void)aqg_col_fetch_wait(ctx);
+    if (ctx->ev_fetch) hipEventDestroy(ctx->ev_fetch);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -299,6 +301,63 @@ int aqg_col_pin(aqg_ctx* ctx, const void* host_ptr, size_t bytes, void** dptr) {
         hipStreamWaitEvent(ctx->stream, pin.ev, 0) != hipSuccess) { ctx->err = "aqg_col_pin: completion event"; return fail(AQG_ERR_HIP); }
     ctx->pins[host_ptr] = pin;
     *dptr = d;
+    return AQG_OK;
+}
+// Egress of a result column to caller-owned host memory (the write-back half of the ingest seam: TableInfo::monetdb_append_table,
+// reference server/table_ext_monetdb.hpp:34-87, hands the data source POINTERS to the result columns).  Asynchronous: ordered behind
+// everything queued on the context's stream (an event the copy stream waits for), the destination page-locked chunk by chunk under
+// the same rules as aqg_col_pin's source (one process-wide registry, foreign locks probed; such chunks take the runtime's pageable
+// path), DMA on the copy stream -- several columns' copies overlap each other and the tail kernels of the query.  aqg_col_fetch_wait
+// completes them and unlocks the pages.
+int aqg_col_fetch(aqg_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    if (!ctx || ((!dst_host || !src_dev) && bytes)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_col_fetch: bad argument");
+    if (!bytes) return AQG_OK;
+    if (!ctx->copy_stream) AQG_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->ev_fetch) AQG_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fetch, hipEventDisableTiming));
+    AQG_HIP(ctx, hipEventRecord(ctx->ev_fetch, ctx->stream));
+    AQG_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_fetch, 0));
+    constexpr size_t CHUNK = (size_t)256 << 20, PAGE = 4096;
+    for (size_t o = 0; o < bytes; o += CHUNK) {
+        const size_t c = bytes - o < CHUNK ? bytes - o : CHUNK;
+        char* dst = static_cast<char*>(dst_host) + o;
+        char* rb = reinterpret_cast<char*>(((uintptr_t)dst + PAGE - 1) & ~(uintptr_t)(PAGE - 1));
+        char* re = reinterpret_cast<char*>(((uintptr_t)dst + c) & ~(uintptr_t)(PAGE - 1));
+        const char* tb = reinterpret_cast<const char*>((uintptr_t)dst & ~(uintptr_t)(PAGE - 1));
+        const char* te = reinterpret_cast<const char*>(((uintptr_t)dst + c + PAGE - 1) & ~(uintptr_t)(PAGE - 1));
+        bool reg = false;
+        {
+            std::lock_guard<std::mutex> lock(g_reg_mu);
+            if (c >= ((size_t)1 << 20) && re > rb && !lib_registered(tb, te) && !foreign_registered(tb, te) &&
+                hipHostRegister(rb, (size_t)(re - rb), hipHostRegisterDefault) == hipSuccess) {
+                ctx->fetch_regs.emplace_back(rb, (size_t)(re - rb));
+                g_regs.push_back(RegRange{rb, (size_t)(re - rb)});
+                reg = true;
+            } else (void)hipGetLastError();
+        }
+        const char* src = static_cast<const char*>(src_dev) + o;
+        auto cp = [&](size_t off, size_t len) -> hipError_t { return len ? hipMemcpyAsync(dst + off, src + off, len, hipMemcpyDeviceToHost, ctx->copy_stream) : hipSuccess; };
+        // (page-locked body and pageable edges by separate calls, as in aqg_col_pin: the runtime classifies a copy by its start address)
+        if (reg) { AQG_HIP(ctx, cp(0, (size_t)(rb - dst))); AQG_HIP(ctx, cp((size_t)(rb - dst), (size_t)(re - rb))); AQG_HIP(ctx, cp((size_t)(re - dst), (size_t)(dst + c - re))); }
+        else AQG_HIP(ctx, cp(0, c));
+    }
+    ctx->fetch_pending = true;
+    return AQG_OK;
+}
+int aqg_col_fetch_wait(aqg_ctx* ctx) {
+    if (!ctx) return AQG_ERR_ARG;
+    if (!ctx->fetch_pending && ctx->fetch_regs.empty()) return AQG_OK;
+    hipError_t e = ctx->copy_stream ? hipStreamSynchronize(ctx->copy_stream) : hipSuccess;
+    {
+        std::lock_guard<std::mutex> lock(g_reg_mu);
+        for (auto& r : ctx->fetch_regs) {
+            (void)hipHostUnregister(r.first);
+            for (size_t i = 0; i < g_regs.size(); ++i) if (g_regs[i].b == static_cast<char*>(r.first)) { g_regs[i] = g_regs.back(); g_regs.pop_back(); break; }
+        }
+    }
+    ctx->fetch_regs.clear();
+    ctx->fetch_pending = false;
+    (void)hipGetLastError();
+    if (e != hipSuccess) { ctx->err = std::string("aqg_col_fetch_wait: ") + hipGetErrorString(e); return AQG_ERR_HIP; }
     return AQG_OK;
 }
 int aqg_col_pin_last(aqg_ctx* ctx, uint32_t* registered, uint32_t* staged, uint32_t* pageable) {

@@ -134,6 +134,7 @@ struct MiniSqlSource : DataSource {
         const size_t lp = s.find('('), rp = s.rfind(')');
         if (lp == std::string::npos || rp == std::string::npos) return fail("CREATE TABLE without a column list");
         auto head = split(trim(s.substr(0, lp)), ' ');
+        if (upper(s).find("IF NOT EXISTS") != std::string::npos && tables.count(head.back())) return;      // (monetdb_append_table creates its target this way)
         Table t;
         for (auto& def : split(s.substr(lp + 1, rp - lp - 1), ',')) {
             auto w = split(def, ' ');
@@ -206,6 +207,40 @@ struct MiniSqlSource : DataSource {
         }
         cnt = (long long)rows.size();
     }
+    // write-back of a result table (TableInfo::monetdb_append_table -> monetdbe_append in the reference, server/table_ext_monetdb.hpp:76):
+    // the rows are copied into the catalog, so that later statements of the message list SELECT them back
+    int append(const char* table, int ncols, const AppendColumn* cols) override {
+        auto it = tables.find(table);
+        if (it == tables.end()) { fail(std::string("append: unknown table ") + table); return -1; }
+        Table& t = it->second;
+        if ((int)t.cols.size() != ncols) { fail("append: column count"); return -1; }
+        for (int c = 0; c < ncols; ++c) {
+            Column& d = t.cols[(size_t)c];
+            const uint32_t n = cols[c].count;
+            auto as_double = [&](uint32_t i) -> double {
+                switch (cols[c].type) {
+                case types::AINT32: return static_cast<const int*>(cols[c].data)[i];
+                case types::AINT64: return (double)static_cast<const long long*>(cols[c].data)[i];
+                case types::AFLOAT: return static_cast<const float*>(cols[c].data)[i];
+                case types::ADOUBLE: return static_cast<const double*>(cols[c].data)[i];
+                case types::AINT16: return static_cast<const short*>(cols[c].data)[i];
+                case types::AINT8: return static_cast<const signed char*>(cols[c].data)[i];
+                case types::AUINT32: return static_cast<const unsigned*>(cols[c].data)[i];
+                default: return 0;
+                }
+            };
+            for (uint32_t i = 0; i < n; ++i) {
+                switch (d.type) {
+                case types::AINT32: d.i32.push_back((int)as_double(i)); break;
+                case types::AINT64: d.i64.push_back(cols[c].type == types::AINT64 ? static_cast<const long long*>(cols[c].data)[i] : (long long)as_double(i)); break;
+                case types::ADOUBLE: d.f64.push_back(as_double(i)); break;
+                case types::AFLOAT: d.f32.push_back((float)as_double(i)); break;
+                default: d.text.push_back(cols[c].type == types::ASTR ? static_cast<const char* const*>(cols[c].data)[i] : std::to_string(as_double(i))); break;
+                }
+            }
+        }
+        return 0;
+    }
     void print_results(const char* sep = " ", const char* end = "\n", uint32_t limit = std::numeric_limits<uint32_t>::max()) override {
         const size_t n = result.empty() ? 0 : result[0].size();
         for (size_t i = 0; i < n && i < limit; ++i) {
@@ -245,7 +280,12 @@ int main(int argc, char** argv) {
         if (msg.empty() || msg[0] == '#') continue;
         const double t0 = now_ms();
         switch (msg[0]) {
-        case 'Q': ds.exec(msg.c_str() + 1); cfg.stats.monet_time += (long long)((now_ms() - t0) * 1e6); break;
+        case 'Q':
+            ds.exec(msg.c_str() + 1);
+            // the previous result set is gone (its buffers may be reused): the module drops the device mirrors of its columns
+            if (auto changed = reinterpret_cast<void (*)(Context*)>(dlsym(handle, "__AQ_Result_Changed__"))) changed(cxt);
+            cfg.stats.monet_time += (long long)((now_ms() - t0) * 1e6);
+            break;
         case 'P':
             if (ds.haserror()) { std::fprintf(stderr, "[aquery_host] skipping %s: the data source is in its error state\n", msg.c_str()); rc |= 1; break; }
             if (auto fn = reinterpret_cast<code_snippet>(dlsym(handle, msg.c_str() + 1))) { rc |= fn(cxt); std::fflush(stdout); }

@@ -102,6 +102,12 @@ int aqg_col_pin(aqg_ctx* ctx, const void* host_ptr, size_t bytes, void** dptr);
  * (the chunk touches pages that are already page-locked -- by another column or context of this library, or by somebody else, which a
  * direct copy or a second registration must not touch: profiles/r3_hostregister_abort.md); plain pageable copy (short columns)       */
 int aqg_col_pin_last(aqg_ctx* ctx, uint32_t* registered_chunks, uint32_t* staged_chunks, uint32_t* pageable_chunks);
+/* Egress of a result column into caller-owned host memory (the write-back half of the seam: TableInfo::monetdb_append_table hands the
+ * data source pointers to the result columns, server/table_ext_monetdb.hpp:34-87): asynchronous, ordered behind everything queued on the
+ * context's stream, destination page-locked chunk by chunk + DMA on the copy stream; several columns overlap each other and the query's
+ * tail kernels.  aqg_col_fetch_wait: every fetch of this context is complete and its pages are unlocked.                            */
+int aqg_col_fetch(aqg_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int aqg_col_fetch_wait(aqg_ctx* ctx);
 int aqg_col_unpin(aqg_ctx* ctx, const void* host_ptr);
 int aqg_col_unpin_all(aqg_ctx* ctx);
 

@@ -418,6 +418,28 @@ public:
         // mutable host access follows: a RESULT's device copy cannot be trusted from here on
         if (!it->second.pinned && !it->second.gctx) { if (it->second.dptr) aqg_free(ctx_, it->second.dptr); map_.erase(it); }
     }
+    // write-back: the host copies of several RESULT columns at once -- asynchronous egress of all of them (aqg_col_fetch: page-locked
+    // destination, DMA on the copy stream, the copies overlap each other and the tail kernels still queued), ONE wait
+    void fetch_all(const std::vector<const void*>& ps) {
+        std::vector<std::map<uintptr_t, Entry>::iterator> pending;
+        for (const void* p : ps) {
+            if (!stale) break;
+            auto it = find(p);
+            if (it == map_.end() || !it->second.host_stale) continue;
+            if (it->second.deferred || (it->second.gctx && !it->second.dptr)) { touch(p); continue; }
+            int rc = aqg_col_fetch(ctx(), (void*)it->first, it->second.dptr, it->second.bytes);
+            if (rc != AQG_OK) die("aqg_col_fetch", rc, ctx_);
+            pending.push_back(it);
+        }
+        if (pending.empty()) return;
+        int rc = aqg_col_fetch_wait(ctx());
+        if (rc != AQG_OK) die("aqg_col_fetch_wait", rc, ctx_);
+        for (auto it : pending) {
+            it->second.host_stale = false;
+            --stale;
+            if (!it->second.pinned && !it->second.gctx) { if (it->second.dptr) aqg_free(ctx_, it->second.dptr); map_.erase(it); }
+        }
+    }
     // the host buffer at p is going away / being rewritten by the host
     void forget(const void* p) {
         auto it = map_.find((uintptr_t)p);

@@ -24,6 +24,9 @@ struct Config {
 };
 
 struct Context;
+// one column handed back to the data source by TableInfo::monetdb_append_table (the reference builds a monetdbe_column {type, data,
+// count, name} per column, server/table_ext_monetdb.hpp:88-116): `type` is the AQuery type tag, `data` a host array of `count` elements
+struct AppendColumn { const char* name; int type; const void* data; uint32_t count; };
 // the abstract data source generated code reads columns from: `server->cnt`, `server->getCol(i, type)`
 struct DataSource {
     void* server = nullptr;
@@ -41,6 +44,8 @@ struct DataSource {
     virtual void exec(const char* q) = 0;
     virtual void* getCol(int col_idx, int type) = 0;
     virtual void getDSTable(const char* name, void* tbl) = 0;
+    // write-back of a result table (monetdbe_append in the reference, server/table_ext_monetdb.hpp:76): 0 = stored
+    virtual int append(const char* table, int ncols, const AppendColumn* cols) { (void)table; (void)ncols; (void)cols; return -1; }
     virtual void close() = 0;
     virtual bool haserror() = 0;
     virtual void print_results(const char* = " ", const char* = "\n", uint32_t = std::numeric_limits<uint32_t>::max()) {}
@@ -86,3 +91,32 @@ struct Context {
 #define __DLLEXPORT__
 #define __AQEXPORT__(_Ty) extern "C" _Ty __DLLEXPORT__
 typedef int (*code_snippet)(void*);
+
+// ---- TableInfo::monetdb_append_table (declared in table.h) ----------------------------------------------------------------------------
+namespace aq {
+inline const char* sql_type_name(int t) {     // reference types::SQL_Type, server/types.h:77-78
+    static const char* names[] = {"INT", "REAL", "TEXT", "DOUBLE", "DOUBLE", "BIGINT", "HUGEINT", "SMALLINT", "DATE", "TIME", "TINYINT",
+                                  "INT", "BIGINT", "HUGEINT", "SMALLINT", "TINYINT", "BOOL", "HUGEINT", "TIMESTAMP", "CHAR", "TEXT", "NULL", "ERROR"};
+    return t >= 0 && t < (int)(sizeof names / sizeof names[0]) ? names[t] : "ERROR";
+}
+}
+template <class... Types>
+void TableInfo<Types...>::monetdb_append_table(void* srv, const char* alt_name) {
+    if (!alt_name) alt_name = this->name;
+    auto* ds = static_cast<DataSource*>(srv);
+    if (!ds || sizeof...(Types) == 0) { std::puts("Error! Empty table."); return; }
+    std::vector<const void*> ptrs;
+    std::apply([&](auto&... c) { (ptrs.push_back(c.container), ...); }, cols);
+    aq::dev::Runtime::get().fetch_all(ptrs);
+    std::string create = std::string("CREATE TABLE IF NOT EXISTS ") + alt_name + " (";
+    std::vector<AppendColumn> ac;
+    std::apply([&](auto&... c) {
+        ((create += std::string(c.name) + ' ' + aq::sql_type_name((int)types::Types<typename std::decay_t<decltype(c)>::value_t>::getType()) + ", ",
+          ac.push_back(AppendColumn{c.name, (int)types::Types<typename std::decay_t<decltype(c)>::value_t>::getType(), (const void*)c.container, c.size})), ...);
+    }, cols);
+    create.resize(create.size() - 2);
+    create += ")";
+    ds->exec(create.c_str());
+    if (ds->haserror()) { std::puts(ds->last_error ? ds->last_error : "Error! CREATE TABLE failed."); return; }
+    if (ds->append(alt_name, (int)ac.size(), ac.data()) != 0) std::puts("Error! The data source does not take appended tables.");
+}

@@ -276,6 +276,10 @@ struct TableInfo {
     TableInfo(const char* nm = "", const char** col_names = nullptr) : name(nm), n_cols(sizeof...(Types)) { init_names(col_names, std::index_sequence_for<Types...>{}); }
 
     template <size_t i = 0> auto& get_col() { return std::get<i>(cols); }
+    // write-back into the data source (reference server/table_ext_monetdb.hpp:34-87; emitted for INSERT INTO ... SELECT and SELECT ... INTO,
+    // engine/ast.py:507,1494): CREATE TABLE IF NOT EXISTS through the source's SQL door, then the columns by pointer.  Result columns still
+    // in HBM come down together: asynchronous egress of all of them, one wait (device.h fetch_all).  Defined in libaquery.h (needs DataSource).
+    void monetdb_append_table(void* srv, const char* alt_name = nullptr);
     TableInfo<Types...>* rename(const char* nm) { name = nm; return this; }
     uint32_t rows() const { return std::get<0>(cols).size; }
 

@@ -25,7 +25,7 @@ def run(module, dataset, *funcs, cwd=None):
 def test_emitted_modules_compile():
     """CPU: the generated-shape translation units compile and link against the new library"""
     build()
-    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "distinct_orderby.so", "funcs_udf.so", "mutate_reuse.so", "stats_factory.so", "string_keys.so", "group_scans.so", "host_main"):
+    for m in ("moving_avg.so", "stock.so", "groupby_q1.so", "aqhashtable_shape.so", "distinct_orderby.so", "funcs_udf.so", "mutate_reuse.so", "stats_factory.so", "string_keys.so", "group_scans.so", "writeback.so", "host_main"):
         assert os.path.exists(os.path.join(EM, "build", m))
 
 
@@ -401,3 +401,35 @@ def test_h2o_q9_corr_by_two_keys(tmp_path, oracle):
     want = r * r                  # pow(r, 2) as the compiler evaluates it (x * x: exactly rounded; libm's pow is not on every input)
     got = np.fromfile(tmp_path / "q9.out.2", np.float64)
     assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.gpu
+def test_write_back_into_the_data_source_and_select_it_back(tmp_path, oracle):
+    """SURVEY 8f-4, the write-back half: a generated module appends its result table to the data source (TableInfo::monetdb_append_table,
+    reference server/table_ext_monetdb.hpp:34-87 -> DataSource::append of the host shim) and later statements of the recorded message list
+    SELECT it back (tests/q4.a:20-26: INSERT INTO ticks2 SELECT ID, max(ratios(p)), min(ratios(p)) FROM ticks GROUP BY ID; SELECT ...).
+    The result columns come down through the asynchronous egress (aqg_col_fetch).  Expected rows: the oracle over the same CSV."""
+    import numpy as np
+    import checker as ck
+    build()
+    root = os.path.dirname(HERE)
+    subprocess.check_call(["make", "-C", os.path.join(root, "aquery2_amd", "host")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(root, "aquery2_amd", "aquery_host"), os.path.join(EM, "build", "writeback.so"), os.path.join(EM, "writeback.msgs"), "--root", root],
+                         capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr
+    t = np.loadtxt(os.path.join(HERE, "golden", "ticks.csv"), delimiter=",", skiprows=1, dtype=np.int64)
+    order = np.argsort(t[:, 1], kind="stable")
+    ids, price = t[order, 0].astype(np.int32), t[order, 2].astype(np.int32)
+    ogb = oracle.groupby([ids])
+    rows = ogb["row_ids"]
+    off = np.concatenate([[0], np.cumsum(ogb["counts"].astype(np.int64))])
+    want1 = []
+    for g in range(ogb["ngroups"]):
+        r = oracle.scan(ck.SCAN_RATIOW, price[rows[off[g]:off[g + 1]]], 1)
+        want1.append("%d %f %f" % (ids[ogb["first_rows"][g]], r.max(), r.min()))
+    gain = price - oracle.scan(ck.SCAN_MINS, price)
+    avg3 = oracle.scan(ck.SCAN_AVGW, price, 3)
+    want2 = ["%d %d %f" % (i, g, a) for i, g, a in zip(ids, gain, avg3)]
+    lines = [l for l in out.stdout.strip().splitlines() if l != "done."]
+    assert lines[:len(want1)] == want1, (lines[:6], want1[:6])
+    assert lines[len(want1):] == want2, (lines[len(want1):len(want1) + 4], want2[:4])
