@@ -384,24 +384,6 @@ int aqg_col_unpin_all(aqg_ctx* ctx) {
     return AQG_OK;
 }
 
-// astring_view keys (reference server/types.h:281-334: equality = the content of the NUL-terminated strings; hash = the string
-// view, server/hasher.h:97-106).  The strings live in host memory, so the dictionary is built on the host: codes[i] = dense id
-// of row i's string in FIRST-OCCURRENCE order, uploaded as a uint32 column the group-by / join entry points take as a key.
-int aqg_str_encode(aqg_ctx* ctx, const char* const* strs_host, uint32_t n, uint32_t* codes_dev, uint32_t* ndistinct_host) {
-    if (!ctx || (!strs_host && n) || (!codes_dev && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_str_encode: bad argument");
-    std::unordered_map<std::string_view, uint32_t> dict;
-    dict.reserve(1024);
-    std::vector<uint32_t> codes(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        const char* p = strs_host[i] ? strs_host[i] : "";
-        auto it = dict.try_emplace(std::string_view(p), (uint32_t)dict.size()).first;
-        codes[i] = it->second;
-    }
-    if (ndistinct_host) *ndistinct_host = (uint32_t)dict.size();
-    if (n) { AQG_HIP(ctx, hipMemcpyAsync(codes_dev, codes.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream)); AQG_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
-    return AQG_OK;
-}
-
 int aqg_timer_start(aqg_ctx* ctx) {
     if (!ctx) return AQG_ERR_ARG;
     AQG_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));

@@ -78,3 +78,59 @@ def test_floating_keys_without_special_values_take_the_bit_patterns(gpu, oracle)
     assert gb.ngroups == o["ngroups"] and np.array_equal(gb.first_rows(), o["first_rows"])
     assert np.array_equal(gb.keys(0, np.float64), k[o["first_rows"]])
     gb.destroy()
+
+
+def _pooled_strings(rng, n, npool, dup_every=7):
+    """n row pointers into a pool of short NUL-terminated strings; every `dup_every`-th pool entry repeats the CONTENT of another entry
+    behind its own pointer (astring_view keys compare content, server/types.h:281-334).  Returns (pointer array, expected codes)."""
+    import ctypes as C
+    contents = [b"sym%07d" % (i * 7919 % 10_000_019) if i % 3 else b"s%d" % i for i in range(npool)]
+    for i in range(dup_every, npool, dup_every):
+        contents[i] = contents[i - dup_every + 1]
+    bufs = [C.create_string_buffer(c) for c in contents]
+    addrs = np.array([C.addressof(b) for b in bufs], dtype=np.uint64)
+    canon = {}
+    cid = np.array([canon.setdefault(c, len(canon)) for c in contents], dtype=np.int64)
+    idx = rng.integers(0, npool, n)
+    ptrs = np.ascontiguousarray(addrs[idx])
+    cont = cid[idx]
+    _, first = np.unique(cont, return_index=True)
+    rank = np.empty(len(canon), np.int64); rank[:] = -1
+    rank[cont[np.sort(first)]] = np.arange(first.size)
+    return ptrs, rank[cont].astype(np.uint32), bufs
+
+
+@pytest.mark.parametrize("n,npool", [(70_000, 50), (3_000_000, 200_000)])
+def test_string_dictionary_built_on_the_device(gpu, n, npool):
+    """aqg_str_encode from 2^16 rows on: bytes + offsets uploaded once, hashed on the device, numbered by first occurrence through the
+    group-by build over {hash, length}, every row compared with its group's first row -- codes equal to content-equality ids"""
+    import ctypes as C
+    rng = np.random.default_rng(n)
+    ptrs, want, keep = _pooled_strings(rng, n, npool)
+    out = gpu.empty(n, np.uint32)
+    nd = C.c_uint32()
+    gpu._chk(gpu.lib.aqg_str_encode(gpu.ctx, C.c_void_p(ptrs.ctypes.data), C.c_uint32(n), C.c_void_p(out.ptr), C.byref(nd)), "aqg_str_encode")
+    got = out.to_host()
+    assert nd.value == int(want.max()) + 1
+    assert np.array_equal(got, want)
+
+
+def test_string_dictionary_host_and_device_paths_agree():
+    """the same column through the host map (AQG_STR_HOST=1) in a fresh process: identical codes"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, ctypes as C
+import numpy as np
+sys.path.insert(0, "tests")
+import aquery2_amd
+from test_gpu_keys import _pooled_strings
+gpu = aquery2_amd.Device(0)
+ptrs, want, keep = _pooled_strings(np.random.default_rng(1), 400_000, 3000)
+out = gpu.empty(400_000, np.uint32)
+gpu._chk(gpu.lib.aqg_str_encode(gpu.ctx, C.c_void_p(ptrs.ctypes.data), C.c_uint32(400_000), C.c_void_p(out.ptr), None), "aqg_str_encode")
+assert np.array_equal(out.to_host(), want)
+print("OK")
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, AQG_STR_HOST="1"), cwd=root)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
