@@ -242,6 +242,17 @@ class Comm:
             return gb
         return run, gb
 
+    def str_encode_sharded(self, strs):
+        """global dictionary codes of this rank's strings (list of bytes): aqg_str_encode_sharded; returns (DevBuf of uint32 codes, global distinct count)"""
+        d = self.dev
+        bufs = [C.create_string_buffer(b) for b in strs]
+        arr = (C.c_char_p * max(1, len(bufs)))(*[C.cast(b, C.c_char_p) for b in bufs])
+        out = d.empty(max(1, len(bufs)), np.uint32)
+        nd = C.c_uint32()
+        d._chk(d.lib.aqg_str_encode_sharded(self.h, arr, C.c_uint32(len(bufs)), C.c_void_p(out.ptr), C.byref(nd)), "aqg_str_encode_sharded")
+        out.n = len(bufs)
+        return out, nd.value
+
     def reduce_sharded(self, op, x):
         """aqg_reduce over a column sharded by row range (`x`: this rank's rows); the whole column's result on every rank"""
         d = self.dev

@@ -374,6 +374,34 @@ __global__ void __launch_bounds__(1024) xmerge_small_kernel(const uint64_t* __re
     if (threadIdx.x == 0) { sm.info[0] = G; sm.info[1] = s_bad; }
 }
 
+// Key columns that are not plain integers travel as the NORMALISED integer columns the local group-by made of them (groupby.hip
+// normalize_keys): date_t -> uint32, time_t -> uint64 (padding byte cleared), timestamp_t -> {uint32 date, uint64 time}, 128-bit integers
+// -> {low, high}.  The layout depends on the key dtypes alone, so every rank -- one whose local call failed too -- sizes the payload alike.
+// Floating keys (their NaN rows are numbered by LOCAL row) and strings (codes of a per-rank dictionary: aqg_str_encode_sharded makes global
+// ones) are not offered here.
+int norm_layout(int nkeys, const int* dts, int* ndt, int* first_of /* [nkeys] first normalised column of user key k */) {
+    int m = 0;
+    for (int k = 0; k < nkeys; ++k) {
+        if (first_of) first_of[k] = m;
+        const int dt = dts[k];
+        if (m + 2 > MAXKEYS + 1) return -1;
+        if (dt == AQG_DATE) ndt[m++] = AQG_UINT32;
+        else if (dt == AQG_TIME) ndt[m++] = AQG_UINT64;
+        else if (dt == AQG_TIMESTAMP) { ndt[m++] = AQG_UINT32; ndt[m++] = AQG_UINT64; }
+        else if (dt == AQG_INT128 || dt == AQG_UINT128) { ndt[m++] = AQG_UINT64; ndt[m++] = AQG_UINT64; }
+        else if (small_int(dt) || dt == AQG_INT64 || dt == AQG_UINT64) ndt[m++] = dt;
+        else return -1;
+        if (m > MAXKEYS) return -1;
+    }
+    return m;
+}
+__global__ void __launch_bounds__(256) denorm_timestamp_kernel(const uint32_t* __restrict__ date, const uint64_t* __restrict__ time, uint32_t G, uint32_t* __restrict__ out) {
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < G; g += gridDim.x * 256) { out[3 * (size_t)g] = date[g]; out[3 * (size_t)g + 1] = (uint32_t)time[g]; out[3 * (size_t)g + 2] = (uint32_t)(time[g] >> 32); }
+}
+__global__ void __launch_bounds__(256) denorm_i128_kernel(const uint64_t* __restrict__ lo, const uint64_t* __restrict__ hi, uint32_t G, uint64_t* __restrict__ out) {
+    for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < G; g += gridDim.x * 256) { out[2 * (size_t)g] = lo[g]; out[2 * (size_t)g + 1] = hi[g]; }
+}
+
 // every rank's return when some rank failed before the exchange (its own message stays on the rank that failed)
 int remote_failure(aqg_ctx* ctx, int status, bool mine = false) {
     if (!mine || ctx->err.empty()) ctx->err = status == AQG_ERR_OVERFLOW ? "sharded call: a rank's group table exceeded its capacity (gmax / table overflow)" :
@@ -681,14 +709,18 @@ int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, co
     int lrc = aqg_groupby_agg(ctx, nkeys, key_dtypes, keys, nparts, lops, ldts, lvals, n, max_groups_hint, &comm->local);
     if (!comm->local) { comm->local = new aqg_groupby(); comm->local->ctx = ctx; }
     aqg_groupby* L = comm->local;
-    if (lrc == AQG_OK && L->nuser) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: plain integer key columns only (dates / times / 128-bit / floating keys: single-GPU calls)");
+    // the key columns the exchange moves: the caller's, or their normalised integer forms (dates, times, timestamps, 128-bit integers)
+    int xdt[MAXKEYS + 2], first_of[MAXKEYS];
+    const int xk = norm_layout(nkeys, key_dtypes, xdt, first_of);
+    if (xk < 0) return aqg_fail(ctx, AQG_ERR_DTYPE, "aqg_groupby_agg_sharded: integer / date / time / timestamp / 128-bit key columns normalising to at most 8 integer columns (floating and string keys: see aqg.h)");
+    if (lrc == AQG_OK && L->nkeys != xk) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_groupby_agg_sharded: internal: the normalised key layout differs from the local call's");
     int pdt[MAXPART], mop[MAXPART], sres[MAXPART], shi[MAXPART];
     for (int p = 0; p < nparts; ++p) {
         int c = parts[p].col0;
         if (parts[p].wide) { pdt[c] = AQG_UINT64; mop[c] = AQG_RED_SUM; sres[c] = p; shi[c] = 0; ++c; }      // low halves
         pdt[c] = parts[p].part_dt; mop[c] = parts[p].merge_op; sres[c] = p; shi[c] = parts[p].wide;
     }
-    AQG_TRY(exchange_core(comm, L, nkeys, key_dtypes, ncols, pdt, mop, row_base, max_groups_hint, gmax, sres, shi, lrc));
+    AQG_TRY(exchange_core(comm, L, xk, xdt, ncols, pdt, mop, row_base, max_groups_hint, gmax, sres, shi, lrc));
     aqg_groupby* M = comm->merged;
     // ---- 5. the result handle: keys and global first rows of the merged table, every aggregate in its own result dtype --------------
     aqg_groupby* H = *out ? *out : new aqg_groupby();
@@ -697,10 +729,18 @@ int aqg_groupby_agg_sharded(aqg_comm* comm, int nkeys, const int* key_dtypes, co
     const size_t GG = M->ngroups ? M->ngroups : 1;
     auto grow_h = [&](void** p, size_t* cap, size_t need) -> int { return grow(ctx, p, cap, need); };
     int rc = AQG_OK;
+    H->nuser = 0;
     for (int k = 0; k < nkeys && rc == AQG_OK; ++k) {
-        H->key_dt[k] = key_dtypes[k];
-        rc = grow_h(&H->keys_out[k], &H->cap_keys[k], GG * 8);
-        if (rc == AQG_OK && M->ngroups) rc = hipMemcpyAsync(H->keys_out[k], M->keys_out[k], (size_t)M->ngroups * aqg_dtype_size(key_dtypes[k]), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? AQG_OK : AQG_ERR_HIP;
+        const int dt = key_dtypes[k], m0 = first_of[k];
+        const size_t esz = dt == AQG_DATE ? 4 : dt == AQG_TIME ? 8 : dt == AQG_TIMESTAMP ? 12 : aqg_dtype_size(dt);
+        H->key_dt[k] = dt;
+        H->key_esz[k] = (int)esz;                              // (aqg_groupby_keys copies elements of this size: the merged keys in the CALLER's types)
+        rc = grow_h(&H->keys_out[k], &H->cap_keys[k], GG * 16);
+        if (rc != AQG_OK || !M->ngroups) continue;
+        const unsigned grid = aqg_grid(ctx, M->ngroups, 256, 1, 8);
+        if (dt == AQG_TIMESTAMP) hipLaunchKernelGGL(denorm_timestamp_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint32_t*)M->keys_out[m0], (const uint64_t*)M->keys_out[m0 + 1], M->ngroups, (uint32_t*)H->keys_out[k]);
+        else if (dt == AQG_INT128 || dt == AQG_UINT128) hipLaunchKernelGGL(denorm_i128_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const uint64_t*)M->keys_out[m0], (const uint64_t*)M->keys_out[m0 + 1], M->ngroups, (uint64_t*)H->keys_out[k]);
+        else rc = hipMemcpyAsync(H->keys_out[k], M->keys_out[m0], (size_t)M->ngroups * esz, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? AQG_OK : AQG_ERR_HIP;
     }
     if (rc == AQG_OK) rc = grow_h(reinterpret_cast<void**>(&H->first_rows64), &H->cap_first64, GG * 8);
     if (rc == AQG_OK && M->ngroups) rc = hipMemcpyAsync(H->first_rows64, comm->mres[0], (size_t)M->ngroups * 8, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess ? AQG_OK : AQG_ERR_HIP;

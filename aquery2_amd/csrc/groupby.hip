@@ -1729,7 +1729,8 @@ int aqg_groupby_keys(aqg_groupby* g, int k, void* out_dev) {
         return aqg_check_launch(ctx, "key_fetch_kernel");
     }
     const int kk = g->nuser ? g->user_norm[k] : k;
-    AQG_HIP(ctx, hipMemcpyAsync(out_dev, g->keys_out[kk], (size_t)g->ngroups * aqg_dtype_size(g->key_dt[kk]), hipMemcpyDeviceToDevice, ctx->stream));
+    const size_t kesz = g->sharded && g->key_esz[kk] ? (size_t)g->key_esz[kk] : aqg_dtype_size(g->key_dt[kk]);
+    AQG_HIP(ctx, hipMemcpyAsync(out_dev, g->keys_out[kk], (size_t)g->ngroups * kesz, hipMemcpyDeviceToDevice, ctx->stream));
     return AQG_OK;
 }
 

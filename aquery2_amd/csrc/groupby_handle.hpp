@@ -11,6 +11,7 @@ struct aqg_groupby {
     uint32_t n = 0, ngroups = 0;
     int nkeys = 0;
     int key_dt[MAXKEYS] = {0};
+    int key_esz[MAXKEYS] = {0};                 // bytes per key element when it is not aqg_dtype_size(key_dt) (merged tables of typed keys: dates 4, times 8, timestamps 12)
     bool has_counts = false, has_reversemap = false;
     // device buffers owned by the handle (grow-only)
     void* keys_out[MAXKEYS] = {nullptr};

@@ -18,14 +18,16 @@
 
 namespace {
 
-int encode_on_host(aqg_ctx* ctx, const char* const* strs_host, uint32_t n, uint32_t* codes_dev, uint32_t* ndistinct_host) {
+int encode_on_host(aqg_ctx* ctx, const char* const* strs_host, uint32_t n, uint32_t* codes_dev, uint32_t* ndistinct_host, std::vector<uint32_t>* first_rows = nullptr) {
     std::unordered_map<std::string_view, uint32_t> dict;
     dict.reserve(1024);
     std::vector<uint32_t> codes(n);
+    if (first_rows) first_rows->clear();
     for (uint32_t i = 0; i < n; ++i) {
         const char* p = strs_host[i] ? strs_host[i] : "";
-        auto it = dict.try_emplace(std::string_view(p), (uint32_t)dict.size()).first;
-        codes[i] = it->second;
+        auto ins = dict.try_emplace(std::string_view(p), (uint32_t)dict.size());
+        if (ins.second && first_rows) first_rows->push_back(i);
+        codes[i] = ins.first->second;
     }
     if (ndistinct_host) *ndistinct_host = (uint32_t)dict.size();
     if (n) { AQG_HIP(ctx, hipMemcpyAsync(codes_dev, codes.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream)); AQG_HIP(ctx, hipStreamSynchronize(ctx->stream)); }
@@ -64,13 +66,84 @@ __global__ void __launch_bounds__(256) str_verify_kernel(const unsigned char* __
     if (bad) atomicAdd(mismatches, 1u);
 }
 
+__global__ void __launch_bounds__(256) remap_codes_kernel(uint32_t* __restrict__ codes, uint32_t n, const uint32_t* __restrict__ remap) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) codes[i] = remap[codes[i]];
+}
+int str_encode_impl(aqg_ctx* ctx, const char* const* strs_host, uint32_t n, uint32_t* codes_dev, uint32_t* ndistinct_host, std::vector<uint32_t>* first_rows);
+
 } // namespace
 
 extern "C" int aqg_str_encode(aqg_ctx* ctx, const char* const* strs_host, uint32_t n, uint32_t* codes_dev, uint32_t* ndistinct_host) {
+    return str_encode_impl(ctx, strs_host, n, codes_dev, ndistinct_host, nullptr);
+}
+
+// astring_view keys of a table sharded by ROW RANGE: codes of ONE dictionary over all shards, in GLOBAL first-occurrence order (shards
+// are contiguous row ranges in rank order, so walking the ranks' dictionaries in rank order, each in its own first-occurrence order, is
+// the global first occurrence) -- the uint32 key column aqg_groupby_agg_sharded takes.  Every rank encodes its rows (aqg_str_encode), the
+// ranks all-gather their dictionaries' strings (sizes first, then the padded bytes: two small collectives), build the merged dictionary on
+// the host and remap their code columns on the device.
+extern "C" int aqg_str_encode_sharded(aqg_comm* comm, const char* const* strs_host, uint32_t n, uint32_t* codes_dev, uint32_t* ndistinct_global_host) {
+    aqg_ctx* ctx = aqg_comm_ctx(comm);
+    if (!comm || (!strs_host && n) || (!codes_dev && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_str_encode_sharded: bad argument");
+    const int world = aqg_comm_world(comm), rank = aqg_comm_rank(comm);
+    std::vector<uint32_t> first;
+    uint32_t nd = 0;
+    int lrc = str_encode_impl(ctx, strs_host, n, codes_dev, &nd, &first);
+    // ---- this rank's dictionary: {count, bytes} then the strings, NUL-separated ------------------------------------------------------
+    std::vector<unsigned char> mine;
+    if (lrc == AQG_OK) for (uint32_t c = 0; c < nd; ++c) { const char* p = strs_host[first[c]] ? strs_host[first[c]] : ""; mine.insert(mine.end(), p, p + strlen(p) + 1); }
+    uint64_t hdr[4] = {(uint64_t)(uint32_t)lrc, nd, mine.size(), 0};
+    void *send, *recv;
+    AQG_TRY(aqg_comm_scratch(comm, 32, (size_t)32 * world, &send, &recv));
+    AQG_TRY(aqg_h2d(ctx, send, hdr, 32));
+    AQG_TRY(aqg_comm_allgather_internal(comm, send, recv, 32));
+    std::vector<uint64_t> all((size_t)4 * world);
+    AQG_TRY(aqg_d2h(ctx, all.data(), recv, (size_t)32 * world));
+    size_t maxb = 8;
+    for (int r = 0; r < world; ++r) {
+        if ((uint32_t)all[4 * r]) { if (r != rank || ctx->err.empty()) ctx->err = "sharded call: a rank failed before the exchange"; return (int)(uint32_t)all[4 * r]; }
+        maxb = all[4 * r + 2] > maxb ? all[4 * r + 2] : maxb;
+    }
+    maxb = (maxb + 7) & ~(size_t)7;
+    AQG_TRY(aqg_comm_scratch(comm, maxb, maxb * world, &send, &recv));
+    if (!mine.empty()) AQG_TRY(aqg_h2d(ctx, send, mine.data(), mine.size()));
+    AQG_TRY(aqg_comm_allgather_internal(comm, send, recv, maxb));
+    std::vector<unsigned char> dicts(maxb * world);
+    AQG_TRY(aqg_d2h(ctx, dicts.data(), recv, maxb * world));
+    // ---- the merged dictionary, rank order ------------------------------------------------------------------------------------------------
+    std::unordered_map<std::string_view, uint32_t> global;
+    std::vector<uint32_t> remap(nd ? nd : 1);
+    for (int r = 0; r < world; ++r) {
+        const char* p = reinterpret_cast<const char*>(dicts.data() + (size_t)r * maxb);
+        for (uint64_t c = 0; c < all[4 * r + 1]; ++c) {
+            const std::string_view sv(p);
+            const uint32_t id = global.try_emplace(sv, (uint32_t)global.size()).first->second;
+            if (r == rank) remap[c] = id;
+            p += sv.size() + 1;
+        }
+    }
+    if (ndistinct_global_host) *ndistinct_global_host = (uint32_t)global.size();
+    if (n) {
+        void* dremap = nullptr;
+        AQG_TRY(aqg_malloc(ctx, (size_t)(nd ? nd : 1) * 4, &dremap));
+        int rc = aqg_h2d(ctx, dremap, remap.data(), (size_t)nd * 4);
+        if (rc == AQG_OK) {
+            hipLaunchKernelGGL(remap_codes_kernel, dim3(aqg_grid(ctx, n, 256, 4, 16)), dim3(256), 0, ctx->stream, codes_dev, n, static_cast<const uint32_t*>(dremap));
+            rc = aqg_check_launch(ctx, "remap_codes_kernel");
+        }
+        if (rc == AQG_OK) rc = aqg_sync(ctx);
+        aqg_free(ctx, dremap);
+        AQG_TRY(rc);
+    }
+    return AQG_OK;
+}
+
+namespace {
+int str_encode_impl(aqg_ctx* ctx, const char* const* strs_host, uint32_t n, uint32_t* codes_dev, uint32_t* ndistinct_host, std::vector<uint32_t>* first_rows) {
     if (!ctx || (!strs_host && n) || (!codes_dev && n)) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_str_encode: bad argument");
     static const bool host_only = getenv("AQG_STR_HOST") != nullptr;          // A/B measurements only
     static const uint32_t dev_min = getenv("AQG_STR_DEVICE_MIN") ? (uint32_t)atoi(getenv("AQG_STR_DEVICE_MIN")) : (1u << 16);
-    if (host_only || n < dev_min) return encode_on_host(ctx, strs_host, n, codes_dev, ndistinct_host);
+    if (host_only || n < dev_min) return encode_on_host(ctx, strs_host, n, codes_dev, ndistinct_host, first_rows);
     // ---- host: one walk over the strings, in parallel: lengths, offsets, bytes ---------------------------------------------------
     unsigned nt = std::thread::hardware_concurrency();
     nt = nt < 1 ? 1 : nt > 16 ? 16 : nt;
@@ -135,12 +208,14 @@ extern "C" int aqg_str_encode(aqg_ctx* ctx, const char* const* strs_host, uint32
         }
         if (rc == AQG_OK) rc = aqg_d2h(ctx, &mism, dmis, 4);
         if (rc == AQG_OK && !mism) rc = aqg_d2d(ctx, codes_dev, aqg_groupby_reversemap(g), (size_t)n * 4);
+        if (rc == AQG_OK && !mism && first_rows) { first_rows->resize(G); rc = aqg_d2h(ctx, first_rows->data(), aqg_groupby_first_rows(g), (size_t)G * 4); }
         if (rc == AQG_OK) rc = aqg_sync(ctx);
     }
     if (g) aqg_groupby_destroy(g);
     for (void* p : {dbytes, doff, dh, dlen, dmis}) if (p) aqg_free(ctx, p);
     if (rc != AQG_OK) return rc;
-    if (mism) return encode_on_host(ctx, strs_host, n, codes_dev, ndistinct_host);      // different strings under one 64-bit hash and length
+    if (mism) return encode_on_host(ctx, strs_host, n, codes_dev, ndistinct_host, first_rows);      // different strings under one 64-bit hash and length
     if (ndistinct_host) *ndistinct_host = G;
     return AQG_OK;
 }
+} // namespace

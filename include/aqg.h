@@ -211,6 +211,11 @@ int aqg_groupby_postproc(aqg_groupby* g, uint32_t* offsets_dev, uint32_t* row_id
  * must still be alive).  `const char*` keys are pointers in the reference (8-byte integers: pass AQG_UINT64); astring_view keys
  * compare string contents: aqg_str_encode turns the host strings into a uint32 code column (dense ids in first-occurrence order).  */
 int aqg_str_encode(aqg_ctx* ctx, const char* const* strs_host, uint32_t n, uint32_t* codes_dev, uint32_t* ndistinct_host);
+/* the same over a table sharded by row range (aqg_comm_* below): codes of ONE dictionary over all shards in GLOBAL first-occurrence order,
+ * the uint32 key column aqg_groupby_agg_sharded takes -- every rank encodes its rows, the ranks all-gather their dictionaries' strings
+ * (two small collectives), merge them in rank order and remap their code columns on the device                                        */
+struct aqg_comm;
+int aqg_str_encode_sharded(struct aqg_comm* comm, const char* const* strs_host, uint32_t n, uint32_t* codes_dev, uint32_t* ndistinct_global_host);
 
 /* one aggregate over all groups in ONE pass over the value column: the device
  * form of the generated per-group loop `out[g] = op(col[vecs[g]])`

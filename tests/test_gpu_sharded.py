@@ -278,6 +278,67 @@ def test_scans_windows_and_shifts_over_row_range_shards_inside_the_library(oracl
                 assert np.all(np.abs(got.astype(np.float64) - want.astype(np.float64)) <= bound), (dt, name, w)
 
 
+def test_typed_and_string_keys_over_row_range_shards(oracle):
+    """aqg_groupby_agg_sharded over key columns that are not plain integers (server/hasher.h:97-144): dates, times, timestamps and 128-bit
+    integers travel as their normalised integer columns and come back in the caller's types; astring_view keys as codes of ONE dictionary
+    merged over the shards in global first-occurrence order (aqg_str_encode_sharded).  Against the oracle's typed group-by of the whole table."""
+    import aquery2_amd
+    import keycases
+    rng = np.random.default_rng(77)
+    n, world = 30_011, 3
+    dates = np.zeros((n, 4), np.uint8); dates[:, 0] = rng.integers(1, 29, n); dates[:, 1] = rng.integers(1, 4, n); dates[:, 2:] = np.array([2022], np.int16).view(np.uint8)
+    times = np.zeros((n, 8), np.uint8); times[:, 4] = rng.integers(0, 3, n); times[:, 5] = rng.integers(0, 5, n); times[:, 7] = rng.integers(0, 255, n)   # (byte 7 is padding: ignored)
+    stamps = np.concatenate([dates, times], axis=1)[:, :12].copy()
+    big = np.zeros(n, ck.I128); big["lo"] = rng.integers(0, 50, n).astype(np.uint64) << np.uint64(60); big["hi"] = rng.integers(-2, 3, n)
+    plain = rng.integers(0, 4, n).astype(np.int16)
+    strs = [b"sym%d" % v for v in rng.integers(0, 300, n)]
+    v = rng.integers(-50, 50, n).astype(np.int32)
+    cuts = [0, 9_000, 9_003, n]
+    cases = {"date": [(ck.DATE, dates)], "time+plain": [(ck.TIME, times), (ck.INT16, plain)], "timestamp": [(ck.TIMESTAMP, stamps)], "int128": [(ck.INT128, big), (ck.DATE, dates)]}
+    tr = aquery2_amd.ThreadRanks(world)
+    def body(rank, dev, comm):
+        lo, hi = cuts[rank], cuts[rank + 1]
+        out = {}
+        vd = dev.to_device(np.ascontiguousarray(v[lo:hi]))
+        for name, cols in cases.items():
+            kd = [dev.key_col(tag, np.ascontiguousarray(data[lo:hi])) if tag in (ck.DATE, ck.TIME, ck.TIMESTAMP) else dev.to_device(np.ascontiguousarray(data[lo:hi])) for tag, data in cols]
+            gb = comm.groupby_agg_sharded(kd, [ck.RED_SUM, ck.RED_COUNT], [vd, vd], row_base=lo, hint=0)
+            eb = [ck.KEY_ELEM_BYTES.get(tag, np.asarray(data).dtype.itemsize) for tag, data in cols]
+            out[name] = (gb.ngroups, gb.first_rows64(), [gb.keys_raw(k, e) for k, e in enumerate(eb)], gb.result(0, ck.RED_SUM, ck.INT32))
+            gb.destroy()
+        codes, nd = comm.str_encode_sharded(strs[lo:hi])
+        gb = comm.groupby_agg_sharded([codes], [ck.RED_SUM], [vd], row_base=lo, hint=0)
+        out["str"] = (nd, codes.to_host(), gb.ngroups, gb.first_rows64(), gb.result(0, ck.RED_SUM, ck.INT32))
+        gb.destroy()
+        return out
+    try:
+        res = tr.run(body)
+    finally:
+        tr.close()
+    for name, cols in cases.items():
+        o = oracle.groupby_typed(cols)
+        want_sum = np.bincount(o["reversemap"].astype(np.int64), weights=v.astype(np.float64), minlength=o["ngroups"]).astype(np.int64)
+        for r in res:
+            G, first, keys, sums = r[name]
+            assert G == o["ngroups"], name
+            assert np.array_equal(first, o["first_rows"].astype(np.int64)), name
+            assert ck.i128_to_int(sums) == want_sum.tolist(), name
+            for k, (tag, data) in enumerate(cols):
+                host = np.ascontiguousarray(data).reshape(n, -1).view(np.uint8).reshape(n, -1)
+                want = host[o["first_rows"]].copy()
+                if tag == ck.TIME: want[:, 7] = 0                     # the padding byte comes back cleared
+                if tag == ck.TIMESTAMP: want[:, 11] = 0
+                assert np.array_equal(keys[k], want), (name, k)
+    o = oracle.groupby_typed([(ck.STR, strs)])
+    want_sum = np.bincount(o["reversemap"].astype(np.int64), weights=v.astype(np.float64), minlength=o["ngroups"]).astype(np.int64)
+    allcodes = np.concatenate([r["str"][1] for r in res])
+    assert np.array_equal(allcodes, o["reversemap"])                 # global first-occurrence ids, the reference's
+    for r in res:
+        nd, _, G, first, sums = r["str"]
+        assert nd == o["ngroups"] == G
+        assert np.array_equal(first, o["first_rows"].astype(np.int64)) and ck.i128_to_int(sums) == want_sum.tolist()
+
+
 def test_rccl_transport_world_of_one(gpu_dev, oracle):
     """the RCCL path itself (librccl opened with dlopen, ncclGetUniqueId / ncclCommInitRank / ncclAllGather on the context's stream)
     with the only world a one-GPU box allows; the sharded call then equals the plain one"""
