@@ -1117,8 +1117,17 @@ int make_plan(aqg_ctx* ctx, int naggs, const int* ops, const int* dts, const voi
 struct DenseOut { bool used; DenseSpec spec; };
 constexpr int AQG_ERR_RANGE_MISS = -1001;            // internal: sampled key ranges missed a value; run_with_retry repeats the attempt      // tells aqg_groupby_build that the table is the direct-indexed one
 
-int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
+int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
             GTable* gt_out, uint32_t** slot_gid_out, uint32_t** occ_out = nullptr, DenseOut* dense_out = nullptr) {
+    // more than ~1.6e7 groups expected out of a partition plan: the records are ORDERED (aqg_sorted_tail) instead of ranked through a
+    // bitmap over the rows and gathered (h2o Q10, 1e9 groups: that tail took 219 of 317 ms and fetched 900 GB)
+    static const uint32_t sorted_min = getenv("AQG_SORTED_TAIL_MIN") ? (uint32_t)atoi(getenv("AQG_SORTED_TAIL_MIN")) : (1u << 24);
+    // A BUILD above the LDS tables takes the partition plans too (partition1.hip: the group table with counts, then one more pass over the
+    // partitioned rows for the id of every row) instead of inserting every row into an HBM table and looking every row up again
+    static const bool build_part_off = getenv("AQG_DISABLE_BUILD_PARTITION") != nullptr;     // A/B measurements only
+    const bool build_part = for_build && !build_part_off && !ks.wide && n >= (1u << 20) && hint > 3072 && hint <= (1u << 25) && hint < sorted_min;
+    Plan plan = plan_in;
+    if (build_part) plan.need_count = 1;          // the group sizes come out of the partition aggregation
     const AccSpec& as = plan.as;
     const bool k32 = ks.nkeys == 1 && ks.total_bytes == 4;
     uint32_t gcap = next_pow2((uint64_t)(hint < 512 ? 512 : hint) * 2);
@@ -1185,7 +1194,11 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     // (partition.hip: h2o Q5, 1e9 rows, 1e7 groups: 42 ms against 141 ms); the build path keeps the HBM table because
     // its second pass looks keys up in it.  AQG_DISABLE_PARTITION=1 forces the HBM table (A/B measurements only).
     static const bool part_off = getenv("AQG_DISABLE_PARTITION") != nullptr;
-    const bool use_part = !part_off && !dense && !use_lds && !ks.wide && !for_build && n >= (1u << 20) && hint <= (1u << 25);
+    bool use_part = !part_off && !dense && !use_lds && !ks.wide && (!for_build || build_part) && n >= (1u << 20) && hint <= (1u << 25);
+    if (use_part && for_build) {                  // (the build's id pass knows the one- and two-level plans only)
+        const uint32_t bp = aqg_partition_parts(ks.total_bytes <= 4 ? 4 : 8, as, plan.need_count, hint);
+        if (!bp || bp > AQG_P2_MAXPARTS) use_part = false;
+    }
     uint32_t part_lcap = 0, pbits = 0;
     if (use_part) {
         // LDS table of one partition: as many slots as fit the budget (the slot of a hash is a multiply-shift, so the
@@ -1204,7 +1217,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     }
     // partition1.hip: ONE level up to ~1000 partitions (every plane moves once), two levels of <= 64 bins up to 4096 (the runs a
     // tile writes stay a kilobyte long); beyond that the round-1 pipeline of partition.hip
-    static const bool p1_off = getenv("AQG_DISABLE_P1") != nullptr;          // A/B measurements only
+    static const bool p1_off_env = getenv("AQG_DISABLE_P1") != nullptr;      // A/B measurements only
+    const bool p1_off = p1_off_env && !for_build;
     static const uint32_t p1_max = getenv("AQG_P1_MAX") ? (uint32_t)atoi(getenv("AQG_P1_MAX")) : 1024u;
     const uint32_t parts = use_part && !p1_off ? aqg_partition_parts(ks.total_bytes <= 4 ? 4 : 8, as, plan.need_count, hint) : 0;
     const uint32_t p1_bins = parts && parts <= p1_max && parts <= AQG_P1_MAXBINS ? parts : 0;
@@ -1214,10 +1228,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
                            !h->no_wide_part && aqg_partitionw_applies(ks, as, n, hint);
     if (use_wpart) gcap = (uint32_t)((uint64_t)hint + hint / 4 + 4096 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : (uint64_t)hint + hint / 4 + 4096);
 
-    // more than ~1.6e7 groups expected out of a partition plan: the records are ORDERED (aqg_sorted_tail) instead of ranked through a
-    // bitmap over the rows and gathered (h2o Q10, 1e9 groups: that tail took 219 of 317 ms and fetched 900 GB)
-    static const uint32_t sorted_min = getenv("AQG_SORTED_TAIL_MIN") ? (uint32_t)atoi(getenv("AQG_SORTED_TAIL_MIN")) : (1u << 24);
-    const bool sorted_tail = (use_part || use_wpart) && hint >= sorted_min && aqg_sorted_tail_plan(n, as.nacc, ks.wide != 0, nullptr);
+    const bool sorted_tail = (use_part || use_wpart) && !for_build && hint >= sorted_min && aqg_sorted_tail_plan(n, as.nacc, ks.wide != 0, nullptr);
     // ---- workspace ----------------------------------------------------------------------------
     size_t slots = (size_t)gcap + 1;
     uint32_t stride = 16;
@@ -1241,6 +1252,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     memset(&gt, 0, sizeof gt);
     gt.cap = gcap;
     gt.has_count = plan.need_count;
+    PartRows prows;
+    memset(&prows, 0, sizeof prows);
     uint32_t *occ, *gid_of_occ, *slot_gid, *bitmap = nullptr, *word_prefix = nullptr, *tile_total = nullptr;
     {
         unsigned char* base = nullptr;
@@ -1341,10 +1354,11 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         AQG_TRY(aqg_dense_aggregate(ctx, ks, dspec, as, n, plan.need_count, gt));
     } else if (n && (use_wpart || use_part)) {
         const size_t mark = ctx->ws_off;
+        memset(&prows, 0, sizeof prows);
         h->plan_bits = (use_wpart ? AQG_PLAN_PART_WIDE : p1_bins ? AQG_PLAN_PART_ONE : p2_parts ? AQG_PLAN_PART_TWO : AQG_PLAN_PART_ROUND1) | (sorted_tail ? AQG_PLAN_SORTED_TAIL : 0u);
         if (use_wpart) AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed, hint));
-        else if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap));
-        else if (p2_parts) AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap));
+        else if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap, for_build ? &prows : nullptr));
+        else if (p2_parts) AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap, for_build ? &prows : nullptr));
         else AQG_TRY(aqg_partition_aggregate(ctx, ks, as, n, pbits, part_lcap, plan.need_count, gt, gcap));
         if (sorted_tail) ctx->ws_off = mark;       // stream order: whatever is allocated there next is written after these kernels
         else hipLaunchKernelGGL(occ_iota_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, occ, (uint32_t)slots);
@@ -1475,7 +1489,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
     AQG_TRY(dev_realloc(ctx, (void**)&h->first_rows, &h->cap_first, gcapn * 4));
     AQG_TRY(dev_realloc(ctx, (void**)&h->counts, &h->cap_counts, gcapn * 4));
     es.first_out = h->first_rows;
-    h->has_counts = plan.need_count && !for_build;
+    h->has_counts = plan.need_count && (!for_build || (use_part && n));
     es.count_out = h->has_counts ? h->counts : nullptr;
     es.nagg = plan.nagg;
     h->nagg = plan.nagg;
@@ -1507,6 +1521,15 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n, uint3
         memcpy(fl, pinned_flags, 16);
         AQG_TRY(judge_flags());
         ctx->tail_in_flight = true;
+    }
+    h->build_assigned = false;
+    if (for_build && use_part && n && G && prows.valid) {       // the id of every row from the rows still lying partitioned in the workspace
+        size_t c = h->reversemap ? h->cap_rows * 4 : 0;
+        AQG_TRY(dev_realloc(ctx, (void**)&h->reversemap, &c, ((size_t)n + 4) * 4));
+        h->cap_rows = c / 4;
+        AQG_TRY(aqg_partition_assign(ctx, prows, gt, slot_gid, h->reversemap));
+        h->build_assigned = true;
+        h->plan_bits |= AQG_PLAN_BUILD_PARTITIONED;
     }
     h->ngroups = G;
     if (gt_out) *gt_out = gt;
@@ -1890,7 +1913,7 @@ int aqg_groupby_build(aqg_ctx* ctx, int nkeys, const int* key_dtypes, const void
     }
     if (rc != AQG_OK) { if (!*out) aqg_groupby_destroy(h); return rc; }
     uint32_t G = h->ngroups;
-    if (n) {
+    if (n && !h->build_assigned) {
         hipMemsetAsync(h->counts, 0, (size_t)(G ? G : 1) * 4, ctx->stream);
         unsigned grid = aqg_grid(ctx, n / 4 + 1, 256, 2, 8);
         if (dn.used) {                      // direct-indexed table: the dense id of a row is slot_gid[idx(row)]
@@ -1941,6 +1964,15 @@ __global__ void __launch_bounds__(256) take_rows_kernel(const uint64_t* __restri
 // of the flat layout -- segscan.hip) through the ordinary group-by plans; ids appear in first-occurrence order, so group g is result g
 int aqg_grouped_reduce_keyed(aqg_ctx* ctx, aqg_groupby* g, const uint32_t* gid_col, int op, int t, const void* x, void* out_dev) {
     const uint32_t G = g->ngroups, n = g->n;
+    // beyond the LDS tables: the build's ids are dense and its group sizes known -- partitioned on the id, direct-indexed (partition1.hip)
+    static const bool gid_off = getenv("AQG_DISABLE_GID_REDUCE") != nullptr;       // A/B measurements only
+    if (!gid_off && gid_col == g->reversemap && g->has_counts && G > (3u << 20) && n >= (1u << 22)) {       // (up to ~3e6 groups the one-level hashed plan is as fast: 8.0-8.4 ms against 9.0 per 1e9 rows; 1e7 groups: 17 against 9)
+        const uint32_t* off = aqg_groupby_offsets(g);
+        if (off) {
+            const int rc = aqg_gid_reduce(ctx, gid_col, off, g->counts, n, G, op, t, x, out_dev);
+            if (rc != AQG_ERR_DTYPE) { if (rc == AQG_OK) g->plan_bits = AQG_PLAN_GID_PARTITION; return rc; }
+        }
+    }
     const int kdt = AQG_UINT32;
     const void* kcol = gid_col;
     KeySpec ks;
@@ -1952,6 +1984,7 @@ int aqg_grouped_reduce_keyed(aqg_ctx* ctx, aqg_groupby* g, const uint32_t* gid_c
     AQG_TRY(make_plan(ctx, 1, &op, &t, &x, n, &plan));
     AQG_TRY(run_with_retry(ctx, ks, plan, n, G, false, h, nullptr, nullptr));
     if (h->ngroups != G) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_reduce: group ids are not dense");
+    g->plan_bits = h->plan_bits;
     AQG_HIP(ctx, hipMemcpyAsync(out_dev, h->results[0], (size_t)G * aqg_dtype_size(aqg_reduce_out_dtype(op, t)), hipMemcpyDeviceToDevice, ctx->stream));
     return AQG_OK;
 }

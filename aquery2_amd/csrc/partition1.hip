@@ -259,7 +259,7 @@ struct AggOps { int opc[MAXACC]; };
 template <int NACC, bool K64, bool V8>
 __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rkeys, const uint32_t* __restrict__ rrows, AccSpec as, AggIn in, AggOps ops,
                                                     const uint32_t* __restrict__ pstart, uint32_t pstride, uint32_t NB, uint32_t ntotal, uint32_t cap, uint32_t gmax, int need_count,
-                                                    GTable out, uint32_t out_cap) {
+                                                    GTable out, uint32_t out_cap, uint32_t* __restrict__ part_base /* null, or [2 NB]: {first record, records} of every partition */) {
     using K = key_t_<K64>;
     using VT = std::conditional_t<V8, uint64_t, uint32_t>;
     constexpr int NA = NACC ? NACC : 1;
@@ -406,6 +406,7 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
         if (threadIdx.x == 0) {
             const uint32_t used = (lused < gmax ? lused : gmax) - 1 + (lfirst[0] != NOROW ? 1u : 0u);
             gbase = atomicAdd(&out.flags[1], used);
+            if (part_base) { part_base[2 * (size_t)part] = gbase; part_base[2 * (size_t)part + 1] = used; }
         }
         __syncthreads();
         for (uint32_t s = threadIdx.x; s <= cap; s += SB) {
@@ -909,7 +910,7 @@ static bool p1_key_is_column(const KeySpec& ks, int ksz) { return ks.nkeys == 1 
 
 // aggregate the partitions [pstart[p * pstride], pstart[(p + 1) * pstride]) (the last one ends at n) of the partitioned planes
 static int p1_launch_agg(aqg_ctx* ctx, int ksz, const AccSpec& as, const ValCols& vc, const void* pkeys, const void* prows, void* const* pvals,
-                         const uint32_t* pstart, uint32_t pstride, uint32_t nparts, uint32_t n, int need_count, GTable out, uint32_t out_cap) {
+                         const uint32_t* pstart, uint32_t pstride, uint32_t nparts, uint32_t n, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr) {
     AggIn in;
     memset(&in, 0, sizeof in);
     for (int a = 0; a < as.nacc; ++a) {
@@ -935,10 +936,17 @@ static int p1_launch_agg(aqg_ctx* ctx, int ksz, const AccSpec& as, const ValCols
     p1_capacity(ksz, as, need_count, &gmax, &cap);
     const size_t lds = (size_t)gmax * (4 + (need_count ? 4 : 0) + 8 * (size_t)as.nacc) + (size_t)cap * (ksz + 2) + 16;
     const unsigned grid = nparts < (unsigned)ctx->num_cu ? nparts : (unsigned)ctx->num_cu;
+    uint32_t* part_base = nullptr;
+    if (pr) {                                      // the build: where the partitioned rows lie and which records every partition wrote
+        AQG_TRY(aqg_ws_get(ctx, 2 * (size_t)nparts + 2, &part_base));
+        AQG_HIP(ctx, hipMemsetAsync(part_base, 0, (2 * (size_t)nparts + 2) * 4, ctx->stream));
+        pr->keys = pkeys; pr->rows = static_cast<const uint32_t*>(prows); pr->pstart = pstart; pr->pstride = pstride; pr->nparts = nparts; pr->ntotal = n;
+        pr->ksz = ksz; pr->part_base = part_base; pr->cap = cap; pr->valid = true;
+    }
     auto launch = [&](auto kern) -> int {
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
         aqg_kernel_timer_begin(ctx);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(SB), lds, ctx->stream, pkeys, static_cast<const uint32_t*>(prows), as, in, ops, pstart, pstride, nparts, n, cap, gmax, need_count, out, out_cap);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SB), lds, ctx->stream, pkeys, static_cast<const uint32_t*>(prows), as, in, ops, pstart, pstride, nparts, n, cap, gmax, need_count, out, out_cap, part_base);
         aqg_kernel_timer_end(ctx);
         return aqg_check_launch(ctx, "p1_agg_kernel");
     };
@@ -970,7 +978,7 @@ size_t aqg_partition1_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
 
 // Partitioned aggregation of (ks, as) over n rows into the compact record table `out` (AoS records, `out_cap` slots,
 // flags[1] = number of groups written, flags[0] = overflow).  Needs packed (<= 8 byte) keys and nbins from aqg_partition1_bins.
-int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap) {
+int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap, PartRows* pr) {
     if (nbins < 1 || nbins > AQG_P1_MAXBINS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "one-level partitioned group-by: 1..3584 bins");
     const int ksz = ks.total_bytes <= 4 ? 4 : 8;
     Chunks ch;
@@ -1043,7 +1051,7 @@ int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     };
     if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
 
-    return p1_launch_agg(ctx, ksz, as, vc, pkeys, prows, pvals, hist, ch.nchunks, nbins, n, need_count, out, out_cap);
+    return p1_launch_agg(ctx, ksz, as, vc, pkeys, prows, pvals, hist, ch.nchunks, nbins, n, need_count, out, out_cap, pr);
 }
 
 
@@ -1062,7 +1070,7 @@ size_t aqg_partition2_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
     return ((size_t)n + 64) * per_row + 256 * (8 + 4 * MAXACC) + (size_t)p2_round_parts(parts) * 16 + 65536;
 }
 
-int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap) {
+int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr) {
     const uint32_t P = p2_round_parts(parts), B1 = P >> 6;
     if (P < 64 || P > AQG_P2_MAXPARTS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "two-level partitioned group-by: 64..4096 partitions");
     const int ksz = ks.total_bytes <= 4 ? 4 : 8;
@@ -1145,7 +1153,7 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         return aqg_check_launch(ctx, "two-level partition scatter");
     };
     if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
-    return p1_launch_agg(ctx, ksz, as, vc, keysB, rowsB, valsB, fstart, 1u, P, n, need_count, out, out_cap);
+    return p1_launch_agg(ctx, ksz, as, vc, keysB, rowsB, valsB, fstart, 1u, P, n, need_count, out, out_cap, pr);
 }
 
 // ---- wide tuples: host ----------------------------------------------------------------------------------------------------------------
@@ -1472,4 +1480,299 @@ int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows,
     for (int a = 0; a < nacc; ++a) out->acc[a] = from->acc[a];
     out->pstart = seg; out->nparts = nseg; out->M = M; out->cap = sp.cap; out->lds = sp.lds;
     return AQG_OK;
+}
+
+// ==== the BUILD through the partition plans: group id of every row ============================================================================
+// aqg_groupby_build needs, beyond the group table, the dense id of every row (AQHashTable's reversemap, server/hasher.h:167-179).  Up to
+// here a build above the LDS tables inserted every row into an HBM table and looked every row up again (1e9 rows, 1e7 groups: 37 + 47 ms
+// of scattered HBM accesses).  Now the group table comes from the partition plan (no accumulators, counts only), and the rows -- still
+// lying partitioned in the workspace, {key, row id} -- are walked ONCE more per partition: the partition's records (p1_agg notes which
+// range of the record table it wrote) go into an LDS table {key -> dense id of the record}, every row probes it and writes
+// reversemap[row id].  8 B/row read + a scattered 4-byte write per row.
+namespace {
+template <bool K64>
+__global__ void __launch_bounds__(1024) p_assign_kernel(PartRows pr, GTable gt, const uint32_t* __restrict__ slot_gid, uint32_t* __restrict__ reversemap) {
+    using K = key_t_<K64>;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    K* ktab = reinterpret_cast<K*>(smem_raw);                        // [cap]
+    uint32_t* gtab = reinterpret_cast<uint32_t*>(ktab + pr.cap);     // [cap]
+    __shared__ uint32_t special_gid;
+    const K EMPTYK = empty_key<K64>();
+    const uint32_t cap = pr.cap, NB = pr.nparts;
+    for (uint32_t part = blockIdx.x; part < NB; part += gridDim.x) {
+        const uint32_t b = pr.pstart[(size_t)part * pr.pstride];
+        const uint32_t e = part + 1 < NB ? pr.pstart[(size_t)(part + 1) * pr.pstride] : pr.ntotal;
+        if (b == e) continue;
+        const uint32_t base = pr.part_base[2 * (size_t)part], used = pr.part_base[2 * (size_t)part + 1];
+        for (uint32_t s = threadIdx.x; s < cap; s += 1024) ktab[s] = EMPTYK;
+        if (threadIdx.x == 0) special_gid = 0;
+        __syncthreads();
+        for (uint32_t r = threadIdx.x; r < used; r += 1024) {         // this partition's records -> {key -> dense id}
+            const uint32_t rec = base + r;
+            const K k = (K)*gt.key_p(rec);
+            const uint32_t gid = slot_gid[rec];
+            if (k == EMPTYK) { special_gid = gid; continue; }
+            uint32_t slot = __umulhi(key_hash<K64>(k) * NB, cap);
+            for (uint32_t step = 0; step < cap; ++step) {
+                K c;
+                if constexpr (K64) c = atomicCAS(reinterpret_cast<unsigned long long*>(&ktab[slot]), (unsigned long long)EMPTYK, (unsigned long long)k);
+                else c = atomicCAS(&ktab[slot], EMPTYK, k);
+                if (c == EMPTYK || c == k) { gtab[slot] = gid; break; }
+                slot = slot + 1 == cap ? 0 : slot + 1;
+            }
+        }
+        __syncthreads();
+        for (uint32_t i0 = b + threadIdx.x; i0 < e; i0 += 4 * 1024) {   // four rows of a lane in flight
+            K key[4]; uint32_t row[4], slot[4]; K w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t i = i0 + q * 1024, ic = i < e ? i : e - 1;
+                key[q] = static_cast<const K*>(pr.keys)[ic];
+                row[q] = pr.rows[ic];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { slot[q] = __umulhi(key_hash<K64>(key[q]) * NB, cap); w[q] = ktab[slot[q]]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!(i0 + q * 1024 < e)) continue;
+                uint32_t gid;
+                if (key[q] == EMPTYK) gid = special_gid;
+                else {
+                    uint32_t sl = slot[q];
+                    K c = w[q];
+                    for (uint32_t step = 0; c != key[q] && step < cap; ++step) { sl = sl + 1 == cap ? 0 : sl + 1; c = ktab[sl]; }
+                    gid = gtab[sl];
+                }
+                reversemap[row[q]] = gid;
+            }
+        }
+        __syncthreads();
+    }
+}
+} // namespace
+int aqg_partition_assign(aqg_ctx* ctx, const PartRows& pr, GTable gt, const uint32_t* slot_gid, uint32_t* reversemap) {
+    if (!pr.valid) return aqg_fail(ctx, AQG_ERR_ARG, "partitioned build: no partitioned rows");
+    const size_t lds = (size_t)pr.cap * (pr.ksz + 4) + 64;
+    const unsigned grid = pr.nparts < 2u * (unsigned)ctx->num_cu ? pr.nparts : 2u * (unsigned)ctx->num_cu;
+    if (pr.ksz == 4) {
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p_assign_kernel<false>), lds));
+        hipLaunchKernelGGL((p_assign_kernel<false>), dim3(grid), dim3(1024), lds, ctx->stream, pr, gt, slot_gid, reversemap);
+    } else {
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p_assign_kernel<true>), lds));
+        hipLaunchKernelGGL((p_assign_kernel<true>), dim3(grid), dim3(1024), lds, ctx->stream, pr, gt, slot_gid, reversemap);
+    }
+    return aqg_check_launch(ctx, "p_assign_kernel");
+}
+
+// ==== grouped reductions keyed by DENSE group ids: aqg_grouped_reduce beyond the LDS tables =============================================
+// `out[g] = op(x[rows of group g])` for the generated loop (engine/ast.py:722-789) groups by the build's id column.  Those ids are dense
+// and the group sizes are known, which the hashed partition plans above cannot use: here the rows {id, value} are partitioned on the id
+// itself -- ORDER-PRESERVING bins umulhi(id, M), so a partition owns a contiguous id range -- with the tile scatter of the two-level
+// plan, in as many levels of <= 128 bins as it takes until a partition's id range fits an LDS array of accumulators.  No histogram
+// pass at any level: a partition's rows are the rows of its groups, so every segment start and write cursor is an entry of the
+// build's offsets (the exclusive scan of the group sizes).  The aggregation is then DIRECT-indexed -- acc[id - first id of the
+// partition], no keys, no probing -- and every workgroup writes its id range of the result column front to back: no record table, no
+// ranking, no emit.  16 B/row and level + 8 B/row for the aggregation (1e9 rows, 1e7 groups: two levels).
+namespace {
+
+__global__ void __launch_bounds__(256) gid_setup_kernel(const uint32_t* __restrict__ offsets, uint32_t G, uint32_t M, uint32_t PP,
+                                                        uint32_t* __restrict__ pstart /* [PP + 1] */, uint32_t* __restrict__ pfirst /* [PP + 1] */) {
+    for (uint32_t p = blockIdx.x * 256 + threadIdx.x; p <= PP; p += gridDim.x * 256) {
+        uint64_t g0 = p == PP ? G : (((uint64_t)p << 32) + M - 1) / M;        // smallest id whose bin is >= p
+        if (g0 > G) g0 = G;
+        pfirst[p] = (uint32_t)g0;
+        pstart[p] = offsets[g0];
+    }
+}
+
+__device__ inline aqg_i128 mul_128_p1(aqg_i128 a, aqg_i128 b) {   // low 128 bits of the product (two's complement: sign-agnostic)
+    aqg_i128 r;
+    r.lo = a.lo * b.lo;
+    r.hi = __umul64hi(a.lo, b.lo) + a.lo * b.hi + a.hi * b.lo;
+    return r;
+}
+struct GidAgg {
+    const uint32_t* gid; const void* val; int vdt; int op;
+    const uint32_t* pstart; const uint32_t* pfirst; const uint32_t* counts;
+    void* out; uint32_t nparts, cap;
+};
+// value of row i as the operand of accumulator `which` (0: the value, 1: its square in the promoted type) -- wave-uniform dtype switch
+__device__ inline uint64_t gid_operand(const GidAgg& a, size_t i, int kind, int square) {
+    switch (a.vdt) {
+    case AQG_INT8: return val_operand_t((int8_t)(uint8_t)static_cast<const uint32_t*>(a.val)[i], kind, square);      // (1- / 2-byte columns travel widened)
+    case AQG_INT16: return val_operand_t((int16_t)(uint16_t)static_cast<const uint32_t*>(a.val)[i], kind, square);
+    case AQG_UINT8: case AQG_BOOL: return val_operand_t((uint8_t)static_cast<const uint32_t*>(a.val)[i], kind, square);
+    case AQG_UINT16: return val_operand_t((uint16_t)static_cast<const uint32_t*>(a.val)[i], kind, square);
+    case AQG_INT32: return val_operand_t(static_cast<const int32_t*>(a.val)[i], kind, square);
+    case AQG_UINT32: return val_operand_t(static_cast<const uint32_t*>(a.val)[i], kind, square);
+    case AQG_FLOAT: return val_operand_t(static_cast<const float*>(a.val)[i], kind, square);
+    case AQG_INT64: return val_operand_t(static_cast<const int64_t*>(a.val)[i], kind, square);
+    case AQG_UINT64: return val_operand_t(static_cast<const uint64_t*>(a.val)[i], kind, square);
+    default: return val_operand_t(static_cast<const double*>(a.val)[i], kind, square);
+    }
+}
+template <class T> __device__ __noinline__ void gid_store_minmax(void* out, uint32_t g, uint64_t mapped, bool is_max) {
+    T v;
+    if constexpr (std::is_floating_point_v<T>) { v = (T)unmap_f(mapped); if (is_max) { T seed = dlimits<T>::min(); v = seed > v ? seed : v; } }   // (D8: max seeds with numeric_limits<T>::min())
+    else if constexpr (std::is_unsigned_v<T>) v = (T)mapped;
+    else v = (T)unmap_i(mapped);
+    static_cast<T*>(out)[g] = v;
+}
+__global__ void __launch_bounds__(1024) gid_agg_kernel(GidAgg a) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint64_t* acc0 = reinterpret_cast<uint64_t*>(smem_raw);
+    uint64_t* acc1 = acc0 + a.cap;
+    const bool two = a.op == AQG_RED_VAR || a.op == AQG_RED_STDDEV;
+    const int vc = vclass(a.vdt);
+    const int kind = a.op == AQG_RED_MIN ? ACC_MIN : a.op == AQG_RED_MAX ? ACC_MAX : vc == VC_F ? ACC_ADD_F : ACC_ADD_I;
+    for (uint32_t p = blockIdx.x; p < a.nparts; p += gridDim.x) {
+        const uint32_t g0 = a.pfirst[p], width = a.pfirst[p + 1] - g0;
+        const uint32_t r0 = a.pstart[p], r1 = a.pstart[p + 1];
+        for (uint32_t j = threadIdx.x; j < width; j += 1024) { acc0[j] = acc_init(kind); if (two) acc1[j] = 0; }
+        __syncthreads();
+        // four rows of a lane in flight (ids and values loaded before the first LDS atomic)
+        for (uint32_t i0 = r0 + threadIdx.x; i0 < r1; i0 += 4 * 1024) {
+            uint32_t g[4]; uint64_t v[4], q[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t i = i0 + k * 1024;
+                const uint32_t ic = i < r1 ? i : r1 - 1;
+                g[k] = a.gid[ic] - g0;
+                v[k] = gid_operand(a, ic, kind, 0);
+                q[k] = two ? gid_operand(a, ic, kind, 1) : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (i0 + k * 1024 < r1) { acc_apply(&acc0[g[k]], kind, v[k]); if (two) acc_apply(&acc1[g[k]], kind, q[k]); }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < width; j += 1024) {
+            const uint32_t gg = g0 + j;
+            const uint64_t s = acc0[j];
+            switch (a.op) {
+            case AQG_RED_SUM:
+                if (vc == VC_F) static_cast<double*>(a.out)[gg] = __builtin_bit_cast(double, s);
+                else static_cast<aqg_i128*>(a.out)[gg] = vc == VC_U ? i128_from_u64(s) : i128_from_i64((int64_t)s);
+                break;
+            case AQG_RED_AVG: {
+                const double sd = vc == VC_F ? __builtin_bit_cast(double, s) : vc == VC_U ? (double)s : (double)(int64_t)s;
+                static_cast<double*>(a.out)[gg] = sd / (double)a.counts[gg];
+            } break;
+            case AQG_RED_VAR: case AQG_RED_STDDEV: {                            // (ssq - s * s / (n + 1)) / (n + 1): D9 kept
+                const double np1 = (double)(uint32_t)(a.counts[gg] + 1);
+                double d;
+                if (vc == VC_F) { const double sd = __builtin_bit_cast(double, s), qd = __builtin_bit_cast(double, acc1[j]); d = (qd - sd * sd / np1) / np1; }
+                else {
+                    const aqg_i128 sm = vc == VC_U ? i128_from_u64(s) : i128_from_i64((int64_t)s);
+                    const aqg_i128 qq = vc == VC_U ? i128_from_u64(acc1[j]) : i128_from_i64((int64_t)acc1[j]);
+                    const aqg_i128 ss = mul_128_p1(sm, sm);
+                    const double sq = vc == VC_U ? u128_to_double(ss.hi, ss.lo) : i128_to_double(ss);
+                    const double qdd = vc == VC_U ? u128_to_double(qq.hi, qq.lo) : i128_to_double(qq);
+                    d = (qdd - sq / np1) / np1;
+                }
+                static_cast<double*>(a.out)[gg] = a.op == AQG_RED_STDDEV ? sqrt(d) : d;
+            } break;
+            default: {
+                const bool mx = a.op == AQG_RED_MAX;
+                switch (a.vdt) {
+                case AQG_INT8: gid_store_minmax<int8_t>(a.out, gg, s, mx); break;
+                case AQG_INT16: gid_store_minmax<int16_t>(a.out, gg, s, mx); break;
+                case AQG_INT32: gid_store_minmax<int32_t>(a.out, gg, s, mx); break;
+                case AQG_INT64: gid_store_minmax<int64_t>(a.out, gg, s, mx); break;
+                case AQG_UINT8: case AQG_BOOL: gid_store_minmax<uint8_t>(a.out, gg, s, mx); break;
+                case AQG_UINT16: gid_store_minmax<uint16_t>(a.out, gg, s, mx); break;
+                case AQG_UINT32: gid_store_minmax<uint32_t>(a.out, gg, s, mx); break;
+                case AQG_UINT64: gid_store_minmax<uint64_t>(a.out, gg, s, mx); break;
+                case AQG_FLOAT: gid_store_minmax<float>(a.out, gg, s, mx); break;
+                default: gid_store_minmax<double>(a.out, gg, s, mx); break;
+                }
+            } break;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+// out[g] = op(x[rows whose id is g]) for dense ids 0 .. G-1 with known group sizes (offsets = their exclusive scan, G + 1 entries).
+// AQG_ERR_DTYPE: this (op, dtype) is not served here (8-byte integer sums need 128 bits per group): the caller takes the hashed plans.
+int aqg_gid_reduce(aqg_ctx* ctx, const uint32_t* gid, const uint32_t* offsets, const uint32_t* counts, uint32_t n, uint32_t G, int op, int t, const void* x, void* out_dev) {
+    const bool two = op == AQG_RED_VAR || op == AQG_RED_STDDEV;
+    if (!(op == AQG_RED_SUM || op == AQG_RED_AVG || op == AQG_RED_MIN || op == AQG_RED_MAX || two)) return AQG_ERR_DTYPE;
+    const bool wide_int = t == AQG_INT64 || t == AQG_UINT64;
+    if (wide_int && op != AQG_RED_MIN && op != AQG_RED_MAX) return AQG_ERR_DTYPE;
+    const int esz = (int)aqg_dtype_size(t), vsz = esz == 8 ? 8 : 4;
+    // ids of one partition: at most 78 KB of accumulators (two 1024-thread workgroups per CU), and at least 1024 partitions whatever the
+    // group count -- the aggregation runs one workgroup per partition (1e5 groups in 8 partitions: 119 ms; in 1024: see DESIGN.md)
+    const uint32_t cap_max = two ? 4992u : 9984u;
+    uint32_t bits = 10;
+    while (bits < 21 && ((uint64_t)G >> bits) + 2 > cap_max) ++bits;
+    if (((uint64_t)G >> bits) + 2 > cap_max || G <= (8u << bits)) return AQG_ERR_DTYPE;
+    const uint32_t cap = (uint32_t)((uint64_t)G >> bits) + 2;
+    const uint32_t levels = (bits + 6) / 7, PP = 1u << bits;
+    const uint32_t M = (uint32_t)((((uint64_t)1 << bits) << 32) / G);
+    AQG_TRY(aqg_ws_reset(ctx));
+    AQG_TRY(aqg_ws_ensure(ctx, ((size_t)n + 64) * (2 * (4 + (size_t)vsz) + (esz < 4 ? 4 : 0)) + (size_t)PP * 40 + 1048576));
+    uint32_t *gA, *gB, *pstart, *pfirst, *seg, *tp, *cur;
+    void *vA, *vB;
+    AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &gA));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &gB));
+    AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * vsz, &vA));
+    AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * vsz, &vB));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &pstart));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &pfirst));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &seg));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &tp));
+    AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &cur));
+    const void* vsrc = x;
+    if (esz < 4) {
+        uint32_t* wide;
+        AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &wide));
+        hipLaunchKernelGGL(p1_widen_kernel, dim3(aqg_grid(ctx, n, 256, 4, 16)), dim3(256), 0, ctx->stream, x, esz, n, wide);
+        vsrc = wide;
+    }
+    hipLaunchKernelGGL(gid_setup_kernel, dim3(aqg_grid(ctx, (uint64_t)PP + 1, 256, 1, 4)), dim3(256), 0, ctx->stream, offsets, G, M, PP, pstart, pfirst);
+    const size_t scat_lds = (size_t)P2_PT * 4;
+    AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, true, false>), scat_lds));
+    AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, false, false>), scat_lds));
+    uint32_t nseg = 1, bits_left = bits;
+    const uint32_t* gsrc = gid;
+    const void* vs = vsrc;
+    for (uint32_t l = 0; l < levels; ++l) {
+        const uint32_t lb = (bits_left + (levels - l) - 1) / (levels - l);        // bits of this level, most significant first
+        bits_left -= lb;
+        const uint32_t nb = 1u << lb, shift = bits_left, mask = nb - 1;
+        // this level's segments are the partitions of the levels before it, its cursors the starts of its own partitions: entries of pstart
+        hipLaunchKernelGGL(pn_gather_strided_kernel, dim3(aqg_grid(ctx, (uint64_t)nseg + 1, 256, 1, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)pstart, nb << shift, nseg + 1, seg);
+        hipLaunchKernelGGL(pn_gather_strided_kernel, dim3(aqg_grid(ctx, (uint64_t)nseg * nb, 256, 1, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)pstart, 1u << shift, nseg * nb, cur);
+        hipLaunchKernelGGL(pn_tiles_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)seg, nseg, (uint32_t)P2_PT, tp);
+        uint32_t* gdst = (l & 1) ? gB : gA;
+        void* vdst = (l & 1) ? vB : vA;
+        Planes pl;
+        memset(&pl, 0, sizeof pl);
+        auto add = [&](const void* s_, int sstride, int soff, void* d, int dstride, int doff) {
+            Plane& Q = pl.p[pl.n++];
+            Q.kind = PL_LOAD; Q.src = static_cast<const uint32_t*>(s_); Q.src_stride_dw = sstride; Q.src_off_dw = soff;
+            Q.dst = static_cast<uint32_t*>(d); Q.dst_stride_dw = dstride; Q.dst_off_dw = doff;
+        };
+        add(gsrc, 1, 0, gdst, 1, 0);
+        if (vsz == 4) add(vs, 1, 0, vdst, 1, 0); else { add(vs, 2, 0, vdst, 2, 0); add(vs, 2, 1, vdst, 2, 1); }
+        P2Level lv{seg, tp, cur, nseg, M, shift, mask, nb, nb};
+        const unsigned tiles = (unsigned)((uint64_t)n / P2_PT) + nseg + 1;
+        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, true, false>), dim3(tiles), dim3(P2_TB), scat_lds, ctx->stream, gsrc, pl, lv);
+        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, false, false>), dim3(nseg), dim3(P2_TB), scat_lds, ctx->stream, gsrc, pl, lv);
+        AQG_TRY(aqg_check_launch(ctx, "id-partitioned grouped reduce: level"));
+        nseg *= nb;
+        gsrc = gdst; vs = vdst;
+    }
+    GidAgg a;
+    a.gid = gsrc; a.val = vs; a.vdt = t; a.op = op; a.pstart = pstart; a.pfirst = pfirst; a.counts = counts; a.out = out_dev; a.nparts = PP; a.cap = cap;
+    const size_t lds = (size_t)cap * 8 * (two ? 2 : 1);
+    AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&gid_agg_kernel), lds));
+    aqg_kernel_timer_begin(ctx);
+    hipLaunchKernelGGL(gid_agg_kernel, dim3(PP < 4096 ? PP : 4096), dim3(1024), lds, ctx->stream, a);
+    aqg_kernel_timer_end(ctx);
+    return aqg_check_launch(ctx, "gid_agg_kernel");
 }

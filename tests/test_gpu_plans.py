@@ -130,3 +130,70 @@ def test_h2o_q10_at_1e8_rows_default_thresholds_groups_of_two():
         assert np.array_equal(s, 2.0 * h3.astype(np.float64))
     finally:
         d.close()
+
+
+@pytest.mark.parametrize("n,G", [(9_000_017, 4_000_000), (4_200_000, -1)])
+def test_grouped_reduce_partitioned_on_the_dense_group_id(n, G):
+    """aqg_grouped_reduce beyond the LDS tables: rows {id, value} partitioned on the build's dense group id (one and two levels of
+    order-preserving bins, cursors from the offsets: no histogram pass), direct-indexed LDS accumulators, results written in id order.
+    Every op and value dtype it serves against the oracle's per-group reduction; 8-byte integer sums still take the hashed plans."""
+    import aquery2_amd
+    import golden_util as gu
+    from aquery2_amd import capi
+    d = aquery2_amd.Device(0)
+    oracle = ck.load_oracle()
+    try:
+        rng = np.random.default_rng(n + G)
+        key = rng.integers(0, G, n).astype(np.int32) if G > 0 else rng.permutation(n).astype(np.int32)     # (G < 0: nearly every row its own group)
+        key[: n // 50] = key[0]                                   # one large group among many small ones
+        o = oracle.groupby([key])
+        gb = d.groupby_build([key])
+        assert gb.ngroups == o["ngroups"] and gb.ngroups > (3 << 20)
+        for dt in (np.int8, np.int16, np.int32, np.uint16, np.uint32, np.float32, np.float64, np.int64):
+            fp = np.dtype(dt).kind == "f"
+            x = np.round(rng.uniform(-1000, 1000, n), 3).astype(dt) if fp else rng.integers(-100 if np.dtype(dt).kind == "i" else 0, 100, n).astype(dt)
+            for name in ("sum", "avg", "min", "max", "var", "stddev"):
+                op = ck.RED_NAMES[name]
+                got, want = d.grouped_reduce(gb, op, x), oracle.grouped_reduce(op, x, o)
+                served = not (dt == np.int64 and name not in ("min", "max"))
+                assert (gb.plan == capi.PLAN_GID_PARTITION) == served, (dt, name, gb.plan)
+                if fp and name in ("sum", "avg", "var", "stddev"):
+                    assert np.allclose(got, want, rtol=1e-9, atol=1e-6), (dt, name)
+                else:
+                    assert gu.same_bits(got, want), (dt, name)
+    finally:
+        d.close()
+
+
+BUILD = r'''
+n = 3_000_017
+def check_build(keys, want_plan):
+    o = oracle.groupby(keys)
+    gb = gpu.groupby_build(keys)
+    assert gb.plan & want_plan == want_plan and (want_plan or not gb.plan & capi.PLAN_BUILD_PARTITIONED), ("plan", gb.plan, want_plan)
+    assert gb.ngroups == o["ngroups"]
+    assert np.array_equal(gb.reversemap(), o["reversemap"]) and np.array_equal(gb.counts(), o["counts"]) and np.array_equal(gb.first_rows(), o["first_rows"])
+    for k, c in enumerate(keys):
+        assert np.array_equal(gb.keys(k, c.dtype), c[o["first_rows"]]), k
+    off, rows = gb.postproc()
+    assert np.array_equal(off[:-1], o["offsets"]) and np.array_equal(rows, o["row_ids"])
+    v = rng.integers(-9, 10, n).astype(np.int32)
+    assert gu.same_bits(gpu.grouped_reduce(gb, ck.RED_SUM, v), oracle.grouped_reduce(ck.RED_SUM, v, o))
+    print("OK", gb.ngroups, flush=True)
+key = rng.integers(0, %d, n).astype(np.int32)
+key[::1000] = np.int32(-2**31)                                  # the value that doubles as the LDS tables' empty mark
+check_build([key], %s)
+check_build([(key.astype(np.int64) << 33) | 5], %s)            # an 8-byte key word
+check_build([(key %% 1000).astype(np.int16), (key // 1000).astype(np.int32)], %s)   # two columns packed into one word
+'''
+
+
+@pytest.mark.parametrize("G", [300_000, 2_500_000])
+def test_build_through_the_partition_plans(G):
+    """aqg_groupby_build above the LDS tables: the group table from the one- / two-level partition plan (counts only), then the id of every row
+    from one more pass over the rows still lying partitioned -- reversemap, counts, first rows, keys, ht_postproc and a grouped reduction
+    against the oracle; 4- and 8-byte key words, a packed pair, the key value that doubles as the empty mark.  With the switch off
+    (AQG_DISABLE_BUILD_PARTITION=1) the same calls take the HBM table and give the same results."""
+    plan = "capi.PLAN_BUILD_PARTITIONED"
+    run_forced({}, BUILD % (G, plan, plan, plan))
+    run_forced({"AQG_DISABLE_BUILD_PARTITION": "1"}, BUILD % (G, "0", "0", "0"))
