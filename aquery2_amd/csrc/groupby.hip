@@ -1246,6 +1246,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
     // (the partition buffers are dead once the record table is written: the ordering pass takes their place in the arena)
     const size_t sort_need = sorted_tail ? aqg_sorted_tail_ws_bytes(gcap, n, as.nacc, ks.wide != 0) : 0;
     need += part_need > sort_need ? part_need : sort_need;
+    if (for_build && use_part) need += aqg_partition_assign_ws_bytes(n);
     AQG_TRY(aqg_ws_reset(ctx));
     AQG_TRY(aqg_ws_ensure(ctx, need));
     GTable gt;

@@ -1491,7 +1491,7 @@ int aqg_sorted_tail(aqg_ctx* ctx, const GTable& gt, uint32_t G, uint32_t n_rows,
 // reversemap[row id].  8 B/row read + a scattered 4-byte write per row.
 namespace {
 template <bool K64>
-__global__ void __launch_bounds__(1024) p_assign_kernel(PartRows pr, GTable gt, const uint32_t* __restrict__ slot_gid, uint32_t* __restrict__ reversemap) {
+__global__ void __launch_bounds__(1024) p_assign_kernel(PartRows pr, GTable gt, const uint32_t* __restrict__ slot_gid, uint32_t* __restrict__ gid_part /* [ntotal]: the id of the row at every partitioned position */) {
     using K = key_t_<K64>;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     K* ktab = reinterpret_cast<K*>(smem_raw);                        // [cap]
@@ -1523,12 +1523,11 @@ __global__ void __launch_bounds__(1024) p_assign_kernel(PartRows pr, GTable gt, 
         }
         __syncthreads();
         for (uint32_t i0 = b + threadIdx.x; i0 < e; i0 += 4 * 1024) {   // four rows of a lane in flight
-            K key[4]; uint32_t row[4], slot[4]; K w[4];
+            K key[4]; uint32_t slot[4]; K w[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const uint32_t i = i0 + q * 1024, ic = i < e ? i : e - 1;
                 key[q] = static_cast<const K*>(pr.keys)[ic];
-                row[q] = pr.rows[ic];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) { slot[q] = __umulhi(key_hash<K64>(key[q]) * NB, cap); w[q] = ktab[slot[q]]; }
@@ -1543,25 +1542,108 @@ __global__ void __launch_bounds__(1024) p_assign_kernel(PartRows pr, GTable gt, 
                     for (uint32_t step = 0; c != key[q] && step < cap; ++step) { sl = sl + 1 == cap ? 0 : sl + 1; c = ktab[sl]; }
                     gid = gtab[sl];
                 }
-                reversemap[row[q]] = gid;
+                gid_part[i0 + q * 1024] = gid;
             }
         }
         __syncthreads();
     }
 }
+// out[idx[i]] = val[i] for a PERMUTATION idx of 0 .. n-1 (every row id once): a scattered 4-byte store per row runs at the rate of the
+// memory side (~3e10/s: 43 ms per 1e9 rows as the build's last step), so the pairs {idx, val} are first partitioned on idx -- order-
+// preserving bins, the tile scatter again, no histogram: a partition's size IS its index interval -- until an interval spans 64 K
+// rows; the stores of a workgroup then land inside a 256 KB window that its L2 turns into whole lines.
+// the last step: partition p holds exactly the pairs whose index lies in [pstart[p], pstart[p + 1]) -- as many pairs as indices.  One
+// workgroup per partition places the values in LDS by index (a window of 32 K indices at a time: a partition of 64 K rows takes two sweeps
+// over its pairs) and streams the window out: every store instruction writes whole lines.  (Plain stores through the index, every
+// workgroup inside its own 256 KB window: 14 ms per 1e9 rows -- 2048 such windows do not fit the L2s.)
+constexpr uint32_t ROUTE_W = 32768;
+__global__ void __launch_bounds__(1024) route_final_kernel(const uint32_t* __restrict__ idx, const uint32_t* __restrict__ val, const uint32_t* __restrict__ pstart, uint32_t nparts,
+                                                           uint32_t n, uint32_t* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    uint32_t* win = reinterpret_cast<uint32_t*>(smem_raw);
+    for (uint32_t p = blockIdx.x; p < nparts; p += gridDim.x) {
+        const uint32_t b = pstart ? pstart[p] : 0u, e = pstart ? pstart[p + 1] : n;
+        for (uint32_t w0 = b; w0 < e; w0 += ROUTE_W) {
+            const uint32_t w1 = e - w0 < ROUTE_W ? e : w0 + ROUTE_W;
+            for (uint32_t i0 = b + threadIdx.x; i0 < e; i0 += 4 * 1024) {
+                uint32_t r[4], v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const uint32_t i = i0 + q * 1024, ic = i < e ? i : e - 1; r[q] = idx[ic]; v[q] = val[ic]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (i0 + q * 1024 < e && r[q] >= w0 && r[q] < w1) win[r[q] - w0] = v[q];
+            }
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < w1 - w0; j += 1024) out[w0 + j] = win[j];
+            __syncthreads();
+        }
+    }
+}
+size_t aqg_route_ws_bytes(uint32_t n) { return ((size_t)n + 64) * 16 + ((size_t)1 << 20); }
+// (declared below: gid_setup_kernel; offsets == nullptr: the identity)
+__global__ void __launch_bounds__(256) gid_setup_kernel(const uint32_t* __restrict__ offsets, uint32_t G, uint32_t M, uint32_t PP, uint32_t* __restrict__ pstart, uint32_t* __restrict__ pfirst);
+int aqg_route_by_row(aqg_ctx* ctx, const uint32_t* idx, const uint32_t* val, uint32_t n, uint32_t* out) {
+    uint32_t bits = 0;
+    while (bits < 21 && ((uint64_t)n >> bits) > 65536) ++bits;
+    const uint32_t* isrc = idx;
+    const uint32_t* vsrc = val;
+    const uint32_t* final_pstart = nullptr;
+    if (bits) {
+        const uint32_t levels = (bits + 6) / 7, PP = 1u << bits;
+        const uint32_t M = (uint32_t)((((uint64_t)1 << bits) << 32) / n);
+        uint32_t *iA, *iB, *vA, *vB, *pstart, *pfirst, *seg, *tp, *cur;
+        AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &iA)); AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &iB));
+        AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &vA)); AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &vB));
+        AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &pstart)); AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &pfirst));
+        AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &seg)); AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &tp)); AQG_TRY(aqg_ws_get(ctx, (size_t)PP + 2, &cur));
+        hipLaunchKernelGGL(gid_setup_kernel, dim3(aqg_grid(ctx, (uint64_t)PP + 1, 256, 1, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)nullptr, n, M, PP, pstart, pfirst);
+        final_pstart = pstart;
+        const size_t scat_lds = (size_t)P2_PT * 4;
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, true, false>), scat_lds));
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, false, false>), scat_lds));
+        uint32_t nseg = 1, bits_left = bits;
+        for (uint32_t l = 0; l < levels; ++l) {
+            const uint32_t lb = (bits_left + (levels - l) - 1) / (levels - l);
+            bits_left -= lb;
+            const uint32_t nb = 1u << lb, shift = bits_left, mask = nb - 1;
+            hipLaunchKernelGGL(pn_gather_strided_kernel, dim3(aqg_grid(ctx, (uint64_t)nseg + 1, 256, 1, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)pstart, nb << shift, nseg + 1, seg);
+            hipLaunchKernelGGL(pn_gather_strided_kernel, dim3(aqg_grid(ctx, (uint64_t)nseg * nb, 256, 1, 4)), dim3(256), 0, ctx->stream, (const uint32_t*)pstart, 1u << shift, nseg * nb, cur);
+            hipLaunchKernelGGL(pn_tiles_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)seg, nseg, (uint32_t)P2_PT, tp);
+            uint32_t* idst = (l & 1) ? iB : iA;
+            uint32_t* vdst = (l & 1) ? vB : vA;
+            Planes pl;
+            memset(&pl, 0, sizeof pl);
+            auto add = [&](const void* s_, void* d) { Plane& Q = pl.p[pl.n++]; Q.kind = PL_LOAD; Q.src = static_cast<const uint32_t*>(s_); Q.src_stride_dw = 1; Q.src_off_dw = 0; Q.dst = static_cast<uint32_t*>(d); Q.dst_stride_dw = 1; Q.dst_off_dw = 0; };
+            add(isrc, idst); add(vsrc, vdst);
+            P2Level lv{seg, tp, cur, nseg, M, shift, mask, nb, nb};
+            const unsigned tiles = (unsigned)((uint64_t)n / P2_PT) + nseg + 1;
+            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, true, false>), dim3(tiles), dim3(P2_TB), scat_lds, ctx->stream, isrc, pl, lv);
+            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, false, false>), dim3(nseg), dim3(P2_TB), scat_lds, ctx->stream, isrc, pl, lv);
+            AQG_TRY(aqg_check_launch(ctx, "route by row: level"));
+            nseg *= nb;
+            isrc = idst; vsrc = vdst;
+        }
+    }
+    AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&route_final_kernel), (size_t)ROUTE_W * 4));
+    hipLaunchKernelGGL(route_final_kernel, dim3(bits ? (1u << bits) : 1u), dim3(1024), (size_t)ROUTE_W * 4, ctx->stream, isrc, vsrc, final_pstart, bits ? (1u << bits) : 1u, n, out);
+    return aqg_check_launch(ctx, "route_final_kernel");
+}
 } // namespace
+size_t aqg_partition_assign_ws_bytes(uint32_t n) { return ((size_t)n + 64) * 4 + aqg_route_ws_bytes(n) + 65536; }
 int aqg_partition_assign(aqg_ctx* ctx, const PartRows& pr, GTable gt, const uint32_t* slot_gid, uint32_t* reversemap) {
     if (!pr.valid) return aqg_fail(ctx, AQG_ERR_ARG, "partitioned build: no partitioned rows");
+    uint32_t* gid_part;
+    AQG_TRY(aqg_ws_get(ctx, (size_t)pr.ntotal + 64, &gid_part));
     const size_t lds = (size_t)pr.cap * (pr.ksz + 4) + 64;
     const unsigned grid = pr.nparts < 2u * (unsigned)ctx->num_cu ? pr.nparts : 2u * (unsigned)ctx->num_cu;
     if (pr.ksz == 4) {
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p_assign_kernel<false>), lds));
-        hipLaunchKernelGGL((p_assign_kernel<false>), dim3(grid), dim3(1024), lds, ctx->stream, pr, gt, slot_gid, reversemap);
+        hipLaunchKernelGGL((p_assign_kernel<false>), dim3(grid), dim3(1024), lds, ctx->stream, pr, gt, slot_gid, gid_part);
     } else {
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p_assign_kernel<true>), lds));
-        hipLaunchKernelGGL((p_assign_kernel<true>), dim3(grid), dim3(1024), lds, ctx->stream, pr, gt, slot_gid, reversemap);
+        hipLaunchKernelGGL((p_assign_kernel<true>), dim3(grid), dim3(1024), lds, ctx->stream, pr, gt, slot_gid, gid_part);
     }
-    return aqg_check_launch(ctx, "p_assign_kernel");
+    AQG_TRY(aqg_check_launch(ctx, "p_assign_kernel"));
+    return aqg_route_by_row(ctx, pr.rows, gid_part, pr.ntotal, reversemap);      // the ids back into row order
 }
 
 // ==== grouped reductions keyed by DENSE group ids: aqg_grouped_reduce beyond the LDS tables =============================================
@@ -1581,7 +1663,7 @@ __global__ void __launch_bounds__(256) gid_setup_kernel(const uint32_t* __restri
         uint64_t g0 = p == PP ? G : (((uint64_t)p << 32) + M - 1) / M;        // smallest id whose bin is >= p
         if (g0 > G) g0 = G;
         pfirst[p] = (uint32_t)g0;
-        pstart[p] = offsets[g0];
+        pstart[p] = offsets ? offsets[g0] : (uint32_t)g0;
     }
 }
 

@@ -14,6 +14,7 @@ size_t aqg_partition2_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
 int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr);
 // the build's id pass over the partitioned rows: reversemap[row] = dense id of the row's key (slot_gid: record -> dense id)
 int aqg_partition_assign(aqg_ctx* ctx, const PartRows& pr, GTable gt, const uint32_t* slot_gid, uint32_t* reversemap);
+size_t aqg_partition_assign_ws_bytes(uint32_t n);
 // tuples wider than 8 bytes: hash-partitioned in up to three levels, every partition grouped inside LDS (sized by ROWS)
 bool aqg_partitionw_applies(const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t hint);
 uint32_t aqg_partitionw_rows(const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t hint);      // rows one partition may hold

@@ -108,6 +108,23 @@ def secondary_entries(dev, n, ck, aq, id1, v1):
         ms = timed(lambda: dev.scan(op, price, w, keep=True, out=o), reps=5)
         entry(name, ms, bpr * n, kernel_ms=round(dev.last_kernel_ms(), 4))
     big.free(); price.free()
+    # ---- seam A at high cardinality: h2o Q5 the way the header layer runs it -- aqg_groupby_build (hint 0: the group count is estimated from
+    # a sample) + one aqg_grouped_reduce per aggregate (include/aquery/hasher.h, device.h), all resident; the host's per-group loop of the
+    # generated code is not part of it (DESIGN.md section 5 gives its cost per group)
+    try:
+        id6, v2, v3 = (dev.gen_column(c, 42, 0, n, n, K) for c in (ck.GEN_ID6, ck.GEN_V2, ck.GEN_V3))
+        t_b = timed(lambda: (h.__setitem__("sa", dev.groupby_build([id6])), None)[1], reps=2)
+        gsa = h["sa"]
+        outs = [dev.empty(gsa.ngroups, ck.I128) for _ in range(3)]
+        def reduces():
+            for x, o in zip((v1, v2, v3), outs):
+                dev._chk(dev.lib.aqg_grouped_reduce(dev.ctx, gsa.h, ck.RED_SUM, x.tag, ctypes.c_void_p(x.ptr), ctypes.c_void_p(o.ptr)), "aqg_grouped_reduce")
+        t_r = timed(reduces)
+        entry("seam_a_q5_build_plus_three_grouped_sums", t_b + t_r, 16 * n + 44 * gsa.ngroups, groups=int(gsa.ngroups), build_ms=round(t_b, 3), three_reduces_ms=round(t_r, 3))
+        gsa.destroy(); id6.free(); v2.free(); v3.free()
+        for o in outs: o.free()
+    except Exception as e:                                    # noqa: BLE001 -- a secondary entry never costs the line
+        out.append({"name": "seam_a_q5", "error": str(e)[:300]})
     # ---- the reference's flagship shape: per-group windows inside the generated group loop (benchmark/quries/Aquery/q7.a
     # `SELECT stocksymbol, avgs(5, price) FROM trade ASSUMING ASC time GROUP BY stocksymbol`, mem_opt.cpp:53-63): the grouping is built once
     # (aqg_groupby_build), then ONE aqg_grouped_scan call answers every symbol -- price into the flat layout (value-carrying radix passes
