@@ -2053,27 +2053,36 @@ int aqg_grouped_corr(aqg_ctx* ctx, aqg_groupby* g, int tx, const void* x, int ty
         if (!g->scratch) g->scratch = new aqg_groupby();
         aqg_groupby* h = g->scratch;
         h->ctx = ctx; h->n = n; h->has_reversemap = false;
-        // two passes through the fast LDS plan (at most four accumulators each) instead of one through the generic five-accumulator kernel:
-        // {sum x, sum x*x, sum y, sum y*y} over the two columns, then {sum xy} over the product column
-        if (!g->scratch2) g->scratch2 = new aqg_groupby();
-        aqg_groupby* h2 = g->scratch2;
-        h2->ctx = ctx; h2->n = n; h2->has_reversemap = false;
-        const int ops[4] = {AQG_RED_SUM, AQG_RED_SUMSQ, AQG_RED_SUM, AQG_RED_SUMSQ};
-        const int dts[4] = {tx, tx, ty, ty};
-        const void* vals[4] = {x, x, y, y};
-        const int op5 = AQG_RED_SUM;
-        const void* v5 = xy;
-        Plan plan, plan2;
-        if (rc == AQG_OK) rc = make_plan(ctx, 4, ops, dts, vals, n, &plan);
-        if (rc == AQG_OK) rc = run_with_retry(ctx, ks, plan, n, G, false, h, nullptr, nullptr);
-        if (rc == AQG_OK) rc = make_plan(ctx, 1, &op5, &pt, &v5, n, &plan2);
-        if (rc == AQG_OK) rc = run_with_retry(ctx, ks, plan2, n, G, false, h2, nullptr, nullptr);
-        if (rc == AQG_OK && (h->ngroups != G || h2->ngroups != G)) rc = aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_corr: group ids are not dense");
+        // up to 3072 groups: two passes through the fast LDS plan (at most four accumulators each) -- {sum x, sum x*x, sum y, sum y*y} over
+        // the two columns, then {sum xy} over the product column.  Beyond (h2o Q9: 1e4 groups): five single-accumulator passes -- four
+        // accumulators per slot push a 1e4-slot table out of LDS (dense plan, three passes over the rows: 19.5 ms per 1e9 rows) while one
+        // accumulator streams at 1.45 ms per pass
+        void* sums = nullptr;                      // [5][G] 128-bit sums, copied out of the scratch handle pass by pass
+        size_t sums_cap = 0;
+        sums = aqg_pool_take(ctx, (size_t)G * 80 + 64, &sums_cap);
+        if (!sums) { sums_cap = (size_t)G * 80 + 64; if (hipMalloc(&sums, sums_cap) != hipSuccess) { (void)hipGetLastError(); sums = nullptr; rc = aqg_fail(ctx, AQG_ERR_NOMEM, "aqg_grouped_corr: sums"); } }
+        const int ops5[5] = {AQG_RED_SUM, AQG_RED_SUMSQ, AQG_RED_SUM, AQG_RED_SUMSQ, AQG_RED_SUM};
+        const int dts5[5] = {tx, tx, ty, ty, pt};
+        const void* vals5[5] = {x, x, y, y, xy};
+        auto slot = [&](int j) { return static_cast<char*>(sums) + (size_t)j * G * 16; };
+        auto pass = [&](int first, int count) -> int {
+            Plan plan;
+            AQG_TRY(make_plan(ctx, count, ops5 + first, dts5 + first, vals5 + first, n, &plan));
+            AQG_TRY(run_with_retry(ctx, ks, plan, n, G, false, h, nullptr, nullptr));
+            if (h->ngroups != G) return aqg_fail(ctx, AQG_ERR_ARG, "aqg_grouped_corr: group ids are not dense");
+            for (int j = 0; j < count; ++j) AQG_HIP(ctx, hipMemcpyAsync(slot(first + j), h->results[j], (size_t)G * 16, hipMemcpyDeviceToDevice, ctx->stream));
+            return AQG_OK;
+        };
         if (rc == AQG_OK) {
-            hipLaunchKernelGGL(corr_final_kernel, dim3(aqg_grid(ctx, G, 256, 1, 8)), dim3(256), 0, ctx->stream, (const aqg_i128*)h->results[0], (const aqg_i128*)h->results[1],
-                               (const aqg_i128*)h->results[2], (const aqg_i128*)h->results[3], (const aqg_i128*)h2->results[0], g->counts, G, out_dev);
+            if (G <= 3072) { rc = pass(0, 4); if (rc == AQG_OK) rc = pass(4, 1); }
+            else for (int j = 0; j < 5 && rc == AQG_OK; ++j) rc = pass(j, 1);
+        }
+        if (rc == AQG_OK) {
+            hipLaunchKernelGGL(corr_final_kernel, dim3(aqg_grid(ctx, G, 256, 1, 8)), dim3(256), 0, ctx->stream, (const aqg_i128*)slot(0), (const aqg_i128*)slot(1),
+                               (const aqg_i128*)slot(2), (const aqg_i128*)slot(3), (const aqg_i128*)slot(4), g->counts, G, out_dev);
             rc = aqg_check_launch(ctx, "corr_final_kernel");
         }
+        if (sums) aqg_pool_give(ctx, sums, sums_cap);
     }
     aqg_pool_give(ctx, xy, cap);           // (stream-ordered reuse: every later user of the buffer runs on this stream)
     return rc;
