@@ -1359,7 +1359,11 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         h->plan_bits = (use_wpart ? AQG_PLAN_PART_WIDE : p1_bins ? AQG_PLAN_PART_ONE : p2_parts ? AQG_PLAN_PART_TWO : AQG_PLAN_PART_ROUND1) | (sorted_tail ? AQG_PLAN_SORTED_TAIL : 0u);
         if (use_wpart) AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed, hint));
         else if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap, for_build ? &prows : nullptr));
-        else if (p2_parts) AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap, for_build ? &prows : nullptr));
+        else if (p2_parts) {
+            int pack = h->no_pack ? 0 : 1;
+            AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap, for_build ? &prows : nullptr, &pack));
+            if (pack) h->plan_bits |= AQG_PLAN_PACKED_VALUES;
+        }
         else AQG_TRY(aqg_partition_aggregate(ctx, ks, as, n, pbits, part_lcap, plan.need_count, gt, gcap));
         if (sorted_tail) ctx->ws_off = mark;       // stream order: whatever is allocated there next is written after these kernels
         else hipLaunchKernelGGL(occ_iota_kernel, dim3(aqg_grid(ctx, slots, 256, 1, 8)), dim3(256), 0, ctx->stream, occ, (uint32_t)slots);
@@ -1405,7 +1409,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
     // ---- dense ids ---------------------------------------------------------------------------------
     unsigned cgrid = aqg_grid(ctx, slots, 256, 1, 8);
     if (!(n && (use_part || use_wpart))) hipLaunchKernelGGL(collect_kernel, dim3(cgrid), dim3(256), 0, ctx->stream, gt, occ);
-    uint32_t fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // [0] overflow, [1] occupied slots, [3] a row outside the sampled key ranges, [4], [5] diagnostics
+    uint32_t fl[8] = {0, 0, 0, 0, 0, 0, 0, 0};        // [0] overflow, [1] occupied slots, [3] a row outside the sampled key ranges, [4], [5] diagnostics, [6] a value outside its packed field
     uint32_t G = 0;
     auto judge_flags = [&]() -> int {
         if (dense && fl[3]) { h->dense_exact = true; h->range_valid = false; return AQG_ERR_RANGE_MISS; }
@@ -1418,6 +1422,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
             if (h->wide_seed == 0 && fl[5] && fl[5] <= rcap + rcap / 2) h->wide_seed = 0x5BD1E995u; else h->no_wide_part = true;
             return AQG_ERR_RANGE_MISS;
         }
+        if (use_part && fl[6]) { h->no_pack = true; return AQG_ERR_RANGE_MISS; }     // a value outside the sampled range of its packed field: once more, unpacked
         if (fl[0]) return AQG_ERR_OVERFLOW;
         G = fl[1];
         if (small_rank && G > 4096) return AQG_ERR_OVERFLOW;

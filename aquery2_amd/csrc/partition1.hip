@@ -17,6 +17,7 @@
 
 #include "groupby_dev.hpp"
 #include "partition1.hpp"
+#include "dense.hpp"
 
 namespace {
 
@@ -51,13 +52,19 @@ template <bool FULL, class T, int R> __device__ inline void load_rows(const T* _
 // from one half of a column of 8-byte elements (stride 2 dwords), or made from the row index, and written at a dword stride.
 // The key is one column of key words (4 or 8 bytes): tuples of several columns and 1- / 2-byte values are packed / widened into
 // such columns first (p1_pack_keys_kernel, p1_widen_kernel).
-enum : int { PL_LOAD = 0, PL_ROWIDX = 1 };
+enum : int { PL_LOAD = 0, PL_ROWIDX = 1, PL_PACK = 2 };
 struct Plane {
     const uint32_t* src; int src_stride_dw; int src_off_dw;
     uint32_t* dst; int dst_stride_dw; int dst_off_dw;
     int kind;
 };
-struct Planes { int n; Plane p[MAXPL]; };
+// Narrow integer value columns travelling INSIDE the 4-byte key word (h2o: id6 < 2^24 leaves eight bits; v1 in 1..5 and v2 in 1..15 need
+// seven): the first level's key plane is made as key | (v - min) << shift per field (PL_PACK), every later user of the word masks the
+// fields off before hashing / comparing and the aggregation unpacks them -- Q5 moves three planes per level instead of five, Q7 two
+// instead of four.  Ranges come from a sample of the rows; every row is verified while it is packed and a miss fails the call over to
+// the unpacked plan (`flag`).
+struct PackSpec { int n; const uint32_t* src[2]; uint32_t min[2], shift[2], fmask[2]; uint32_t kmax; uint32_t* flag; };
+struct Planes { int n; Plane p[MAXPL]; PackSpec pk; };
 
 // Chunks of whole tiles cover rows [0, nfull); the rows behind the last whole tile, if any, are one more chunk (the TAIL chunk,
 // index nchunks - 1), scattered by its own small kernel so that the main kernel never sees a partial tile.
@@ -226,7 +233,11 @@ __global__ void __launch_bounds__(SB) p1_scatter_tail_kernel(const key_t_<K64>* 
 }
 
 // ---- aggregate each partition in LDS ---------------------------------------------------------------------------------------------
-struct AggIn { const void* col[MAXACC]; int esz[MAXACC]; };   // partitioned value arrays (4- or 8-byte elements); null: the row id
+struct AggIn {
+    const void* col[MAXACC]; int esz[MAXACC];    // partitioned value arrays (4- or 8-byte elements); null: the row id, or a packed field
+    int packed[MAXACC]; uint32_t pshift[MAXACC], pmask[MAXACC], pmin[MAXACC];   // the operand is a field of the key word: ((key >> pshift) & pmask) + pmin
+    uint32_t kclear;                             // the packed fields' bits of the key word (0: none)
+};
 constexpr uint32_t ID_PENDING = 0xFFFFu, ID_OVER = 0xFFFEu;
 
 __device__ inline uint64_t val_operand_bits(int dt, uint64_t bits, int kind, int square, int part) {
@@ -281,7 +292,7 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
         __builtin_memcpy(t.key, static_cast<const K*>(rkeys) + o, sizeof t.key);
         __builtin_memcpy(t.row, rrows + o, sizeof t.row);
         _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
-            if (!in.col[a]) continue;                            // row-index operand: the carried row id, taken at the use (a copy here would wait for the row load)
+            if (!in.col[a]) continue;                            // row-index operand (the carried row id) or a field of the key word: taken at the use (a copy here would wait for the load)
             if (!V8 || in.esz[a] == 4) {
                 uint32_t w[AR];
                 __builtin_memcpy(w, static_cast<const uint32_t*>(in.col[a]) + o, sizeof w);
@@ -332,6 +343,11 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
             const uint32_t o = i0 + threadIdx.x * AR;
             uint32_t slot[AR];
             K w[AR];
+            K raw[AR];                                                    // the key word as it travelled (value fields included)
+            if constexpr (!K64) {
+#pragma unroll
+                for (int q = 0; q < AR; ++q) { raw[q] = cur.key[q]; cur.key[q] &= ~in.kclear; }
+            }
 #pragma unroll
             for (int q = 0; q < AR; ++q) { slot[q] = __umulhi(key_hash<K64>(cur.key[q]) * NB, cap); w[q] = ktab[slot[q]]; }   // AR probes in flight
             uint32_t pend = 0, special = 0;
@@ -383,7 +399,8 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
             }
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
                 uint64_t* acc = lacc + (size_t)a * gmax;
-#define AQG_ROWS(expr) _Pragma("unroll") for (int q = 0; q < AR; ++q) if (ok[q]) { const VT x = in.col[a] ? cur.v[a][q] : (VT)cur.row[q]; (void)x; expr; } break
+#define AQG_ROWS(expr) _Pragma("unroll") for (int q = 0; q < AR; ++q) if (ok[q]) { VT x = in.col[a] ? cur.v[a][q] : (VT)cur.row[q]; \
+                if constexpr (!K64) { if (in.packed[a]) x = (VT)((((uint32_t)raw[q] >> in.pshift[a]) & in.pmask[a]) + in.pmin[a]); } (void)x; expr; } break
                 switch (ops.opc[a]) {
                 case OPC_ADDI_I32: AQG_ROWS(atomicAdd(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(long long)(int32_t)(uint32_t)x));
                 case OPC_ADDI_U32: AQG_ROWS(atomicAdd(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(uint32_t)x));
@@ -443,6 +460,7 @@ struct P2Level {
     const uint32_t* tile_prefix;  // [nseg + 1] first tile of every segment
     uint32_t* cursor;             // write cursors: level 1 [B1], level 2 [P]
     uint32_t nseg, P, shift, mask, nbins, cursor_per_seg;
+    uint32_t kclear;              // bits of the key word that are not key (packed value fields): cleared before hashing (0: none)
 };
 
 template <int TB> __device__ inline uint32_t trow(int r) { return (uint32_t)(r >> 2) * (TB * 4) + threadIdx.x * 4 + (r & 3); }
@@ -511,7 +529,7 @@ __global__ void __launch_bounds__(1024) p2_setup_kernel(const uint32_t* __restri
 }
 
 // FULL: grid over all tiles of all segments, whole tiles only.  !FULL: one workgroup per segment takes its last, partial tile.
-template <int TB, int TR, bool K64, bool FULL, bool HASHED = true>
+template <int TB, int TR, bool K64, bool FULL, bool HASHED = true, bool PACK = false>
 __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 64 / 4 : 1) p2_scatter_kernel(const key_t_<K64>* __restrict__ keys, Planes pl, P2Level lv) {
     constexpr int TPT = TB * TR;
     constexpr int HH = TR < 16 ? TR : 16;
@@ -546,7 +564,7 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < HH; ++r) {
-            const uint32_t d = (__umulhi(HASHED ? key_hash<K64>(key[r]) : (uint32_t)key[r], lv.P) >> lv.shift) & lv.mask;
+            const uint32_t d = (__umulhi(HASHED ? key_hash<K64>(K64 ? key[r] : (key_t_<K64>)((uint32_t)key[r] & ~lv.kclear)) : (uint32_t)key[r], lv.P) >> lv.shift) & lv.mask;
             pos[h + r] = FULL || trow<TB>(h + r) < nrows ? (d << 15) | atomicAdd(&lb[d], 1u) : 0xFFFFFFFFu;
         }
     }
@@ -589,6 +607,18 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
             if (Q.kind == PL_ROWIDX) {
 #pragma unroll
                 for (int r = 0; r < HH; ++r) v[r] = rb + trow<TB>(h + r);
+            } else if (PACK && Q.kind == PL_PACK) {    // the key word with the narrow value columns in its spare bits, every row verified
+                load_rows_t<TB, FULL>(Q.src, rb, nrows, h, v);
+                uint32_t bad = 0;
+#pragma unroll
+                for (int r = 0; r < HH; ++r) bad |= v[r] > pl.pk.kmax ? 1u : 0u;
+                for (int f = 0; f < pl.pk.n; ++f) {
+                    uint32_t x[HH];
+                    load_rows_t<TB, FULL>(pl.pk.src[f], rb, nrows, h, x);
+#pragma unroll
+                    for (int r = 0; r < HH; ++r) { const uint32_t y = x[r] - pl.pk.min[f]; bad |= y > pl.pk.fmask[f] ? 1u : 0u; v[r] |= (y & pl.pk.fmask[f]) << pl.pk.shift[f]; }
+                }
+                if (bad) *pl.pk.flag = 1u;               // (rows beyond a partial tile repeat its last row: no false alarm)
             } else if (Q.src_stride_dw == 1) {
                 load_rows_t<TB, FULL>(Q.src, rb, nrows, h, v);
             } else {                                   // one dword of every element of a wider record (halves of 8-byte columns, fields of AoS records)
@@ -908,13 +938,58 @@ static void p1_val_cols(const AccSpec& as, ValCols* vc) {
 }
 static bool p1_key_is_column(const KeySpec& ks, int ksz) { return ks.nkeys == 1 && (int)aqg_dtype_size(ks.dt[0]) == ksz; }
 
+// which value columns travel inside the key word (PackSpec): one 4-byte integer key column whose sampled maximum leaves spare bits, 4-byte
+// integer value columns whose sampled range fits them (at most two), every accumulator over such a column a plain sum / min / max / square
+struct PackPlan { int n; const void* col[2]; uint32_t min[2], shift[2], fmask[2]; uint32_t kmax, kclear; };
+static int plan_pack(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, const ValCols& vc, PackPlan* pp) {
+    memset(pp, 0, sizeof *pp);
+    static const bool off = getenv("AQG_DISABLE_PACK") != nullptr;           // A/B measurements only
+    if (off || n < (1u << 22) || !p1_key_is_column(ks, 4) || !(ks.dt[0] == AQG_INT32 || ks.dt[0] == AQG_UINT32) || vc.n == 0) return AQG_OK;
+    KeySpec probe;
+    memset(&probe, 0, sizeof probe);
+    probe.nkeys = 1; probe.dt[0] = ks.dt[0]; probe.col[0] = ks.col[0];
+    int cand[MAXACC], nc = 0;
+    for (int u = 0; u < vc.n && probe.nkeys < MAXKEYS; ++u) {
+        if (!(vc.dt[u] == AQG_INT32 || vc.dt[u] == AQG_UINT32)) continue;
+        bool ok = true;
+        for (int a = 0; a < as.nacc; ++a) if (as.col[a] == vc.col[u] && as.dt[a] != AQG_NONE) ok = ok && as.part[a] == 0 && (as.kind[a] == ACC_ADD_I || as.kind[a] == ACC_MIN || as.kind[a] == ACC_MAX);
+        if (!ok) continue;
+        probe.dt[probe.nkeys] = vc.dt[u]; probe.col[probe.nkeys] = vc.col[u]; ++probe.nkeys;
+        cand[nc++] = u;
+    }
+    if (!nc) return AQG_OK;
+    long long mins[MAXKEYS], maxs[MAXKEYS];
+    bool ok = false;
+    AQG_TRY(aqg_key_ranges(ctx, probe, 1u << 20, mins, maxs, &ok));          // (a sample: every row is verified while it is packed)
+    if (!ok || mins[0] < 0 || maxs[0] >= (1ll << 31)) return AQG_OK;
+    auto bits_of = [](unsigned long long v) { int b = 0; while (b < 33 && (1ull << b) <= v) ++b; return b; };
+    int used = bits_of((unsigned long long)maxs[0]);
+    if (used < 1) used = 1;
+    pp->kmax = (uint32_t)((1ull << used) - 1);
+    for (int i = 0; i < nc && pp->n < 2; ++i) {
+        const unsigned long long range = (unsigned long long)(maxs[1 + i] - mins[1 + i]);
+        const int fb = bits_of(range) < 1 ? 1 : bits_of(range);
+        if (used + fb > 32) continue;
+        const int f = pp->n++;
+        pp->col[f] = vc.col[cand[i]]; pp->min[f] = (uint32_t)(long long)mins[1 + i]; pp->shift[f] = (uint32_t)used; pp->fmask[f] = (uint32_t)((1ull << fb) - 1);
+        pp->kclear |= pp->fmask[f] << used;
+        used += fb;
+    }
+    return AQG_OK;
+}
+static int pack_field_of(const PackPlan& pp, const void* col) { for (int f = 0; f < pp.n; ++f) if (pp.col[f] == col) return f; return -1; }
+
 // aggregate the partitions [pstart[p * pstride], pstart[(p + 1) * pstride]) (the last one ends at n) of the partitioned planes
 static int p1_launch_agg(aqg_ctx* ctx, int ksz, const AccSpec& as, const ValCols& vc, const void* pkeys, const void* prows, void* const* pvals,
-                         const uint32_t* pstart, uint32_t pstride, uint32_t nparts, uint32_t n, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr) {
+                         const uint32_t* pstart, uint32_t pstride, uint32_t nparts, uint32_t n, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr,
+                         const PackPlan* pp = nullptr) {
     AggIn in;
     memset(&in, 0, sizeof in);
+    if (pp) in.kclear = pp->kclear;
     for (int a = 0; a < as.nacc; ++a) {
-        if (vc.of_acc[a] >= 0) { in.col[a] = pvals[vc.of_acc[a]]; in.esz[a] = (int)part_val_bytes(vc.dt[vc.of_acc[a]]); }
+        const int f = pp && as.dt[a] != AQG_NONE ? pack_field_of(*pp, as.col[a]) : -1;
+        if (f >= 0) { in.col[a] = nullptr; in.esz[a] = 4; in.packed[a] = 1; in.pshift[a] = pp->shift[f]; in.pmask[a] = pp->fmask[f]; in.pmin[a] = pp->min[f]; }
+        else if (vc.of_acc[a] >= 0) { in.col[a] = pvals[vc.of_acc[a]]; in.esz[a] = (int)part_val_bytes(vc.dt[vc.of_acc[a]]); }
         else { in.col[a] = nullptr; in.esz[a] = 4; }     // row-index operands: the carried row id
     }
     AggOps ops;
@@ -1070,12 +1145,16 @@ size_t aqg_partition2_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
     return ((size_t)n + 64) * per_row + 256 * (8 + 4 * MAXACC) + (size_t)p2_round_parts(parts) * 16 + 65536;
 }
 
-int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr) {
+int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr, int* pack) {
     const uint32_t P = p2_round_parts(parts), B1 = P >> 6;
     if (P < 64 || P > AQG_P2_MAXPARTS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "two-level partitioned group-by: 64..4096 partitions");
     const int ksz = ks.total_bytes <= 4 ? 4 : 8;
     ValCols vc;
     p1_val_cols(as, &vc);
+    PackPlan pp;
+    memset(&pp, 0, sizeof pp);
+    if (pack && *pack && !pr) AQG_TRY(plan_pack(ctx, ks, as, n, vc, &pp));   // narrow value columns inside the key word (fewer planes per level)
+    if (pack) *pack = pp.n;
     const void* keycol = ks.col[0];
     if (!p1_key_is_column(ks, ksz)) {
         void* packed;
@@ -1092,6 +1171,8 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * ksz, &keysB));
     AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * 4, &rowsB));
     for (int u = 0; u < vc.n; ++u) {
+        valsA[u] = valsB[u] = nullptr; vsrc[u] = nullptr;
+        if (pack_field_of(pp, vc.col[u]) >= 0) continue;                     // travels in the key word
         AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * part_val_bytes(vc.dt[u]), &valsA[u]));
         AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * part_val_bytes(vc.dt[u]), &valsB[u]));
         vsrc[u] = vc.col[u];
@@ -1124,10 +1205,16 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         };
         const void* ksrc = level1 ? keycol : keysA;
         void* kdst = level1 ? keysA : keysB;
-        if (ksz == 4) add(PL_LOAD, ksrc, 1, 0, kdst, 1, 0);
+        if (ksz == 4 && pp.n && level1) {
+            add(PL_PACK, ksrc, 1, 0, kdst, 1, 0);
+            pl.pk.n = pp.n; pl.pk.kmax = pp.kmax; pl.pk.flag = out.flags + 6;
+            for (int f = 0; f < pp.n; ++f) { pl.pk.src[f] = static_cast<const uint32_t*>(pp.col[f]); pl.pk.min[f] = pp.min[f]; pl.pk.shift[f] = pp.shift[f]; pl.pk.fmask[f] = pp.fmask[f]; }
+        }
+        else if (ksz == 4) add(PL_LOAD, ksrc, 1, 0, kdst, 1, 0);
         else { add(PL_LOAD, ksrc, 2, 0, kdst, 2, 0); add(PL_LOAD, ksrc, 2, 1, kdst, 2, 1); }
         if (level1) add(PL_ROWIDX, nullptr, 0, 0, rowsA, 1, 0); else add(PL_LOAD, rowsA, 1, 0, rowsB, 1, 0);
         for (int u = 0; u < vc.n; ++u) {
+            if (!valsA[u]) continue;                                          // (packed)
             const void* vs = level1 ? vsrc[u] : valsA[u];
             void* vd = level1 ? valsA[u] : valsB[u];
             if (part_val_bytes(vc.dt[u]) == 4) add(PL_LOAD, vs, 1, 0, vd, 1, 0);
@@ -1145,15 +1232,24 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, K, true>), scat_lds));
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, K, false>), scat_lds));
         P2Level l1{seg1, tp1, cur1, 1u, P, 6u, 0xFFFFFFFFu, B1, 0u};
-        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, true>), dim3(tiles1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keycol), planes(true), l1);
-        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, false>), dim3(1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keycol), planes(true), l1);
-        P2Level l2{seg2, tp2, cur2, B1, P, 0u, 63u, 64u, 64u};
+        if (pp.n && !K) {
+            if constexpr (!K) {
+                AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, true, true, true>), scat_lds));
+                AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, false, true, true>), scat_lds));
+                hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, true, true, true>), dim3(tiles1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const uint32_t*>(keycol), planes(true), l1);
+                hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, false, true, true>), dim3(1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const uint32_t*>(keycol), planes(true), l1);
+            }
+        } else {
+            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, true>), dim3(tiles1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keycol), planes(true), l1);
+            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, false>), dim3(1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keycol), planes(true), l1);
+        }
+        P2Level l2{seg2, tp2, cur2, B1, P, 0u, 63u, 64u, 64u, pp.kclear};
         hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, true>), dim3(tiles2), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keysA), planes(false), l2);
         hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, false>), dim3(B1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keysA), planes(false), l2);
         return aqg_check_launch(ctx, "two-level partition scatter");
     };
     if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
-    return p1_launch_agg(ctx, ksz, as, vc, keysB, rowsB, valsB, fstart, 1u, P, n, need_count, out, out_cap, pr);
+    return p1_launch_agg(ctx, ksz, as, vc, keysB, rowsB, valsB, fstart, 1u, P, n, need_count, out, out_cap, pr, pp.n ? &pp : nullptr);
 }
 
 // ---- wide tuples: host ----------------------------------------------------------------------------------------------------------------

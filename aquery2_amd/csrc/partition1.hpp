@@ -11,7 +11,7 @@ struct PartRows { const void* keys; const uint32_t* rows; const uint32_t* pstart
 size_t aqg_partition1_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t nbins);
 int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr);
 size_t aqg_partition2_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t parts);
-int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr);
+int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr, int* pack = nullptr);   // *pack: in, packing allowed; out, value columns that travelled inside the key word
 // the build's id pass over the partitioned rows: reversemap[row] = dense id of the row's key (slot_gid: record -> dense id)
 int aqg_partition_assign(aqg_ctx* ctx, const PartRows& pr, GTable gt, const uint32_t* slot_gid, uint32_t* reversemap);
 size_t aqg_partition_assign_ws_bytes(uint32_t n);

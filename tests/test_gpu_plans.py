@@ -63,6 +63,30 @@ def test_two_level_partition_plan_forced():
     run_forced({"AQG_P1_MAX": "1"}, PACKED % ("capi.PLAN_PART_TWO", "capi.PLAN_PART_TWO"))
 
 
+PACKVALS = r"""
+n = 4_700_023                                                  # (value packing is planned from 2^22 rows on)
+key = rng.integers(0, 400_000, n).astype(np.int32)
+v1, v2 = rng.integers(1, 6, n).astype(np.int32), rng.integers(-3, 12, n).astype(np.int32)
+v3 = np.round(rng.uniform(0, 100, n), 3).astype(np.float32)
+PT = capi.PLAN_PART_TWO
+check([key], [ck.RED_SUM, ck.RED_SUM, ck.RED_SUM], [v1, v2, v3], 500_000, PT | capi.PLAN_PACKED_VALUES)            # h2o Q5: {key|v1|v2, row, v3}
+check([key], [ck.RED_MAX, ck.RED_MIN, ck.RED_COUNT], [v1, v2, v1], 500_000, PT | capi.PLAN_PACKED_VALUES)          # h2o Q7: no value plane at all
+check([key], [ck.RED_AVG, ck.RED_VAR, ck.RED_MIN], [v2, v1, v2], 500_000, PT | capi.PLAN_PACKED_VALUES)            # sums of squares of a packed field
+wide = v1.copy(); wide[::7] = 1 << 20                          # a range that leaves no room next to the key: travels as its own plane
+check([key], [ck.RED_SUM, ck.RED_SUM], [wide, v2], 500_000, PT | capi.PLAN_PACKED_VALUES)
+late = v1.copy(); late[n - 5] = 77                             # a value outside the range of the sampled first 2^20 rows: caught while packing, the call repeats unpacked
+check([key], [ck.RED_SUM, ck.RED_MAX], [late, late], 500_000, PT)
+bigkey = key.copy(); bigkey[n - 9] = (1 << 30) + 5             # a KEY above the sampled maximum would run into the value fields: caught the same way
+check([bigkey], [ck.RED_SUM, ck.RED_SUM], [v1, v2], 500_000, PT)
+"""
+
+
+def test_two_level_plan_with_narrow_value_columns_inside_the_key_word():
+    """AQG_P1_MAX=1 at >= 2^22 rows: the two-level plan packs 4-byte integer value columns of a small sampled range into the spare bits of a
+    4-byte key word (h2o Q5 / Q7 at 1e9 rows), verifies every row while packing and repeats the call unpacked when a row does not fit"""
+    run_forced({"AQG_P1_MAX": "1"}, PACKVALS)
+
+
 def test_round1_partition_pipeline_forced():
     """AQG_DISABLE_P1=1: the round-1 pipeline of partition.hip (packed keys beyond 4096 partitions at default thresholds): part_* kernels"""
     run_forced({"AQG_DISABLE_P1": "1"}, PACKED % ("capi.PLAN_PART_ROUND1", "capi.PLAN_PART_ROUND1"))
