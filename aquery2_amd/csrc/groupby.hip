@@ -1362,7 +1362,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         else if (p2_parts) {
             int pack = h->no_pack ? 0 : 1;
             AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap, for_build ? &prows : nullptr, &pack));
-            if (pack) h->plan_bits |= AQG_PLAN_PACKED_VALUES;
+            if (pack & 1) h->plan_bits |= AQG_PLAN_PACKED_VALUES;
+            if (pack & 2) h->plan_bits |= AQG_PLAN_RANGE_PARTITIONS;
         }
         else AQG_TRY(aqg_partition_aggregate(ctx, ks, as, n, pbits, part_lcap, plan.need_count, gt, gcap));
         if (sorted_tail) ctx->ws_off = mark;       // stream order: whatever is allocated there next is written after these kernels

@@ -442,6 +442,152 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
 }
 
 
+// ---- the same over a DENSE key domain: no key table at all -------------------------------------------------------------------------
+// When the key is one 4-byte integer column whose values fill their range (h2o id3 / id6: 1 .. 1e7), the two-level plan bins the rows by
+// RANGE -- bin = umulhi(key - kmin, M), order-preserving, so a partition owns a contiguous piece of the domain -- and the aggregation is
+// direct-indexed: acc[key - first key of the partition].  No probe, no compare-and-swap, no dense-id indirection: every LDS operation of a
+// row is a fire-and-forget atomic, nothing in the row loop waits for LDS (the hashed kernel above: three dependent LDS round trips per
+// row, ~1000 instructions per 256 rows; h2o Q5 at 1e9 rows: 5.3 ms for 12 GB).  Rows beyond the end of a partial step and keys outside
+// the partition's piece (only possible when the sampled range missed a value: flagged, the call repeats hashed) go to one dummy entry.
+// LDS: acc u64[NACC][W + 1] | first u32[W + 1] | count u32[W + 1] (need_count); entry W is the dummy.
+struct DirectSpec { uint32_t M, kmin, D, W; uint32_t* miss; };
+template <int NACC, bool V8>
+__global__ void __launch_bounds__(SB) p1_agg_direct_kernel(const uint32_t* __restrict__ rkeys, const uint32_t* __restrict__ rrows, AccSpec as, AggIn in, AggOps ops,
+                                                           const uint32_t* __restrict__ pstart, uint32_t NB, uint32_t ntotal, DirectSpec ds, int need_count,
+                                                           GTable out, uint32_t out_cap) {
+    using VT = std::conditional_t<V8, uint64_t, uint32_t>;
+    constexpr int NA = NACC ? NACC : 1;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const uint32_t W1 = ds.W + 1;
+    uint64_t* lacc = reinterpret_cast<uint64_t*>(smem_raw);                       // [NACC][W1]
+    uint32_t* lfirst = reinterpret_cast<uint32_t*>(lacc + (size_t)NACC * W1);     // [W1]
+    uint32_t* lcount = lfirst + W1;                                               // [W1] (only when need_count)
+    __shared__ uint32_t lused, lemit, gbase;
+    struct Batch { uint32_t key[AR]; uint32_t row[AR]; VT v[NA][AR]; };
+    auto load_full = [&](uint32_t i0, Batch& t) {                                 // (as in p1_agg_kernel: the only form the prefetch uses)
+        const uint32_t o = i0 + threadIdx.x * AR;
+        __builtin_memcpy(t.key, rkeys + o, sizeof t.key);
+        __builtin_memcpy(t.row, rrows + o, sizeof t.row);
+        _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+            if (!in.col[a]) continue;
+            if (!V8 || in.esz[a] == 4) {
+                uint32_t w[AR];
+                __builtin_memcpy(w, static_cast<const uint32_t*>(in.col[a]) + o, sizeof w);
+                _Pragma("unroll") for (int q = 0; q < AR; ++q) t.v[a][q] = w[q];
+            } else {
+                if constexpr (V8) __builtin_memcpy(t.v[a], static_cast<const uint64_t*>(in.col[a]) + o, sizeof(uint64_t) * AR);
+            }
+        }
+    };
+    auto load_edge = [&](uint32_t i0, uint32_t e, Batch& t) {
+        const uint32_t o = i0 + threadIdx.x * AR;
+        _Pragma("unroll") for (int q = 0; q < AR; ++q) {
+            const uint32_t i = o + q < e ? o + q : e - 1;
+            t.key[q] = rkeys[i]; t.row[q] = rrows[i];
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                if (!in.col[a]) continue;
+                if (!V8 || in.esz[a] == 4) t.v[a][q] = static_cast<const uint32_t*>(in.col[a])[i];
+                else if constexpr (V8) t.v[a][q] = static_cast<const uint64_t*>(in.col[a])[i];
+            }
+        }
+    };
+    for (uint32_t part = blockIdx.x; part < NB; part += gridDim.x) {
+        const uint32_t b = pstart[part];
+        const uint32_t e = part + 1 < NB ? pstart[part + 1] : ntotal;
+        if (b == e) continue;
+        // the piece of the domain this partition owns: x in [lo, hi), lo = the smallest x with umulhi(x, M) >= part
+        uint64_t lo64 = (((uint64_t)part << 32) + ds.M - 1) / ds.M, hi64 = ((((uint64_t)part + 1) << 32) + ds.M - 1) / ds.M;
+        if (hi64 > ds.D) hi64 = ds.D;
+        if (lo64 > hi64) lo64 = hi64;
+        const uint32_t lo = (uint32_t)lo64;
+        uint32_t width = (uint32_t)(hi64 - lo64);
+        if (width > ds.W) { if (threadIdx.x == 0) out.flags[0] = 1; continue; }   // (the host sized W for every piece)
+        constexpr uint32_t STEP = SB * AR;
+        const uint32_t nfull = (e - b) / STEP, nsteps = nfull + ((e - b) % STEP ? 1u : 0u);
+        const uint32_t safe_last = nfull ? b + (nfull - 1) * STEP : (b + STEP <= ntotal ? b : ntotal - STEP);
+        Batch cur;
+        load_full(nfull ? b : safe_last, cur);                 // in flight while the arrays are cleared
+        for (uint32_t g = threadIdx.x; g < W1; g += SB) {
+            if (g >= width && g != ds.W) continue;
+            lfirst[g] = NOROW;
+            if (need_count) lcount[g] = 0;
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) lacc[(size_t)a * W1 + g] = acc_init(as.kind[a]);
+        }
+        if (threadIdx.x == 0) { lused = 0; lemit = 0; }
+        __syncthreads();
+        const uint32_t base = ds.kmin + lo;                    // key of entry 0
+        uint32_t miss = 0;
+        uint32_t i0 = b;
+        for (uint32_t st = 0; st < nsteps; ++st) {
+            const bool edge = st >= nfull;
+            if (edge) load_edge(i0, e, cur);
+            Batch nxt;
+            { const uint32_t inext = i0 + STEP; load_full(inext <= safe_last && st + 1 < nfull ? inext : safe_last, nxt); }
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t o = i0 + threadIdx.x * AR;
+            uint32_t id[AR];
+#pragma unroll
+            for (int q = 0; q < AR; ++q) {
+                const uint32_t x = (cur.key[q] & ~in.kclear) - base;
+                const bool live = !edge || o + q < e;
+                miss |= live && x >= width ? 1u : 0u;
+                id[q] = live && x < width ? x : ds.W;
+            }
+#pragma unroll
+            for (int q = 0; q < AR; ++q) atomicMin(&lfirst[id[q]], cur.row[q]);
+            if (need_count) {
+#pragma unroll
+                for (int q = 0; q < AR; ++q) atomicAdd(&lcount[id[q]], 1u);
+            }
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                uint64_t* acc = lacc + (size_t)a * W1;
+                VT x[AR];
+                if (in.packed[a]) { _Pragma("unroll") for (int q = 0; q < AR; ++q) x[q] = (VT)(((cur.key[q] >> in.pshift[a]) & in.pmask[a]) + in.pmin[a]); }
+                else if (in.col[a]) { _Pragma("unroll") for (int q = 0; q < AR; ++q) x[q] = cur.v[a][q]; }
+                else { _Pragma("unroll") for (int q = 0; q < AR; ++q) x[q] = (VT)cur.row[q]; }
+#define AQG_ROWS(expr) _Pragma("unroll") for (int q = 0; q < AR; ++q) { expr; } break
+                switch (ops.opc[a]) {
+                case OPC_ADDI_I32: AQG_ROWS(atomicAdd(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(long long)(int32_t)(uint32_t)x[q]));
+                case OPC_ADDI_U32: AQG_ROWS(atomicAdd(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(uint32_t)x[q]));
+                case OPC_ADDF_F32: AQG_ROWS(atomicAdd(reinterpret_cast<double*>(acc + id[q]), (double)__uint_as_float((uint32_t)x[q])));
+                case OPC_ADDF_F64: AQG_ROWS(atomicAdd(reinterpret_cast<double*>(acc + id[q]), __builtin_bit_cast(double, (uint64_t)x[q])));
+                case OPC_MIN_I32: AQG_ROWS(atomicMin(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)map_i((int32_t)(uint32_t)x[q])));
+                case OPC_MAX_I32: AQG_ROWS(atomicMax(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)map_i((int32_t)(uint32_t)x[q])));
+                case OPC_MIN_U32: AQG_ROWS(atomicMin(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(uint32_t)x[q]));
+                case OPC_MAX_U32: AQG_ROWS(atomicMax(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)(uint32_t)x[q]));
+                case OPC_MIN_F32: AQG_ROWS(atomicMin(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)map_f((double)__uint_as_float((uint32_t)x[q]))));
+                case OPC_MAX_F32: AQG_ROWS(atomicMax(reinterpret_cast<unsigned long long*>(acc + id[q]), (unsigned long long)map_f((double)__uint_as_float((uint32_t)x[q]))));
+                default: AQG_ROWS(acc_apply(acc + id[q], as.kind[a], val_operand_bits(as.dt[a] == AQG_NONE ? AQG_UINT32 : as.dt[a], (uint64_t)x[q], as.kind[a], as.square[a], as.part[a])));
+                }
+#undef AQG_ROWS
+            }
+            cur = nxt;
+            i0 += STEP;
+        }
+        if (miss) *ds.miss = 1u;
+        __syncthreads();
+        // the entries that saw a row become records, reserved with one global atomic per partition
+        uint32_t mine = 0;
+        for (uint32_t j = threadIdx.x; j < width; j += SB) mine += lfirst[j] != NOROW ? 1u : 0u;
+        mine = wave_reduce(mine, OpAdd{});
+        if (lane_id() == 0 && mine) atomicAdd(&lused, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) gbase = atomicAdd(&out.flags[1], lused);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < width; j += SB) {
+            if (lfirst[j] == NOROW) continue;
+            const uint32_t g = gbase + atomicAdd(&lemit, 1u);
+            if (g >= out_cap) { out.flags[0] = 1; continue; }
+            *out.key_p(g) = (uint64_t)(base + j);
+            *out.first_p(g) = lfirst[j];
+            *out.count_p(g) = need_count ? lcount[j] : 0;
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) *out.acc_p(a, g) = lacc[(size_t)a * W1 + j];
+        }
+        __syncthreads();
+    }
+}
+
+
 // ==== two levels (more partitions than one level writes well) ==================================================================
 // The run a tile writes per bin and plane is (LDS staging bytes / bins) long: 3000 bins leave 44-byte runs, and partial lines are
 // what the memory system charges for (measured at 1e9 rows, 5 planes: the one-level scatter takes 8.0 ms at 64 bins, 10.6 at 256,
@@ -461,7 +607,11 @@ struct P2Level {
     uint32_t* cursor;             // write cursors: level 1 [B1], level 2 [P]
     uint32_t nseg, P, shift, mask, nbins, cursor_per_seg;
     uint32_t kclear;              // bits of the key word that are not key (packed value fields): cleared before hashing (0: none)
+    uint32_t kmin, xmax;          // BIN_RANGED: the bin is umulhi(key - kmin, P) -- order-preserving bins over a dense key domain
+    uint32_t* flag;               // BIN_RANGED: set when a key lies outside [kmin, kmin + xmax] (the range came from a sample)
 };
+// how a key word becomes a bin: BIN_RAW umulhi(word, P) (dense group ids, row ids), BIN_HASHED umulhi(hash(word), P), BIN_RANGED
+enum : int { BIN_RAW = 0, BIN_HASHED = 1, BIN_RANGED = 2 };
 
 template <int TB> __device__ inline uint32_t trow(int r) { return (uint32_t)(r >> 2) * (TB * 4) + threadIdx.x * 4 + (r & 3); }
 template <int TB, bool FULL, class T, int R> __device__ inline void load_rows_t(const T* __restrict__ p, size_t tile_first, uint32_t nrows, int r0, T (&t)[R]) {
@@ -476,11 +626,11 @@ template <int TB, bool FULL, class T, int R> __device__ inline void load_rows_t(
 }
 
 constexpr int HB = 16;    // rows per thread and step of the fine histogram
-template <bool K64>
-__global__ void __launch_bounds__(1024) p2_hist_kernel(const key_t_<K64>* __restrict__ keys, uint32_t n, uint32_t P, uint32_t* __restrict__ ftot) {
+template <bool K64, bool RANGED = false>
+__global__ void __launch_bounds__(1024) p2_hist_kernel(const key_t_<K64>* __restrict__ keys, uint32_t n, uint32_t P, uint32_t* __restrict__ ftot, uint32_t kmin = 0, uint32_t xmax = 0) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);
-    for (uint32_t b = threadIdx.x; b < P; b += 1024) cnt[b] = 0;
+    for (uint32_t b = threadIdx.x; b < (RANGED ? __umulhi(xmax, P) + 1 : P); b += 1024) cnt[b] = 0;
     __syncthreads();
     const uint64_t step = (uint64_t)1024 * HB;
     for (uint64_t rb = (uint64_t)blockIdx.x * step; rb < n; rb += (uint64_t)gridDim.x * step) {
@@ -488,10 +638,17 @@ __global__ void __launch_bounds__(1024) p2_hist_kernel(const key_t_<K64>* __rest
         key_t_<K64> key[HB];
         if (nrows == step) load_rows_t<1024, true>(keys, rb, nrows, 0, key); else load_rows_t<1024, false>(keys, rb, nrows, 0, key);
 #pragma unroll
-        for (int r = 0; r < HB; ++r) if (trow<1024>(r) < nrows) atomicAdd(&cnt[__umulhi(key_hash<K64>(key[r]), P)], 1u);
+        for (int r = 0; r < HB; ++r) {
+            if (!(trow<1024>(r) < nrows)) continue;
+            uint32_t h;
+            if constexpr (RANGED) { h = (uint32_t)key[r] - kmin; h = h < xmax ? h : xmax; }       // (a key outside the sampled range: the scatter flags it)
+            else h = key_hash<K64>(key[r]);
+            atomicAdd(&cnt[__umulhi(h, P)], 1u);
+        }
     }
     __syncthreads();
-    for (uint32_t b = threadIdx.x; b < P; b += 1024) { const uint32_t c = cnt[b]; if (c) atomicAdd(&ftot[b], c); }
+    const uint32_t nb = RANGED ? __umulhi(xmax, P) + 1 : P;                                        // (RANGED: P is the multiplier, not the bin count)
+    for (uint32_t b = threadIdx.x; b < nb; b += 1024) { const uint32_t c = cnt[b]; if (c) atomicAdd(&ftot[b], c); }
 }
 
 // one workgroup: fstart = exclusive scan of the P partition sizes (P <= 4096); segments, tile counts and cursors of both levels
@@ -529,7 +686,7 @@ __global__ void __launch_bounds__(1024) p2_setup_kernel(const uint32_t* __restri
 }
 
 // FULL: grid over all tiles of all segments, whole tiles only.  !FULL: one workgroup per segment takes its last, partial tile.
-template <int TB, int TR, bool K64, bool FULL, bool HASHED = true, bool PACK = false>
+template <int TB, int TR, bool K64, bool FULL, int MODE = BIN_HASHED, bool PACK = false>
 __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 64 / 4 : 1) p2_scatter_kernel(const key_t_<K64>* __restrict__ keys, Planes pl, P2Level lv) {
     constexpr int TPT = TB * TR;
     constexpr int HH = TR < 16 ? TR : 16;
@@ -557,6 +714,7 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
     if (threadIdx.x <= 128) lb[threadIdx.x] = 0;
     __syncthreads();
     uint32_t pos[TR];                                         // (bin << 15) | rank, later the staged position
+    uint32_t outside = 0;
 #pragma unroll
     for (int h = 0; h < TR; h += HH) {
         key_t_<K64> key[HH];
@@ -564,10 +722,15 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < HH; ++r) {
-            const uint32_t d = (__umulhi(HASHED ? key_hash<K64>(K64 ? key[r] : (key_t_<K64>)((uint32_t)key[r] & ~lv.kclear)) : (uint32_t)key[r], lv.P) >> lv.shift) & lv.mask;
+            uint32_t hw;
+            if constexpr (MODE == BIN_HASHED) hw = key_hash<K64>(K64 ? key[r] : (key_t_<K64>)((uint32_t)key[r] & ~lv.kclear));
+            else if constexpr (MODE == BIN_RANGED) { hw = ((uint32_t)key[r] & ~lv.kclear) - lv.kmin; outside |= hw > lv.xmax ? 1u : 0u; hw = hw < lv.xmax ? hw : lv.xmax; }
+            else hw = (uint32_t)key[r];
+            const uint32_t d = (__umulhi(hw, lv.P) >> lv.shift) & lv.mask;
             pos[h + r] = FULL || trow<TB>(h + r) < nrows ? (d << 15) | atomicAdd(&lb[d], 1u) : 0xFFFFFFFFu;
         }
     }
+    if constexpr (MODE == BIN_RANGED) { if (outside) *lv.flag = 1u; }     // (rows beyond a partial tile repeat its last row: no false alarm)
     __syncthreads();
     {   // first two wavefronts: exclusive scan of the bin counts; reserve this tile's run of every bin with one atomic per bin
         uint32_t c = 0, incl = 0;
@@ -940,16 +1103,16 @@ static bool p1_key_is_column(const KeySpec& ks, int ksz) { return ks.nkeys == 1 
 
 // which value columns travel inside the key word (PackSpec): one 4-byte integer key column whose sampled maximum leaves spare bits, 4-byte
 // integer value columns whose sampled range fits them (at most two), every accumulator over such a column a plain sum / min / max / square
-struct PackPlan { int n; const void* col[2]; uint32_t min[2], shift[2], fmask[2]; uint32_t kmax, kclear; };
+struct PackPlan { int n; const void* col[2]; uint32_t min[2], shift[2], fmask[2]; uint32_t kmax, kclear; bool have_range; long long key_lo, key_hi; };
 static int plan_pack(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, const ValCols& vc, PackPlan* pp) {
     memset(pp, 0, sizeof *pp);
     static const bool off = getenv("AQG_DISABLE_PACK") != nullptr;           // A/B measurements only
-    if (off || n < (1u << 22) || !p1_key_is_column(ks, 4) || !(ks.dt[0] == AQG_INT32 || ks.dt[0] == AQG_UINT32) || vc.n == 0) return AQG_OK;
+    if (n < (1u << 22) || !p1_key_is_column(ks, 4) || !(ks.dt[0] == AQG_INT32 || ks.dt[0] == AQG_UINT32)) return AQG_OK;
     KeySpec probe;
     memset(&probe, 0, sizeof probe);
     probe.nkeys = 1; probe.dt[0] = ks.dt[0]; probe.col[0] = ks.col[0];
     int cand[MAXACC], nc = 0;
-    for (int u = 0; u < vc.n && probe.nkeys < MAXKEYS; ++u) {
+    for (int u = 0; u < vc.n && probe.nkeys < MAXKEYS && !off; ++u) {
         if (!(vc.dt[u] == AQG_INT32 || vc.dt[u] == AQG_UINT32)) continue;
         bool ok = true;
         for (int a = 0; a < as.nacc; ++a) if (as.col[a] == vc.col[u] && as.dt[a] != AQG_NONE) ok = ok && as.part[a] == 0 && (as.kind[a] == ACC_ADD_I || as.kind[a] == ACC_MIN || as.kind[a] == ACC_MAX);
@@ -957,11 +1120,12 @@ static int plan_pack(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_
         probe.dt[probe.nkeys] = vc.dt[u]; probe.col[probe.nkeys] = vc.col[u]; ++probe.nkeys;
         cand[nc++] = u;
     }
-    if (!nc) return AQG_OK;
     long long mins[MAXKEYS], maxs[MAXKEYS];
     bool ok = false;
-    AQG_TRY(aqg_key_ranges(ctx, probe, 1u << 20, mins, maxs, &ok));          // (a sample: every row is verified while it is packed)
-    if (!ok || mins[0] < 0 || maxs[0] >= (1ll << 31)) return AQG_OK;
+    AQG_TRY(aqg_key_ranges(ctx, probe, 1u << 20, mins, maxs, &ok));          // (a sample: every row is verified while it is packed / binned)
+    if (!ok) return AQG_OK;
+    pp->have_range = true; pp->key_lo = mins[0]; pp->key_hi = maxs[0];
+    if (!nc || mins[0] < 0 || maxs[0] >= (1ll << 31)) return AQG_OK;
     auto bits_of = [](unsigned long long v) { int b = 0; while (b < 33 && (1ull << b) <= v) ++b; return b; };
     int used = bits_of((unsigned long long)maxs[0]);
     if (used < 1) used = 1;
@@ -977,13 +1141,14 @@ static int plan_pack(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_
     }
     return AQG_OK;
 }
+// Range partitions over a dense key domain (p1_agg_direct_kernel): the sampled domain [key_lo, key_hi] cut into P pieces of at most W key
+// values, P a multiple of 64 within the two-level plan's limits.  The slack on both ends (a sample of the first 2^20 rows rarely sees the
+// extremes of the column) costs nothing: empty pieces of the domain are empty partitions.
 static int pack_field_of(const PackPlan& pp, const void* col) { for (int f = 0; f < pp.n; ++f) if (pp.col[f] == col) return f; return -1; }
 
 // aggregate the partitions [pstart[p * pstride], pstart[(p + 1) * pstride]) (the last one ends at n) of the partitioned planes
-static int p1_launch_agg(aqg_ctx* ctx, int ksz, const AccSpec& as, const ValCols& vc, const void* pkeys, const void* prows, void* const* pvals,
-                         const uint32_t* pstart, uint32_t pstride, uint32_t nparts, uint32_t n, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr,
-                         const PackPlan* pp = nullptr) {
-    AggIn in;
+static void p1_agg_args(const AccSpec& as, const ValCols& vc, void* const* pvals, const PackPlan* pp, AggIn* inp, AggOps* opsp, bool* v8p) {
+    AggIn& in = *inp;
     memset(&in, 0, sizeof in);
     if (pp) in.kclear = pp->kclear;
     for (int a = 0; a < as.nacc; ++a) {
@@ -992,7 +1157,7 @@ static int p1_launch_agg(aqg_ctx* ctx, int ksz, const AccSpec& as, const ValCols
         else if (vc.of_acc[a] >= 0) { in.col[a] = pvals[vc.of_acc[a]]; in.esz[a] = (int)part_val_bytes(vc.dt[vc.of_acc[a]]); }
         else { in.col[a] = nullptr; in.esz[a] = 4; }     // row-index operands: the carried row id
     }
-    AggOps ops;
+    AggOps& ops = *opsp;
     memset(&ops, 0, sizeof ops);
     bool v8 = false;
     for (int a = 0; a < as.nacc; ++a) {
@@ -1007,6 +1172,70 @@ static int p1_launch_agg(aqg_ctx* ctx, int ksz, const AccSpec& as, const ValCols
         ops.opc[a] = opc;
         v8 = v8 || in.esz[a] == 8;
     }
+    *v8p = v8;
+}
+
+// the direct-indexed aggregation over range partitions (p1_agg_direct_kernel)
+struct RangePlan { bool on; uint32_t kmin, D, P, M, W; };
+static uint32_t p1_direct_capacity(const AccSpec& as, int need_count) {
+    const size_t per = 4 + (need_count ? 4 : 0) + 8 * (size_t)as.nacc;
+    size_t w = (AGG_LDS - 64) / per;
+    if (w > 32768) w = 32768;
+    return (uint32_t)w - 1;                        // (one entry is the dummy)
+}
+static void plan_range(const PackPlan& pp, const AccSpec& as, int need_count, uint32_t parts_hashed, RangePlan* rp) {
+    memset(rp, 0, sizeof *rp);
+    static const bool off = getenv("AQG_DISABLE_RANGED") != nullptr;         // A/B measurements only
+    if (off || !pp.have_range || pp.key_hi < pp.key_lo) return;
+    const long long span = pp.key_hi - pp.key_lo + 1, slack = span / 64 + 1024;
+    // (the key column is int32 or uint32: its values as 64-bit integers; the bins work on the 32-bit difference to kmin, which wraps correctly)
+    const long long lo = pp.key_lo - slack, hi = pp.key_hi + slack;
+    const unsigned long long D = (unsigned long long)(hi - lo + 1);
+    if (D >= (1ull << 32)) return;
+    const uint32_t W = p1_direct_capacity(as, need_count);
+    if (W < 64) return;
+    uint64_t P = (D + (W - 4) - 1) / (W - 4);
+    if (P < 256) P = 256;                                                     // every CU gets a partition
+    P = (P + 63) & ~63ull;
+    for (; P <= AQG_P2_MAXPARTS; P += 64) {
+        if (D <= 8 * P) return;                                               // (a domain this small is not this plan's business)
+        const uint64_t M = (P << 32) / D;                                     // umulhi(x, M) < P for every x < D
+        if (M < 1 || M >= (1ull << 32)) return;
+        if ((1ull << 32) / M + 2 <= W) { rp->on = true; rp->kmin = (uint32_t)lo; rp->D = (uint32_t)D; rp->P = (uint32_t)P; rp->M = (uint32_t)M; rp->W = W; return; }
+    }
+    (void)parts_hashed;
+}
+static int p1_launch_agg_direct(aqg_ctx* ctx, const AccSpec& as, const ValCols& vc, const void* pkeys, const void* prows, void* const* pvals,
+                                const uint32_t* pstart, uint32_t n, int need_count, GTable out, uint32_t out_cap, const PackPlan* pp, const RangePlan& rp) {
+    AggIn in; AggOps ops; bool v8;
+    p1_agg_args(as, vc, pvals, pp, &in, &ops, &v8);
+    const size_t lds = (size_t)(rp.W + 1) * (4 + (need_count ? 4 : 0) + 8 * (size_t)as.nacc) + 16;
+    const unsigned grid = rp.P < (unsigned)ctx->num_cu ? rp.P : (unsigned)ctx->num_cu;
+    DirectSpec ds{rp.M, rp.kmin, rp.D, rp.W, out.flags + 6};
+    auto launch = [&](auto kern) -> int {
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
+        aqg_kernel_timer_begin(ctx);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SB), lds, ctx->stream, static_cast<const uint32_t*>(pkeys), static_cast<const uint32_t*>(prows), as, in, ops, pstart, rp.P, n, ds, need_count, out, out_cap);
+        aqg_kernel_timer_end(ctx);
+        return aqg_check_launch(ctx, "p1_agg_direct_kernel");
+    };
+    auto pick = [&](auto nacc) -> int {
+        constexpr int N = decltype(nacc)::value;
+        return v8 ? launch(&p1_agg_direct_kernel<N, true>) : launch(&p1_agg_direct_kernel<N, false>);
+    };
+#define AQG_P1_CASE(N) case N: return pick(std::integral_constant<int, N>{});
+    switch (as.nacc) {
+    AQG_P1_CASE(0) AQG_P1_CASE(1) AQG_P1_CASE(2) AQG_P1_CASE(3) AQG_P1_CASE(4) AQG_P1_CASE(5) AQG_P1_CASE(6) AQG_P1_CASE(7)
+    default: return pick(std::integral_constant<int, 8>{});
+    }
+#undef AQG_P1_CASE
+}
+
+static int p1_launch_agg(aqg_ctx* ctx, int ksz, const AccSpec& as, const ValCols& vc, const void* pkeys, const void* prows, void* const* pvals,
+                         const uint32_t* pstart, uint32_t pstride, uint32_t nparts, uint32_t n, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr,
+                         const PackPlan* pp = nullptr) {
+    AggIn in; AggOps ops; bool v8;
+    p1_agg_args(as, vc, pvals, pp, &in, &ops, &v8);
     uint32_t gmax, cap;
     p1_capacity(ksz, as, need_count, &gmax, &cap);
     const size_t lds = (size_t)gmax * (4 + (need_count ? 4 : 0) + 8 * (size_t)as.nacc) + (size_t)cap * (ksz + 2) + 16;
@@ -1146,15 +1375,20 @@ size_t aqg_partition2_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
 }
 
 int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr, int* pack) {
-    const uint32_t P = p2_round_parts(parts), B1 = P >> 6;
-    if (P < 64 || P > AQG_P2_MAXPARTS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "two-level partitioned group-by: 64..4096 partitions");
     const int ksz = ks.total_bytes <= 4 ? 4 : 8;
     ValCols vc;
     p1_val_cols(as, &vc);
     PackPlan pp;
+    RangePlan rp;
     memset(&pp, 0, sizeof pp);
-    if (pack && *pack && !pr) AQG_TRY(plan_pack(ctx, ks, as, n, vc, &pp));   // narrow value columns inside the key word (fewer planes per level)
-    if (pack) *pack = pp.n;
+    memset(&rp, 0, sizeof rp);
+    if (pack && *pack && !pr) {
+        AQG_TRY(plan_pack(ctx, ks, as, n, vc, &pp));                         // narrow value columns inside the key word (fewer planes per level)
+        plan_range(pp, as, need_count, parts, &rp);                          // a dense key domain: range partitions, direct-indexed aggregation
+    }
+    if (pack) *pack = (pp.n ? 1 : 0) | (rp.on ? 2 : 0);
+    const uint32_t P = rp.on ? rp.P : p2_round_parts(parts), B1 = P >> 6;
+    if (P < 64 || P > AQG_P2_MAXPARTS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "two-level partitioned group-by: 64..4096 partitions");
     const void* keycol = ks.col[0];
     if (!p1_key_is_column(ks, ksz)) {
         void* packed;
@@ -1227,28 +1461,40 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     auto run = [&](auto k64) -> int {
         constexpr bool K = decltype(k64)::value;
         const unsigned hgrid = aqg_grid(ctx, n, 1024, HB, 4);
-        hipLaunchKernelGGL((p2_hist_kernel<K>), dim3(hgrid), dim3(1024), (size_t)P * 4, ctx->stream, static_cast<const key_t_<K>*>(keycol), n, P, ftot);
+        if (rp.on) { if constexpr (!K) hipLaunchKernelGGL((p2_hist_kernel<false, true>), dim3(hgrid), dim3(1024), (size_t)P * 4, ctx->stream, static_cast<const uint32_t*>(keycol), n, rp.M, ftot, rp.kmin, rp.D - 1); }
+        else hipLaunchKernelGGL((p2_hist_kernel<K>), dim3(hgrid), dim3(1024), (size_t)P * 4, ctx->stream, static_cast<const key_t_<K>*>(keycol), n, P, ftot);
         hipLaunchKernelGGL(p2_setup_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)ftot, P, n, (uint32_t)P2_PT, fstart, cur2, seg1, tp1, cur1, seg2, tp2);
-        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, K, true>), scat_lds));
-        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, K, false>), scat_lds));
-        P2Level l1{seg1, tp1, cur1, 1u, P, 6u, 0xFFFFFFFFu, B1, 0u};
-        if (pp.n && !K) {
-            if constexpr (!K) {
-                AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, true, true, true>), scat_lds));
-                AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, false, true, true>), scat_lds));
-                hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, true, true, true>), dim3(tiles1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const uint32_t*>(keycol), planes(true), l1);
-                hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, false, true, true>), dim3(1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const uint32_t*>(keycol), planes(true), l1);
+        // the bin of a key word at both levels: the hash or (range partitions) the offset in the domain, scaled to P fine partitions;
+        // level 1 takes the coarse partition (fine >> 6), level 2 the fine one inside it (fine & 63)
+        const uint32_t scale = rp.on ? rp.M : P;
+        P2Level l1{seg1, tp1, cur1, 1u, scale, 6u, 0xFFFFFFFFu, B1, 0u, 0u, rp.kmin, rp.on ? rp.D - 1 : 0u, out.flags + 6};
+        P2Level l2{seg2, tp2, cur2, B1, scale, 0u, 63u, 64u, 64u, pp.kclear, rp.kmin, rp.on ? rp.D - 1 : 0u, out.flags + 6};
+        auto level = [&](auto mode, auto packing, const key_t_<K>* src, const Planes& pl, const P2Level& lv, unsigned tiles, unsigned tails) -> int {
+            constexpr int MODE = decltype(mode)::value;
+            constexpr bool PK = decltype(packing)::value;
+            if constexpr (K && (MODE != BIN_HASHED || PK)) return AQG_ERR_ARG;               // (8-byte key words are hashed and never packed)
+            else {
+                AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, K, true, MODE, PK>), scat_lds));
+                AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, K, false, MODE, PK>), scat_lds));
+                hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, true, MODE, PK>), dim3(tiles), dim3(P2_TB), scat_lds, ctx->stream, src, pl, lv);
+                hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, false, MODE, PK>), dim3(tails), dim3(P2_TB), scat_lds, ctx->stream, src, pl, lv);
+                return AQG_OK;
             }
-        } else {
-            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, true>), dim3(tiles1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keycol), planes(true), l1);
-            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, false>), dim3(1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keycol), planes(true), l1);
-        }
-        P2Level l2{seg2, tp2, cur2, B1, P, 0u, 63u, 64u, 64u, pp.kclear};
-        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, true>), dim3(tiles2), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keysA), planes(false), l2);
-        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, K, false>), dim3(B1), dim3(P2_TB), scat_lds, ctx->stream, static_cast<const key_t_<K>*>(keysA), planes(false), l2);
+        };
+        using Hashed = std::integral_constant<int, BIN_HASHED>;
+        using Ranged = std::integral_constant<int, BIN_RANGED>;
+        const key_t_<K>* k1 = static_cast<const key_t_<K>*>(keycol);
+        const key_t_<K>* k2 = static_cast<const key_t_<K>*>(keysA);
+        if (rp.on && pp.n) AQG_TRY(level(Ranged{}, std::true_type{}, k1, planes(true), l1, tiles1, 1u));
+        else if (rp.on) AQG_TRY(level(Ranged{}, std::false_type{}, k1, planes(true), l1, tiles1, 1u));
+        else if (pp.n) AQG_TRY(level(Hashed{}, std::true_type{}, k1, planes(true), l1, tiles1, 1u));
+        else AQG_TRY(level(Hashed{}, std::false_type{}, k1, planes(true), l1, tiles1, 1u));
+        if (rp.on) AQG_TRY(level(Ranged{}, std::false_type{}, k2, planes(false), l2, tiles2, B1));
+        else AQG_TRY(level(Hashed{}, std::false_type{}, k2, planes(false), l2, tiles2, B1));
         return aqg_check_launch(ctx, "two-level partition scatter");
     };
     if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
+    if (rp.on) return p1_launch_agg_direct(ctx, as, vc, keysB, rowsB, valsB, fstart, n, need_count, out, out_cap, pp.n ? &pp : nullptr, rp);
     return p1_launch_agg(ctx, ksz, as, vc, keysB, rowsB, valsB, fstart, 1u, P, n, need_count, out, out_cap, pr, pp.n ? &pp : nullptr);
 }
 

@@ -84,7 +84,37 @@ check([bigkey], [ck.RED_SUM, ck.RED_SUM], [v1, v2], 500_000, PT)
 def test_two_level_plan_with_narrow_value_columns_inside_the_key_word():
     """AQG_P1_MAX=1 at >= 2^22 rows: the two-level plan packs 4-byte integer value columns of a small sampled range into the spare bits of a
     4-byte key word (h2o Q5 / Q7 at 1e9 rows), verifies every row while packing and repeats the call unpacked when a row does not fit"""
-    run_forced({"AQG_P1_MAX": "1"}, PACKVALS)
+    run_forced({"AQG_P1_MAX": "1", "AQG_DISABLE_RANGED": "1"}, PACKVALS)
+
+
+RANGED = r"""
+n = 4_700_023
+PT, PK, RG = capi.PLAN_PART_TWO, capi.PLAN_PACKED_VALUES, capi.PLAN_RANGE_PARTITIONS
+key = rng.integers(0, 400_000, n).astype(np.int32)
+v1, v2 = rng.integers(1, 6, n).astype(np.int32), rng.integers(-3, 12, n).astype(np.int32)
+v3, v4 = np.round(rng.uniform(0, 100, n), 3).astype(np.float32), rng.integers(-2**40, 2**40, n).astype(np.int64)
+check([key], [ck.RED_SUM, ck.RED_SUM, ck.RED_SUM], [v1, v2, v3], 500_000, PT | PK | RG)                              # h2o Q5
+check([key], [ck.RED_MAX, ck.RED_MIN, ck.RED_COUNT], [v1, v2, v1], 500_000, PT | PK | RG)                             # h2o Q7
+check([key], [ck.RED_AVG, ck.RED_VAR, ck.RED_SUM, ck.RED_MAX], [v3, v2, v4, v4], 500_000, PT | PK | RG)               # 8-byte planes, squares, counts
+check([key - 200_000], [ck.RED_SUM, ck.RED_MIN], [v3, v3], 500_000, PT | RG)                                          # a domain around zero: nothing packs beside a negative key
+check([(key.astype(np.int64) + 2**32 - 500_000).astype(np.uint32)], [ck.RED_SUM, ck.RED_COUNT], [v1, v1], 500_000, PT | RG)   # uint32 keys up to 2^32 - 1
+sparse = key * 37                                              # 1.5e7 key values for 4e5 groups: still range partitions (more of them)
+check([sparse], [ck.RED_SUM, ck.RED_SUM], [v1, v3], 500_000, PT | PK | RG)
+wide = key.astype(np.int64) * 5003                             # a domain of 2e9: hashed
+check([wide.astype(np.int32)], [ck.RED_SUM, ck.RED_SUM], [v1, v3], 500_000, PT)
+skew = key.copy(); skew[2_000_000 : 2_000_000 + n // 3] = 77      # one key holds a third of the rows (behind the sampled first 2^20)
+check([skew], [ck.RED_SUM, ck.RED_MAX], [v1, v3], 500_000, PT | PK | RG)
+late = key.copy(); late[n - 9] = 900_000                       # a key far outside the sampled range: flagged by the scatter, the call repeats hashed
+check([late], [ck.RED_SUM, ck.RED_SUM], [v1, v3], 500_000, PT)
+near = key.copy(); near[n - 9] = 400_700                       # just outside the sample's maximum: inside the slack the domain is given, still ranged
+check([near], [ck.RED_SUM, ck.RED_SUM], [v3, v3], 500_000, PT | RG)
+"""
+
+
+def test_two_level_plan_over_a_dense_key_domain_takes_range_partitions():
+    """one 4-byte integer key column whose sampled values fill their range (h2o id3 / id6): order-preserving bins umulhi(key - kmin, M) at both
+    levels and p1_agg_direct_kernel (accumulators indexed by the key, no key table); a key outside the sampled domain repeats the call hashed"""
+    run_forced({"AQG_P1_MAX": "1"}, RANGED)
 
 
 def test_round1_partition_pipeline_forced():

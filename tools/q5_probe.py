@@ -19,6 +19,6 @@ for w in which:
         try:
             h = d.groupby_agg(keys, ops, vals, hint=n // K + 1024, handle=h)
             ms = d.timer_stop_ms()
-            print(f"{w} n={n:.0e} rep{rep}: {ms:8.3f} ms  groups {h.ngroups}  {bpr * n / ms / 1e6:7.1f} GB/s ({bpr * n / ms / 8e7:.1f}%)", flush=True)
+            print(f"{w} n={n:.0e} rep{rep}: {ms:8.3f} ms  plan {h.plan}  groups {h.ngroups}  {bpr * n / ms / 1e6:7.1f} GB/s ({bpr * n / ms / 8e7:.1f}%)", flush=True)
         except Exception as e:
             print(w, "failed:", e, flush=True); break
