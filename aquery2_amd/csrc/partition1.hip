@@ -713,21 +713,44 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
     const uint32_t NB = lv.nbins;
     if (threadIdx.x <= 128) lb[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t pos[TR];                                         // (bin << 15) | rank, later the staged position
+    // FUSE0 (4-byte key words; every caller's plane 0 IS the key column): the keys stay in registers from the ranking to the staging of
+    // plane 0 -- COUNT the bins (non-returning LDS atomics), scan, then take every row's staged position from its bin's running cursor
+    // and store the key word there.  The other form ranks rows while counting and re-reads the keys for their plane: 4 bytes per row
+    // and level (h2o Q5 at 1e9 rows: 4 of a level's 28 GB).
+    constexpr bool FUSE0 = !K64 && TR <= 16;
+    uint32_t pos[TR];                                         // !FUSE0: (bin << 15) | rank; then the staged position
+    uint32_t kw[FUSE0 ? TR : 1], dpk[FUSE0 ? (TR + 3) / 4 : 1];   // FUSE0: the key words and their bins (a byte each)
     uint32_t outside = 0;
-#pragma unroll
-    for (int h = 0; h < TR; h += HH) {
-        key_t_<K64> key[HH];
-        load_rows_t<TB, FULL>(keys, rb, nrows, h, key);
+    if constexpr (FUSE0) {
+        load_rows_t<TB, FULL>(reinterpret_cast<const uint32_t*>(keys), rb, nrows, 0, kw);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int r = 0; r < HH; ++r) {
+        for (int q = 0; q < (TR + 3) / 4; ++q) dpk[q] = 0;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
             uint32_t hw;
-            if constexpr (MODE == BIN_HASHED) hw = key_hash<K64>(K64 ? key[r] : (key_t_<K64>)((uint32_t)key[r] & ~lv.kclear));
-            else if constexpr (MODE == BIN_RANGED) { hw = ((uint32_t)key[r] & ~lv.kclear) - lv.kmin; outside |= hw > lv.xmax ? 1u : 0u; hw = hw < lv.xmax ? hw : lv.xmax; }
-            else hw = (uint32_t)key[r];
+            if constexpr (MODE == BIN_HASHED) hw = key_hash<false>(kw[r] & ~lv.kclear);
+            else if constexpr (MODE == BIN_RANGED) { hw = (kw[r] & ~lv.kclear) - lv.kmin; outside |= hw > lv.xmax ? 1u : 0u; hw = hw < lv.xmax ? hw : lv.xmax; }
+            else hw = kw[r];
             const uint32_t d = (__umulhi(hw, lv.P) >> lv.shift) & lv.mask;
-            pos[h + r] = FULL || trow<TB>(h + r) < nrows ? (d << 15) | atomicAdd(&lb[d], 1u) : 0xFFFFFFFFu;
+            dpk[r >> 2] |= d << (8 * (r & 3));
+            if (FULL || trow<TB>(r) < nrows) atomicAdd(&lb[d], 1u);
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < TR; h += HH) {
+            key_t_<K64> key[HH];
+            load_rows_t<TB, FULL>(keys, rb, nrows, h, key);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < HH; ++r) {
+                uint32_t hw;
+                if constexpr (MODE == BIN_HASHED) hw = key_hash<K64>(K64 ? key[r] : (key_t_<K64>)((uint32_t)key[r] & ~lv.kclear));
+                else if constexpr (MODE == BIN_RANGED) { hw = ((uint32_t)key[r] & ~lv.kclear) - lv.kmin; outside |= hw > lv.xmax ? 1u : 0u; hw = hw < lv.xmax ? hw : lv.xmax; }
+                else hw = (uint32_t)key[r];
+                const uint32_t d = (__umulhi(hw, lv.P) >> lv.shift) & lv.mask;
+                pos[h + r] = FULL || trow<TB>(h + r) < nrows ? (d << 15) | atomicAdd(&lb[d], 1u) : 0xFFFFFFFFu;
+            }
         }
     }
     if constexpr (MODE == BIN_RANGED) { if (outside) *lv.flag = 1u; }     // (rows beyond a partial tile repeat its last row: no false alarm)
@@ -748,20 +771,63 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < TR; ++r) {
-        if (FULL || pos[r] != 0xFFFFFFFFu) {
-            const uint32_t d = pos[r] >> 15, p = lb[d] + (pos[r] & 0x7FFFu);
-            pos[r] = p;
-            stage[p] = d;
-        }
-    }
-    __syncthreads();
     uint32_t dlt[TR];                                         // destination row minus staged position, per output position
+    if constexpr (FUSE0) {
+        if constexpr (PACK) {                                 // plane 0 = the key word with the narrow value columns in its spare bits, every row verified
+            uint32_t bad = 0;
 #pragma unroll
-    for (int i = 0; i < TR; ++i) { const uint32_t j = i * TB + threadIdx.x; dlt[i] = FULL || j < nrows ? gd[stage[j]] : 0; }
+            for (int r = 0; r < TR; ++r) bad |= kw[r] > pl.pk.kmax ? 1u : 0u;
+            for (int f = 0; f < pl.pk.n; ++f) {
+                uint32_t x[TR];
+                load_rows_t<TB, FULL>(pl.pk.src[f], rb, nrows, 0, x);
+#pragma unroll
+                for (int r = 0; r < TR; ++r) { const uint32_t y = x[r] - pl.pk.min[f]; bad |= y > pl.pk.fmask[f] ? 1u : 0u; kw[r] |= (y & pl.pk.fmask[f]) << pl.pk.shift[f]; }
+            }
+            if (bad) *pl.pk.flag = 1u;                        // (rows beyond a partial tile repeat its last row: no false alarm)
+        }
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            if (FULL || trow<TB>(r) < nrows) {
+                const uint32_t p = atomicAdd(&lb[(dpk[r >> 2] >> (8 * (r & 3))) & 0xFFu], 1u);     // the bin's cursor: exclusive start -> end
+                pos[r] = p;
+                stage[p] = kw[r];
+            } else pos[r] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        // lb[d] is now the END of bin d in the staged order: the bin of an output position = the first bin that ends behind it
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+            const uint32_t j = i * TB + threadIdx.x;
+            uint32_t lo = 0, hi = 127;
+#pragma unroll
+            for (int it = 0; it < 7; ++it) { const uint32_t mid = (lo + hi) >> 1; if (lb[mid] > j) hi = mid; else lo = mid + 1; }
+            dlt[i] = FULL || j < nrows ? gd[lo] : 0;
+        }
+        {
+            const Plane& Q = pl.p[0];
+            uint32_t* dst = Q.dst + Q.dst_off_dw;
+            const uint32_t dstride = (uint32_t)Q.dst_stride_dw;
+#pragma unroll
+            for (int i = 0; i < TR; ++i) {
+                const uint32_t j = i * TB + threadIdx.x;
+                if (FULL || j < nrows) dst[(size_t)(j + dlt[i]) * dstride] = stage[j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+            if (FULL || pos[r] != 0xFFFFFFFFu) {
+                const uint32_t d = pos[r] >> 15, p = lb[d] + (pos[r] & 0x7FFFu);
+                pos[r] = p;
+                stage[p] = d;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TR; ++i) { const uint32_t j = i * TB + threadIdx.x; dlt[i] = FULL || j < nrows ? gd[stage[j]] : 0; }
+    }
 #pragma nounroll
-    for (int ci = 0; ci < pl.n; ++ci) {
+    for (int ci = FUSE0 ? 1 : 0; ci < pl.n; ++ci) {
         const Plane& Q = pl.p[ci];
         __syncthreads();                       // the previous plane (or the bin ids) has left `stage`
 #pragma unroll
