@@ -629,25 +629,33 @@ __global__ void __launch_bounds__(256) emit_order_kernel(const uint32_t* __restr
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G; i += gridDim.x * blockDim.x) order[gid_of_occ[i]] = i;
 }
 // one group: record `s` of `gt` -> row `g` of every output column.  `key`: the packed key, or (wide tuples) the group's first row
-template <bool KEYS = true>
-__device__ inline void emit_record(const GTable& gt, uint32_t s, uint32_t g, const EmitSpec& es, uint64_t key) {
+// `R` = where the record comes from: first(), count(), acc(a).  TableRecord: slot `s` of a group table; RowRecord (below): ONE ROW of
+// the input taken as a whole group (every row its own group).
+struct TableRecord {
+    const GTable& gt; uint32_t s;
+    __device__ inline uint32_t first() const { return *gt.first_p(s); }
+    __device__ inline uint32_t count() const { return gt.has_count ? *gt.count_p(s) : 0; }
+    __device__ inline uint64_t acc(int a) const { return *gt.acc_p(a, s); }
+};
+template <bool KEYS, class R>
+__device__ inline void emit_record_from(const R& rec, uint32_t g, const EmitSpec& es, uint64_t key) {
     if constexpr (KEYS) for (int k = 0; k < es.nkeys; ++k) {
         uint64_t bits = es.wide ? load_bits(es.key_dt[k], es.key_col[k], (size_t)(uint32_t)key) : key >> es.key_shift[k];
         store_sized(es.key_out[k], g, aqg_dtype_size_dev(es.key_dt[k]), bits);
     }
-    es.first_out[g] = (*gt.first_p(s));
-    uint32_t cnt = gt.has_count ? (*gt.count_p(s)) : 0;
+    es.first_out[g] = rec.first();
+    uint32_t cnt = rec.count();
     if (es.count_out) es.count_out[g] = cnt;
     for (int j = 0; j < es.nagg; ++j) {
         const AggOut& a = es.agg[j];
         int vc = vclass(a.dt);
-        uint64_t v0 = a.acc0 >= 0 ? (*gt.acc_p(a.acc0, s)) : 0;
+        uint64_t v0 = a.acc0 >= 0 ? rec.acc(a.acc0) : 0;
         const bool wide = a.dt == AQG_INT64 || a.dt == AQG_UINT64;
         // exact 128-bit sum (and sum of squares) of an integer column
         auto sum128 = [&](int lo_acc, int hi_acc) -> aqg_i128 {
-            uint64_t lo = (*gt.acc_p(lo_acc, s));
+            uint64_t lo = rec.acc(lo_acc);
             if (!wide) return vc == VC_U ? i128_from_u64(lo) : i128_from_i64((int64_t)lo);
-            uint64_t hi = (*gt.acc_p(hi_acc, s));                       // sum of the high halves, to be shifted by 32
+            uint64_t hi = rec.acc(hi_acc);                       // sum of the high halves, to be shifted by 32
             aqg_i128 h = vc == VC_U ? i128_from_u64(hi) : i128_from_i64((int64_t)hi);
             aqg_i128 sh = {h.lo << 32, (h.hi << 32) | (h.lo >> 32)};
             return i128_add(sh, i128_from_u64(lo));
@@ -666,7 +674,7 @@ __device__ inline void emit_record(const GTable& gt, uint32_t s, uint32_t g, con
         case AQG_RED_VAR: case AQG_RED_STDDEV: {                        // (ssq - s*s/(double)(n+1)) / (double)(n+1)
             double np1 = (double)(uint32_t)(cnt + 1), d;
             if (vc == VC_F) {
-                double sd = __builtin_bit_cast(double, v0), q = __builtin_bit_cast(double, (*gt.acc_p(a.acc2, s)));
+                double sd = __builtin_bit_cast(double, v0), q = __builtin_bit_cast(double, rec.acc(a.acc2));
                 d = (q - sd * sd / np1) / np1;
             } else {
                 aqg_i128 sm = sum128(a.acc0, a.acc1), q = sum128(a.acc2, a.acc3);
@@ -692,6 +700,25 @@ __device__ inline void emit_record(const GTable& gt, uint32_t s, uint32_t g, con
         } break;
         }
     }
+}
+template <bool KEYS = true>
+__device__ inline void emit_record(const GTable& gt, uint32_t s, uint32_t g, const EmitSpec& es, uint64_t key) { emit_record_from<KEYS>(TableRecord{gt, s}, g, es, key); }
+
+// Every row its own group (G == n: a grouping by a unique key, h2o Q10 at 1e9 rows): the groups in first-occurrence order ARE the rows in
+// row order, so the result columns are a map of the input columns -- no ranking, no ordering of a billion records.  The record of
+// group i is made from row i on the fly: the accumulator a table would hold after that one row (acc_init folded with the row's operand).
+struct RowRecord {
+    const AccSpec& as; uint32_t i;
+    __device__ inline uint32_t first() const { return i; }
+    __device__ inline uint32_t count() const { return 1u; }
+    __device__ inline uint64_t acc(int a) const {
+        const uint64_t v = val_operand(as.dt[a], as.col[a], i, as.kind[a], as.square[a], as.part[a]);
+        if (as.kind[a] == ACC_ADD_F) return __builtin_bit_cast(uint64_t, 0.0 + __builtin_bit_cast(double, v));     // (what the atomic add onto +0.0 leaves: -0.0 becomes +0.0)
+        return v;                                                                                               // 0 + v; min(~0, v); max(0, v)
+    }
+};
+__global__ void __launch_bounds__(256) emit_rows_kernel(AccSpec as, EmitSpec es, uint32_t n) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) emit_record_from<false>(RowRecord{as, i}, i, es, (uint64_t)i);     // (the key columns: plain copies)
 }
 __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __restrict__ occ, const uint32_t* __restrict__ gid_of_occ, EmitSpec es,
                                                    const uint32_t* __restrict__ order, uint32_t gmax /* 0: no bound; else give up beyond it (ranks were not computed) */) {
@@ -1466,8 +1493,13 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         }
         AQG_TRY(aqg_check_launch(ctx, "first_rows_kernel"));
     }
+    // every row its own group: the result is a map of the input (emit_rows_kernel) -- nothing to rank or order
+    static const bool rows_off = getenv("AQG_DISABLE_ROW_EMIT") != nullptr;                 // A/B measurements only
+    const bool row_emit = !rows_off && !defer && G == n && n >= (1u << 16) && (use_part || use_wpart) && !for_build && !plan.sj && !gt_out && !slot_gid_out && !occ_out;
     SortedParts sparts;
-    if (sorted_tail && G) {
+    if (row_emit) {
+        h->plan_bits |= AQG_PLAN_ROW_EMIT;
+    } else if (sorted_tail && G) {
         AQG_TRY(aqg_sorted_tail(ctx, gt, G, n, as.nacc, ks.wide != 0, &sparts));
     } else if (defer || G) {
         if (small_rank) {
@@ -1506,7 +1538,11 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         AQG_TRY(dev_realloc(ctx, &h->results[j], &h->cap_results[j], gcapn * 16));
         es.agg[j].out = h->results[j];
     }
-    if (sorted_tail && G) {
+    if (row_emit) {
+        for (int k = 0; k < ks.nkeys; ++k) AQG_HIP(ctx, hipMemcpyAsync(h->keys_out[k], ks.col[k], (size_t)n * aqg_dtype_size(ks.dt[k]), hipMemcpyDeviceToDevice, ctx->stream));
+        hipLaunchKernelGGL(emit_rows_kernel, dim3(aqg_grid(ctx, n, 256, 1, 8)), dim3(256), 0, ctx->stream, as, es, n);
+        AQG_TRY(aqg_check_launch(ctx, "emit_rows_kernel"));
+    } else if (sorted_tail && G) {
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&sorted_emit_kernel), sparts.lds));
         const unsigned per_cu = sparts.lds <= 80 * 1024 ? 2 : 1;
         const unsigned sg = sparts.nparts < 4u * per_cu * ctx->num_cu ? sparts.nparts : 4u * per_cu * ctx->num_cu;

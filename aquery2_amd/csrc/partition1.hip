@@ -687,12 +687,13 @@ __global__ void __launch_bounds__(1024) p2_setup_kernel(const uint32_t* __restri
 
 // FULL: grid over all tiles of all segments, whole tiles only.  !FULL: one workgroup per segment takes its last, partial tile.
 template <int TB, int TR, bool K64, bool FULL, int MODE = BIN_HASHED, bool PACK = false>
-__global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 64 / 4 : 1) p2_scatter_kernel(const key_t_<K64>* __restrict__ keys, Planes pl, P2Level lv) {
+__global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2_scatter_kernel(const key_t_<K64>* __restrict__ keys, Planes pl, P2Level lv) {
     constexpr int TPT = TB * TR;
     constexpr int HH = TR < 16 ? TR : 16;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);      // [TPT]
     __shared__ uint32_t lb[129], gd[128], wtot;                // up to 128 bins per level
+    __shared__ uint8_t tb[(TPT + 127) / 128];                   // FUSE0: the bin at every 128th staged position
     uint32_t seg, rb, nrows;
     if constexpr (FULL) {
         const uint32_t t = blockIdx.x;
@@ -794,14 +795,19 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 2 * TB / 
             } else pos[r] = 0xFFFFFFFFu;
         }
         __syncthreads();
-        // lb[d] is now the END of bin d in the staged order: the bin of an output position = the first bin that ends behind it
+        // lb[d] is now the END of bin d in the staged order: the bin of an output position = the first bin that ends behind it, found
+        // from the bin at the start of the position's block of 128 (tb, written by the bins themselves) in a step or two
+        if (threadIdx.x < NB) {
+            const uint32_t s0 = threadIdx.x ? lb[threadIdx.x - 1] : 0, e0 = lb[threadIdx.x];
+            for (uint32_t blk = (s0 + 127) >> 7; (blk << 7) < e0; ++blk) tb[blk] = (uint8_t)threadIdx.x;
+        }
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < TR; ++i) {
             const uint32_t j = i * TB + threadIdx.x;
-            uint32_t lo = 0, hi = 127;
-#pragma unroll
-            for (int it = 0; it < 7; ++it) { const uint32_t mid = (lo + hi) >> 1; if (lb[mid] > j) hi = mid; else lo = mid + 1; }
-            dlt[i] = FULL || j < nrows ? gd[lo] : 0;
+            uint32_t b = 0;
+            if (FULL || j < nrows) { b = tb[j >> 7]; while (lb[b] <= j) ++b; }
+            dlt[i] = FULL || j < nrows ? gd[b] : 0;
         }
         {
             const Plane& Q = pl.p[0];

@@ -117,6 +117,39 @@ def test_two_level_plan_over_a_dense_key_domain_takes_range_partitions():
     run_forced({"AQG_P1_MAX": "1"}, RANGED)
 
 
+ROWS = r"""
+n = 2_600_003
+def check_rows(keys, ops, vals, hint):
+    o = oracle.groupby(keys)
+    assert o["ngroups"] == n
+    gb = gpu.groupby_agg(keys, ops, vals, hint=hint)
+    assert gb.plan & capi.PLAN_ROW_EMIT, gb.plan
+    assert gb.ngroups == n and np.array_equal(gb.first_rows(), np.arange(n, dtype=np.uint32))
+    for k, c in enumerate(keys):
+        assert np.array_equal(gb.keys(k, c.dtype), c), k
+    for j, (op, v) in enumerate(zip(ops, vals)):
+        got, want = gb.result(j, op, ck.tag_of(v)), oracle.grouped_reduce(op, v, o)
+        assert gu.same_bits(got, want), (j, op)
+    print("OK", gb.ngroups, flush=True)
+key = rng.permutation(n).astype(np.int32) - 1_000_000
+i32, f32 = rng.integers(-2**31, 2**31, n).astype(np.int32), np.round(rng.normal(0, 1e3, n), 2).astype(np.float32)
+f32[::5] = -0.0
+i64, f64, u16 = rng.integers(-2**62, 2**62, n).astype(np.int64), rng.normal(0, 1e6, n), rng.integers(0, 2**16, n).astype(np.uint16)
+check_rows([key], [ck.RED_SUM, ck.RED_AVG, ck.RED_MIN, ck.RED_MAX, ck.RED_COUNT], [i32, i32, f32, f32, i32], n + 1000)
+check_rows([key], [ck.RED_SUM, ck.RED_VAR, ck.RED_STDDEV, ck.RED_SUM], [f32, i32, f32, i64], n + 1000)
+check_rows([key.astype(np.int64) * 3], [ck.RED_SUM, ck.RED_MAX, ck.RED_AVG, ck.RED_MIN], [f64, i64, u16, u16], n + 1000)
+ids = [(key % 1000).astype(np.int32), (key // 1000).astype(np.int32), np.zeros(n, np.int32), (key % 7).astype(np.int32)]       # a 16-byte tuple, all distinct
+check_rows(ids, [ck.RED_SUM, ck.RED_COUNT, ck.RED_AVG], [f32, f32, i32], n + 1000)
+"""
+
+
+def test_every_row_its_own_group_is_emitted_as_a_map_of_the_input():
+    """G == n out of a partition plan (a grouping by a unique key: h2o Q10 at 1e9 rows): emit_rows_kernel writes the result columns from the
+    input rows -- every aggregate and value type against the oracle's per-group reductions (groups of one row: D9's n + 1 included), the
+    -0.0 a floating sum turns into +0.0, packed keys and a wide tuple"""
+    run_forced({}, ROWS)
+
+
 def test_round1_partition_pipeline_forced():
     """AQG_DISABLE_P1=1: the round-1 pipeline of partition.hip (packed keys beyond 4096 partitions at default thresholds): part_* kernels"""
     run_forced({"AQG_DISABLE_P1": "1"}, PACKED % ("capi.PLAN_PART_ROUND1", "capi.PLAN_PART_ROUND1"))
