@@ -74,8 +74,21 @@ def secondary_entries(dev, n, ck, aq, id1, v1):
         h["q5"] = dev.groupby_agg([id6], [ck.RED_SUM] * 3, [v1, v2, v3], hint=n // K + 1024, handle=h.get("q5"))
     ms = timed(q5)
     G = h["q5"].ngroups
-    entry("h2o_q5_sum_v1_v2_v3_by_id6", ms, 16 * n + 44 * G, groups=int(G), kernel_ms_last_stage=round(dev.last_kernel_ms(), 4))
-    h["q5"].destroy(); id6.free(); v2.free(); v3.free()
+    entry("h2o_q5_sum_v1_v2_v3_by_id6", ms, 16 * n + 44 * G, groups=int(G), plan=int(h["q5"].plan), kernel_ms_last_stage=round(dev.last_kernel_ms(), 4))
+    h["q5"].destroy(); id6.free()
+    # h2o Q3 `sum(v1), avg(v3) BY id3` and Q7 `max(v1), min(v2) BY id3` (benchmark/h2o/groupby.sql:5,14): the same plan over id3
+    try:
+        id3 = dev.gen_column(ck.GEN_ID3, 42, 0, n, n, K)
+        for name, ops, vals in (("h2o_q3_sum_v1_avg_v3_by_id3", [ck.RED_SUM, ck.RED_AVG], [v1, v3]), ("h2o_q7_max_v1_min_v2_by_id3", [ck.RED_MAX, ck.RED_MIN], [v1, v2])):
+            def q37():
+                h["q37"] = dev.groupby_agg([id3], ops, vals, hint=n // K + 1024, handle=h.get("q37"))
+            ms = timed(q37)
+            entry(name, ms, 12 * n + 28 * h["q37"].ngroups, groups=int(h["q37"].ngroups), plan=int(h["q37"].plan))
+            h.pop("q37").destroy()
+        id3.free()
+    except Exception as e:                                    # noqa: BLE001 -- a secondary entry never costs the line
+        out.append({"name": "h2o_q3_q7", "error": str(e)[:300]})
+    v2.free(); v3.free()
     # ---- config 2 again: h2o Q2 (two keys, 1e4 groups: the dense-domain plan) and Q10 (six keys, ~N groups: the wide-tuple partition
     # plan + the ordering tail; 48 GB of output), benchmark/h2o/groupby.sql:7,23
     try:
@@ -92,7 +105,7 @@ def secondary_entries(dev, n, ck, aq, id1, v1):
                 h["q10"] = dev.groupby_agg(ids, [ck.RED_SUM, ck.RED_COUNT], [v3, v3], hint=n, handle=h.get("q10"))
             ms = timed(q10, reps=2)
             G = h["q10"].ngroups
-            entry("h2o_q10_sum_v3_count_by_id1_to_id6", ms, 28 * n + 48 * G, groups=int(G))
+            entry("h2o_q10_sum_v3_count_by_id1_to_id6", ms, 28 * n + 48 * G, groups=int(G), plan=int(h["q10"].plan))
             h["q10"].destroy()
             for c in ids[2:]: c.free()
             v3.free()
