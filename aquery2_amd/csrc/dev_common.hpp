@@ -92,6 +92,10 @@ __device__ static inline aqg_i128 shfl_xor_i128(aqg_i128 x, int off) {
     return r;
 }
 
+// one element of a result column, stored through a call: a run-time switch whose arms STORE, inlined into a loop with a 64-bit index live
+// across it, is the shape hipcc 7.2 miscompiled (profiles/r2_hipcc_switch_miscompile.md) -- the arms of such switches store through these
+template <class T> __device__ __noinline__ static void store_at(void* __restrict__ col, size_t i, T v) { static_cast<T*>(col)[i] = v; }
+
 struct OpAdd { template <class T> __device__ T operator()(T a, T b) const { return a + b; } };
 struct OpMin { template <class T> __device__ T operator()(T a, T b) const { return b < a ? b : a; } };
 struct OpMax { template <class T> __device__ T operator()(T a, T b) const { return b > a ? b : a; } };

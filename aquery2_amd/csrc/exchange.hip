@@ -207,6 +207,11 @@ __device__ inline aqg_i128 join_halves(const void* lo, const void* hi, uint32_t 
     return {l.lo, h.lo + l.hi};
 }
 __device__ inline aqg_i128 xmul_128(aqg_i128 a, aqg_i128 b) { return {a.lo * b.lo, __umul64hi(a.lo, b.lo) + a.lo * b.hi + a.hi * b.lo}; }
+__device__ __noinline__ static void copy_element(void* __restrict__ dst_col, const void* __restrict__ src_col, size_t g, int size) {
+    const unsigned char* src = static_cast<const unsigned char*>(src_col) + g * size;
+    unsigned char* dst = static_cast<unsigned char*>(dst_col) + g * size;
+    for (int k = 0; k < size; ++k) dst[k] = src[k];
+}
 __global__ void __launch_bounds__(256) xfinal_kernel(FinalSpec fs, uint32_t G) {
     for (uint32_t g = blockIdx.x * 256 + threadIdx.x; g < G; g += gridDim.x * 256) {
         for (int j = 0; j < fs.nagg; ++j) {
@@ -215,11 +220,11 @@ __global__ void __launch_bounds__(256) xfinal_kernel(FinalSpec fs, uint32_t G) {
             auto int_sum = [&]() -> aqg_i128 { return fs.a_hi[j] ? join_halves(fs.a[j], fs.a_hi[j], g) : static_cast<const aqg_i128*>(fs.a[j])[g]; };
             auto to_double = [&](aqg_i128 v) -> double { return uns ? u128_to_double(v.hi, v.lo) : i128_to_double(v); };
             switch (fs.op[j]) {
-            case AQG_RED_COUNT: static_cast<uint64_t*>(fs.out[j])[g] = static_cast<const aqg_i128*>(fs.a[j])[g].lo; break;   // sum of uint32 counts: unsigned 128-bit
+            case AQG_RED_COUNT: store_at<uint64_t>(fs.out[j], g, static_cast<const aqg_i128*>(fs.a[j])[g].lo); break;   // sum of uint32 counts: unsigned 128-bit
             case AQG_RED_AVG: {                                               // sum / (double)size (aggregations.h:28-32)
                 const aqg_i128 cn = static_cast<const aqg_i128*>(fs.b[j])[g];
                 const double s = fp ? static_cast<const double*>(fs.a[j])[g] : to_double(int_sum());
-                static_cast<double*>(fs.out[j])[g] = s / (double)cn.lo;
+                store_at<double>(fs.out[j], g, s / (double)cn.lo);
             } break;
             case AQG_RED_VAR: case AQG_RED_STDDEV: {                          // (ssq - s*s/(double)(n+1)) / (double)(n+1), as emit_record (groupby.hip)
                 const double np1 = (double)(static_cast<const aqg_i128*>(fs.b[j])[g].lo + 1);
@@ -232,15 +237,13 @@ __global__ void __launch_bounds__(256) xfinal_kernel(FinalSpec fs, uint32_t G) {
                     const aqg_i128 ss = xmul_128(sm, sm);                     // s * s in the 128-bit LongType (wraps like the reference)
                     d = (to_double(qq) - to_double(ss) / np1) / np1;
                 }
-                static_cast<double*>(fs.out[j])[g] = fs.op[j] == AQG_RED_STDDEV ? sqrt(d) : d;
+                store_at<double>(fs.out[j], g, fs.op[j] == AQG_RED_STDDEV ? sqrt(d) : d);
             } break;
             case AQG_RED_SUM:
-                if (!fp && fs.a_hi[j]) { static_cast<aqg_i128*>(fs.out[j])[g] = int_sum(); break; }
+                if (!fp && fs.a_hi[j]) { store_at<aqg_i128>(fs.out[j], g, int_sum()); break; }
                 [[fallthrough]];
             default: {                                                        // SUM / MIN / MAX: the merged column is the result
-                const unsigned char* src = static_cast<const unsigned char*>(fs.a[j]) + (size_t)g * fs.out_size[j];
-                unsigned char* dst = static_cast<unsigned char*>(fs.out[j]) + (size_t)g * fs.out_size[j];
-                for (int k = 0; k < fs.out_size[j]; ++k) dst[k] = src[k];
+                copy_element(fs.out[j], fs.a[j], g, fs.out_size[j]);
             } break;
             }
         }

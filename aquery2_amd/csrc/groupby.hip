@@ -632,6 +632,7 @@ __global__ void __launch_bounds__(256) emit_order_kernel(const uint32_t* __restr
 // `R` = where the record comes from: first(), count(), acc(a).  TableRecord: slot `s` of a group table; RowRecord (below): ONE ROW of
 // the input taken as a whole group (every row its own group).
 struct TableRecord {
+    static constexpr bool inline_stores = false;
     const GTable& gt; uint32_t s;
     __device__ inline uint32_t first() const { return *gt.first_p(s); }
     __device__ inline uint32_t count() const { return gt.has_count ? *gt.count_p(s) : 0; }
@@ -643,6 +644,9 @@ __device__ inline void emit_record_from(const R& rec, uint32_t g, const EmitSpec
         uint64_t bits = es.wide ? load_bits(es.key_dt[k], es.key_col[k], (size_t)(uint32_t)key) : key >> es.key_shift[k];
         store_sized(es.key_out[k], g, aqg_dtype_size_dev(es.key_dt[k]), bits);
     }
+    // (table records store through calls -- see store_at; the streaming row map keeps its stores inline: 5.9 against 7.3 ms per 1e9 rows,
+    // and tests/test_gpu_plans.py::test_every_row_its_own_group... checks every arm and value type of that kernel)
+    auto put = [&](void* col, size_t i, auto v) { using T = decltype(v); if constexpr (R::inline_stores) static_cast<T*>(col)[i] = v; else store_at<T>(col, i, v); };
     es.first_out[g] = rec.first();
     uint32_t cnt = rec.count();
     if (es.count_out) es.count_out[g] = cnt;
@@ -663,13 +667,13 @@ __device__ inline void emit_record_from(const R& rec, uint32_t g, const EmitSpec
         auto to_double = [&](aqg_i128 v) -> double { return vc == VC_U ? u128_to_double(v.hi, v.lo) : i128_to_double(v); };
         switch (a.op) {
         case AQG_RED_SUM: case AQG_RED_SUMSQ:                           // -> GetLongType
-            if (vc == VC_F) static_cast<double*>(a.out)[g] = __builtin_bit_cast(double, v0);
-            else static_cast<aqg_i128*>(a.out)[g] = sum128(a.acc0, a.acc1);
+            if (vc == VC_F) put(a.out, g, __builtin_bit_cast(double, v0));
+            else put(a.out, g, sum128(a.acc0, a.acc1));
             break;
-        case AQG_RED_COUNT: static_cast<uint64_t*>(a.out)[g] = cnt; break;
+        case AQG_RED_COUNT: put(a.out, g, (uint64_t)cnt); break;
         case AQG_RED_AVG: {                                             // sum / (double)size
             double sd = vc == VC_F ? __builtin_bit_cast(double, v0) : to_double(sum128(a.acc0, a.acc1));
-            static_cast<double*>(a.out)[g] = sd / (double)cnt;
+            put(a.out, g, sd / (double)cnt);
         } break;
         case AQG_RED_VAR: case AQG_RED_STDDEV: {                        // (ssq - s*s/(double)(n+1)) / (double)(n+1)
             double np1 = (double)(uint32_t)(cnt + 1), d;
@@ -681,7 +685,7 @@ __device__ inline void emit_record_from(const R& rec, uint32_t g, const EmitSpec
                 aqg_i128 ss = mul_128(sm, sm);                          // s * s in the 128-bit LongType (wraps like the reference)
                 d = (to_double(q) - to_double(ss) / np1) / np1;
             }
-            static_cast<double*>(a.out)[g] = a.op == AQG_RED_STDDEV ? sqrt(d) : d;
+            put(a.out, g, a.op == AQG_RED_STDDEV ? sqrt(d) : d);
         } break;
         case AQG_RED_MIN: case AQG_RED_MAX: {
             bool mx = a.op == AQG_RED_MAX;
@@ -708,6 +712,7 @@ __device__ inline void emit_record(const GTable& gt, uint32_t s, uint32_t g, con
 // row order, so the result columns are a map of the input columns -- no ranking, no ordering of a billion records.  The record of
 // group i is made from row i on the fly: the accumulator a table would hold after that one row (acc_init folded with the row's operand).
 struct RowRecord {
+    static constexpr bool inline_stores = true;
     const AccSpec& as; uint32_t i;
     __device__ inline uint32_t first() const { return i; }
     __device__ inline uint32_t count() const { return 1u; }
@@ -758,7 +763,7 @@ __global__ void __launch_bounds__(1024, 8) sorted_emit_kernel(SortedParts sp, ui
         const uint64_t lo64 = (((uint64_t)part << 32) + sp.M - 1) / sp.M, hi64 = ((((uint64_t)part + 1) << 32) + sp.M - 1) / sp.M;
         const uint32_t lo = (uint32_t)lo64, hi = hi64 < n_rows ? (uint32_t)hi64 : n_rows;
         const uint32_t c = e - b, nw = (hi - lo + 31) / 32;
-        if (hi - lo > C || c > C || e > G) { if (threadIdx.x == 0) flags[0] = 1; continue; }       // (the plan rules it out)
+        if (hi - lo > C || c > C || e > G) { if (threadIdx.x == 0) flags[7] = 1; continue; }       // (the plan rules it out; the host checks the word behind this kernel)
         for (uint32_t w = threadIdx.x; w < nw; w += NT) bm[w] = 0;
         __syncthreads();
         // (four rows of a lane per step, their loads issued together from clamped indices: a partition is a chain of barriers, and a
@@ -1255,7 +1260,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
                            !h->no_wide_part && aqg_partitionw_applies(ks, as, n, hint);
     if (use_wpart) gcap = (uint32_t)((uint64_t)hint + hint / 4 + 4096 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : (uint64_t)hint + hint / 4 + 4096);
 
-    const bool sorted_tail = (use_part || use_wpart) && !for_build && hint >= sorted_min && aqg_sorted_tail_plan(n, as.nacc, ks.wide != 0, nullptr);
+    const bool sorted_tail = (use_part || use_wpart) && !for_build && hint >= sorted_min && !h->no_sorted_tail && aqg_sorted_tail_plan(n, as.nacc, ks.wide != 0, nullptr);
     // ---- workspace ----------------------------------------------------------------------------
     size_t slots = (size_t)gcap + 1;
     uint32_t stride = 16;
@@ -1330,7 +1335,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
     // of any kind over integer / floating value columns (also the first pass of aqg_groupby_build: no accumulators, only the distinct keys)
     auto key32 = [&](int j) { return (ks.dt[j] == AQG_INT32 || ks.dt[j] == AQG_UINT32) && ((uintptr_t)ks.col[j] & 15) == 0; };
     // two 4-byte key columns, or one 8-byte key column whose bits are the packed key
-    const bool fast_key8 = ks.nkeys == 1 && !ks.wide && (ks.dt[0] == AQG_INT64 || ks.dt[0] == AQG_UINT64) && ((uintptr_t)ks.col[0] & 15) == 0 && getenv("AQG_DISABLE_FAST64") == nullptr;
+    static const bool fast64_off = getenv("AQG_DISABLE_FAST64") != nullptr;                  // A/B measurements only (read once per process)
+    const bool fast_key8 = ks.nkeys == 1 && !ks.wide && (ks.dt[0] == AQG_INT64 || ks.dt[0] == AQG_UINT64) && ((uintptr_t)ks.col[0] & 15) == 0 && !fast64_off;
     const bool fast_k64 = (ks.nkeys == 2 && !ks.wide && ks.total_bytes == 8 && key32(0) && key32(1)) || fast_key8;
     bool fast = use_lds && !plan.sj && !big_lds && ((k32 && key32(0)) || fast_k64) && n >= 8 && (as.nacc >= 1 || plan.need_count || for_build) && as.nacc <= 4;
     FastVals fv;
@@ -1341,7 +1347,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
     auto tiny_dt = [](int dt) { return dt == AQG_INT8 || dt == AQG_UINT8 || dt == AQG_BOOL || dt == AQG_INT16 || dt == AQG_UINT16; };
     bool fast_v8 = false;                       // some value column is 1, 2 or 8 bytes wide: the VW = 8 instantiation (it takes 4-byte ones, too)
     for (int a = 0; a < as.nacc; ++a) fast_v8 = fast_v8 || wide_dt(as.dt[a]) || tiny_dt(as.dt[a]);
-    fast_v8 = fast_v8 && getenv("AQG_DISABLE_FAST64") == nullptr;
+    fast_v8 = fast_v8 && !fast64_off;
     for (int a = 0; a < as.nacc && fast; ++a) {
         const int dt = as.dt[a];
         if ((uintptr_t)as.col[a] & 15) fast = false;
@@ -1445,9 +1451,11 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
             // a partition larger than LDS holds (fl[5] rows).  A little over: chance (a million partitions sized at mean + 6 sigma) --
             // ONE more try with another seed of the partition hash; far over, or over again: a tuple that dominates the input, which no
             // seed spreads -- the HBM table, same hint
-            if (getenv("AQG_DEBUG_FLAGS")) fprintf(stderr, "aqg: wide partition plan gave up: flags %u %u %u %u, partition %u holds %u rows (n %u, hint %u, seed %u)\n", fl[0], fl[1], fl[2], fl[3], fl[4], fl[5], n, hint, h->wide_seed);
+            static const bool debug_flags = getenv("AQG_DEBUG_FLAGS") != nullptr;
+            if (debug_flags) fprintf(stderr, "aqg: wide partition plan gave up: flags %u %u %u %u, partition %u holds %u rows (n %u, hint %u, seed %u)\n", fl[0], fl[1], fl[2], fl[3], fl[4], fl[5], n, hint, h->wide_seed);
             const uint32_t rcap = aqg_partitionw_rows(ks, as, n, hint);
-            if (h->wide_seed == 0 && fl[5] && fl[5] <= rcap + rcap / 2) h->wide_seed = 0x5BD1E995u; else h->no_wide_part = true;
+            if (!fl[5]) return AQG_ERR_OVERFLOW;     // no partition was too large: the record table (out_cap) was -- more groups than hinted, the caller grows the hint
+            if (h->wide_seed == 0 && fl[5] <= rcap + rcap / 2) h->wide_seed = 0x5BD1E995u; else h->no_wide_part = true;
             return AQG_ERR_RANGE_MISS;
         }
         if (use_part && fl[6]) { h->no_pack = true; return AQG_ERR_RANGE_MISS; }     // a value outside the sampled range of its packed field: once more, unpacked
@@ -1546,9 +1554,17 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&sorted_emit_kernel), sparts.lds));
         const unsigned per_cu = sparts.lds <= 80 * 1024 ? 2 : 1;
         const unsigned sg = sparts.nparts < 4u * per_cu * ctx->num_cu ? sparts.nparts : 4u * per_cu * ctx->num_cu;
-        static const unsigned se_block = getenv("AQG_SORTED_EMIT_BLOCK") ? (unsigned)atoi(getenv("AQG_SORTED_EMIT_BLOCK")) : 1024u;
+        static const unsigned se_env = getenv("AQG_SORTED_EMIT_BLOCK") ? (unsigned)atoi(getenv("AQG_SORTED_EMIT_BLOCK")) : 1024u;
+        const unsigned se_block = se_env >= 512 && se_env <= 1024 && se_env % 64 == 0 ? se_env : 1024u;      // (one lane per bitmap word of a 16384-row interval: 512 at least)
         hipLaunchKernelGGL(sorted_emit_kernel, dim3(sg), dim3(se_block), sparts.lds, ctx->stream, sparts, G, n, as.nacc, (int)gt.has_count, (int)(ks.wide != 0), es, gt.flags);
         AQG_TRY(aqg_check_launch(ctx, "sorted_emit_kernel"));
+        // a partition that does not keep to the plan (more records or a longer row interval than LDS was sized for) is skipped by the kernel
+        // and reported in flag word 7: the output would miss its rows, so the call waits for the word (calls of this size run for tens of
+        // milliseconds) and, should it ever be set, runs once more through the bitmap tail
+        uint32_t bad = 0;
+        AQG_HIP(ctx, hipMemcpyAsync(&bad, gt.flags + 7, 4, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (bad) { h->no_sorted_tail = true; return AQG_ERR_RANGE_MISS; }
     } else if (defer || G) {
         unsigned eg = aqg_grid(ctx, defer ? gupper : G, 256, 1, 8);
         uint32_t* order = nullptr;
@@ -1880,7 +1896,8 @@ int aqg_groupby_merge_packed(aqg_ctx* ctx, const int64_t* gathered_dev, uint32_t
     h->ctx = ctx;
     const bool int_key = key_dtype == AQG_INT8 || key_dtype == AQG_INT16 || key_dtype == AQG_INT32 || key_dtype == AQG_INT64 || key_dtype == AQG_UINT8 ||
                          key_dtype == AQG_UINT16 || key_dtype == AQG_UINT32 || key_dtype == AQG_UINT64 || key_dtype == AQG_BOOL;
-    if (cap_rows <= MERGE_ROWS && int_key && getenv("AQG_DISABLE_SMALL_MERGE") == nullptr) {
+    static const bool small_merge_off = getenv("AQG_DISABLE_SMALL_MERGE") != nullptr;        // A/B measurements only
+    if (cap_rows <= MERGE_ROWS && int_key && !small_merge_off) {
         // ---- a few small shard tables: one workgroup does the whole merge ------------------------------------------------
         const int mop = op == AQG_RED_COUNT ? AQG_RED_SUM : op;
         int rc = AQG_OK;

@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "device.h"
@@ -15,7 +16,7 @@ public:
     void* ret = nullptr;
     char* scratchspace = nullptr;
     size_t ptr = 0, cnt = 0, capacity = 0, initial_capacity = 0;
-    std::vector<char*> retired;   // arenas outgrown since the last release()
+    std::vector<std::pair<char*, size_t>> retired;   // arenas outgrown since the last release(), and their sizes
 
     void init(size_t initial) {
         scratchspace = static_cast<char*>(std::malloc(initial));
@@ -26,7 +27,7 @@ public:
         size_t need = (size_t)sz;
         size_t at = (cnt + 15) & ~(size_t)15;             // 16-byte aligned: device-side vector loads
         if (at + need > capacity) {
-            retired.push_back(scratchspace);               // live temporaries keep pointing into the old arena
+            retired.push_back({scratchspace, capacity});   // live temporaries keep pointing into the old arena
             capacity = at + need + (capacity >> 1);
             scratchspace = static_cast<char*>(std::malloc(capacity));
             at = 0;
@@ -36,9 +37,16 @@ public:
         return scratchspace + at;
     }
     void register_ret(void* r) { ret = r; }
+    // does `p` point into memory that the next release() gives up?
+    bool owns(const void* p) const {
+        const char* c = static_cast<const char*>(p);
+        if (scratchspace && c >= scratchspace && c < scratchspace + capacity) return true;
+        for (const auto& m : retired) if (c >= m.first && c < m.first + m.second) return true;
+        return false;
+    }
     void release() {
         aq::dev::Runtime::get().forget_range(scratchspace, capacity);   // device mirrors of arena temporaries die with them
-        for (char* m : retired) { aq::dev::Runtime::get().forget_range(m, 1); std::free(m); }
+        for (auto& m : retired) { aq::dev::Runtime::get().forget_range(m.first, m.second); std::free(m.first); }
         retired.clear();
         ptr = cnt = 0;
     }

@@ -83,7 +83,18 @@ public:
     }
     vector_type<_Ty>& operator=(const vector_type<_Ty>& o) { if (this != &o) { drop(); copy_from(o); } return *this; }
     vector_type<_Ty>& operator=(vector_type<_Ty>&& o) noexcept {
-        if (this != &o) { drop(); container = o.container; size = o.size; capacity = o.capacity; o.container = nullptr; o.size = o.capacity = 0; }
+        if (this == &o) return *this;
+        // A non-owning view into the per-group scratch arena (`col[i] = v3[val].subvec(0, 2)`, benchmark/h2o/groupby.sql:17 as engine/expr.py:237
+        // emits it) would dangle as soon as the iteration releases the arena -- in the reference every group ends up showing the last
+        // group's bytes.  The receiver takes a copy instead (host access: a deferred per-group temporary is materialised first).
+        if (o.capacity == 0 && o.container && o.size && GC::scratch_space != nullptr && GC::scratch_space->owns(o.container) && !GC::scratch_space->owns(this)) {
+            drop();
+            size = capacity = o.size;
+            container = static_cast<_Ty*>(std::malloc(size * sizeof(_Ty)));
+            std::memcpy((void*)container, (const void*)o.host(), size * sizeof(_Ty));
+            return *this;
+        }
+        drop(); container = o.container; size = o.size; capacity = o.capacity; o.container = nullptr; o.size = o.capacity = 0;
         return *this;
     }
     template <template <class> class VT> vector_type<_Ty>& operator=(const VT<_Ty>& o) {
@@ -116,8 +127,8 @@ public:
                 aq::dev::Runtime::get().forget(old);
                 n = static_cast<_Ty*>(std::realloc((void*)old, (ncap ? ncap : 1) * sizeof(_Ty)));
             }
-            if constexpr (_resize) size = sz;
-            if (ncap > size) std::memset((void*)(n + size), 0, sizeof(_Ty) * (ncap - size));
+            if (ncap > size) std::memset((void*)(n + size), 0, sizeof(_Ty) * (ncap - size));   // (before `size` moves: resize()'s new elements are zero --
+            if constexpr (_resize) size = sz;                                                   //  a column of vectors assigns INTO them, and assignment drops what was there)
             container = n;
             capacity = ncap;
         } else if constexpr (_resize) size = sz;

@@ -6,6 +6,7 @@
 //   dll_memopt  mem_opt.cpp:28-65              the older AQHashTable shape: avgw(10, sales[vecs[i]], col[i]) into buf + offsets
 //   dll_q4      tests/q4.a:23                  SELECT ID, max(ratios(endofdayprice)), min(ratios(endofdayprice)) FROM ticks GROUP BY ID
 //   dll_q9      benchmark/h2o/groupby.sql:20   SELECT id2, id4, pow(corr(v1, v2), 2) AS r2 FROM source GROUP BY id2, id4
+//   dll_q8      benchmark/h2o/groupby.sql:17   SELECT id6, subvec(v3,0,2) AS v3 FROM source GROUP BY id6   (engine/expr.py:237: `v3[val].subvec(0, 2)`)
 //   dll_expr    tests/stock.a:24 per symbol    SELECT sym, max(price - mins(price)), sum(price + price), mins(2, price) ... GROUP BY sym
 #include "header.cxx"
 #include "./server/monetdb_conn.h"
@@ -211,6 +212,40 @@ GC::scratch_space->release();
 }
 GC::scratch_space = nullptr;
 aqtest::dump_table("expr.out", *out_5e);
+puts("done.");
+return 0;
+}
+
+__AQEXPORT__(int) dll_q8(Context* cxt) {
+	using namespace std;
+	using namespace types;
+	auto server = static_cast<DataSource*>(cxt->curr_server);
+auto len_1a = server->cnt;
+auto id6_2b = ColRef<int>(len_1a, server->getCol(0, types::Type_t::AINT32));
+auto v3_3c = ColRef<int>(len_1a, server->getCol(1, types::Type_t::AINT32));
+const char* names_4d[] = {"id6", "v3"};
+auto out_5e = new TableInfo<int,vector_type<int>>("out_5e", names_4d);
+decltype(auto) col_6f = out_5e->get_col<0>();
+decltype(auto) col_7g = out_5e->get_col<1>();
+uint32_t len_8h = id6_2b.size;
+typedef record<decays<decltype(id6_2b)>::value_t> record_type9i;
+auto g10j = HashTableFactory<record_type9i, transTypes<record_type9i, hasher>>::get<decays<decltype(id6_2b)>>(id6_2b);
+auto sz_g10j = g10j.size;
+auto vecs_11k = g10j.values;
+col_6f.resize(sz_g10j);
+col_7g.resize(sz_g10j);
+GC::scratch_space = GC::gc_handle ? &(GC::gc_handle->scratch) : nullptr;
+for (uint32_t i13 = 0; i13 < sz_g10j; ++i13) {
+auto &key_14l = (*g10j.keys)[i13];
+auto &val_15m = vecs_11k[i13];
+col_6f[i13] = (get<0>(key_14l));
+
+col_7g[i13] = (v3_3c[val_15m].subvec(0, 2));
+
+GC::scratch_space->release();
+}
+GC::scratch_space = nullptr;
+aqtest::dump_table("q8.out", *out_5e);
 puts("done.");
 return 0;
 }

@@ -380,6 +380,29 @@ def test_reductions_of_per_group_scans_and_expressions(tmp_path, oracle, dataset
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dataset,n,S", [("trade_small", 50_000, 300), ("trade", 10_000_000, 100_000)])
+def test_h2o_q8_first_two_of_every_group(tmp_path, oracle, dataset, n, S):
+    """benchmark/h2o/groupby.sql:17 `SELECT id6, subvec(v3,0,2) AS v3 FROM source GROUP BY id6` (engine/expr.py:237 emits
+    `v3[val].subvec(0, 2)`): the first two entries of every group's row list (ht_postproc order: the group's two LAST rows), 1e5 groups over
+    1e7 rows through the unchanged generated loop -- the row lists come from one device ht_postproc, no launch per group"""
+    import time
+    import numpy as np
+    build()
+    sym, price = _trade(n, S)
+    ogb = oracle.groupby([sym])
+    assert int(ogb["counts"].min()) >= 2
+    t0 = time.time()
+    run("group_scans.so", dataset, "dll_q8", cwd=str(tmp_path))
+    dt = time.time() - t0
+    assert np.array_equal(np.fromfile(tmp_path / "q8.out.0", np.int32), sym[ogb["first_rows"]])
+    rows = ogb["row_ids"]
+    off = ogb["offsets"].astype(np.int64)
+    want = np.stack([price[rows[off]], price[rows[off + 1]]], axis=1).ravel()
+    assert np.array_equal(np.fromfile(tmp_path / "q8.out.1", np.int32), want)
+    assert dt < 120, f"{dt:.1f} s"
+
+
+@pytest.mark.gpu
 def test_h2o_q9_corr_by_two_keys(tmp_path, oracle):
     """benchmark/h2o/groupby.sql:20 `SELECT id2, id4, pow(corr(v1, v2), 2) AS r2 FROM source GROUP BY id2, id4` at 1e7 rows / 1e4 groups:
     `corr(v1[val], v2[val])` inside the generated loop is ONE grouped pass (five sums per group); bit for bit against the oracle's corr"""
