@@ -95,8 +95,8 @@ __device__ inline uint32_t xcd_tile(uint32_t ntiles) {
 }
 
 template <bool FIRST>
-__global__ void __launch_bounds__(RB) radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t ntiles,
-                                                        uint32_t* __restrict__ hist /* [256][ntiles] */) {
+__global__ void __launch_bounds__(RB) radix_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t dmask, uint32_t ntiles,
+                                                        uint32_t* __restrict__ hist /* [digits][ntiles] */) {
     __shared__ uint32_t h[256];
     const uint32_t tile = xcd_tile(ntiles);
     if (tile >= ntiles) return;
@@ -110,9 +110,9 @@ __global__ void __launch_bounds__(RB) radix_hist_kernel(const uint32_t* __restri
         k[r] = FIRST ? keys[n - 1 - q] : keys[q];
     }
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) if (tbase + r * RB + threadIdx.x < n) atomicAdd(&h[(k[r] >> shift) & 255], 1u);
+    for (int r = 0; r < ROUNDS; ++r) if (tbase + r * RB + threadIdx.x < n) atomicAdd(&h[(k[r] >> shift) & dmask], 1u);
     __syncthreads();
-    if (threadIdx.x < 256) hist[(size_t)threadIdx.x * ntiles + tile] = h[threadIdx.x];
+    if (threadIdx.x <= dmask) hist[(size_t)threadIdx.x * ntiles + tile] = h[threadIdx.x];
 }
 
 // Stable scatter of one tile.  Rank of a row among the tile's rows of its digit = rows of that digit in earlier
@@ -129,7 +129,7 @@ template <bool FIRST, bool LAST, int PAY>
 __global__ void __launch_bounds__(RB) radix_scatter_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n, uint32_t shift,
                                                            uint32_t ntiles, const uint32_t* __restrict__ hist_scanned,
                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int nbits /* significant bits of this pass's digit */,
-                                                           PayIO io) {
+                                                           uint32_t dmask /* 2^(digit width) - 1 */, PayIO io) {
     constexpr int CELLS = ROUNDS * NW;                 // (round, wavefront) cells in rank order
     __shared__ uint16_t cell[CELLS][256];              // rows of each digit per cell, then their exclusive prefix over the cells
     __shared__ uint32_t gbase[256], lbase[256], wsum[4];
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(RB) radix_scatter_kernel(const uint32_t* __res
     const int lane = lane_id(), wid = wave_id();
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     for (uint32_t i = threadIdx.x; i < CELLS * 256 / 2; i += RB) reinterpret_cast<uint32_t*>(&cell[0][0])[i] = 0;
-    if (threadIdx.x < 256) gbase[threadIdx.x] = hist_scanned[(size_t)threadIdx.x * ntiles + tile];
+    if (threadIdx.x < 256) gbase[threadIdx.x] = threadIdx.x <= dmask ? hist_scanned[(size_t)threadIdx.x * ntiles + tile] : 0u;
     uint32_t k[ROUNDS], v[ROUNDS], v2[ROUNDS], d[ROUNDS], rank[ROUNDS];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(RB) radix_scatter_kernel(const uint32_t* __res
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
         const bool live = r * RB + threadIdx.x < nrows;
-        d[r] = (k[r] >> shift) & 255;
+        d[r] = (k[r] >> shift) & dmask;
         uint64_t peers = __ballot(live);                // lanes of this wave holding the same digit in this round
 #pragma unroll
         for (int bit = 0; bit < 8; ++bit) {
@@ -273,7 +273,10 @@ size_t aqg_postproc_ws_bytes(uint32_t n, uint32_t G, int esz) {
     uint32_t bits = 0;
     while (bits < 32 && (1ull << bits) < G) ++bits;
     const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;
-    const uint64_t hcount = (uint64_t)256 * ntiles;
+    // digits of EQUAL width: 17 bits (1e5 groups) are three digits of 6 / 6 / 5 bits, not 8 / 8 / 1 -- the run a tile writes per digit is
+    // four times as long (64 rows: two whole lines) and a rank takes six ballots instead of eight
+    const uint32_t width = bits == 0 ? 1 : (bits + passes - 1) / passes, dmask = (1u << width) - 1;
+    const uint64_t hcount = (uint64_t)(dmask + 1) * ntiles;
     size_t need = hcount * 4 + ((hcount + 2047) / 2048 + (G + 2048) / 2048 + 16) * 4 + 8192;
     if (passes > 1) need += (size_t)n * (esz == 8 ? 24 : 16) + 8192;
     return need;
@@ -285,7 +288,10 @@ int aqg_radix_by_group(aqg_ctx* ctx, aqg_groupby* g, uint32_t* row_ids_dev, cons
     uint32_t bits = 0;
     while (bits < 32 && (1ull << bits) < G) ++bits;
     const uint32_t passes = bits == 0 ? 1 : (bits + 7) / 8;
-    const uint64_t hcount = (uint64_t)256 * ntiles;
+    // digits of EQUAL width: 17 bits (1e5 groups) are three digits of 6 / 6 / 5 bits, not 8 / 8 / 1 -- the run a tile writes per digit is
+    // four times as long (64 rows: two whole lines) and a rank takes six ballots instead of eight
+    const uint32_t width = bits == 0 ? 1 : (bits + passes - 1) / passes, dmask = (1u << width) - 1;
+    const uint64_t hcount = (uint64_t)(dmask + 1) * ntiles;
     const uint32_t grid8 = (ntiles + 7) / 8 * 8;                 // xcd_tile: eight interleaved walks over the tiles
     if (!ws_managed) { AQG_TRY(aqg_ws_reset(ctx)); AQG_TRY(aqg_ws_ensure(ctx, aqg_postproc_ws_bytes(n, G, esz))); }
     uint32_t *hist, *bsum, *k0 = nullptr, *v0 = nullptr, *k1 = nullptr, *v1 = nullptr, *w0 = nullptr, *w1 = nullptr;
@@ -301,16 +307,16 @@ int aqg_radix_by_group(aqg_ctx* ctx, aqg_groupby* g, uint32_t* row_ids_dev, cons
     const uint32_t* win = nullptr;
     for (uint32_t pass = 0; pass < passes; ++pass) {
         const bool first = pass == 0, last = pass + 1 == passes;
-        const uint32_t shift = pass * 8;
-        const int nbits = bits <= shift ? 1 : (int)(bits - shift < 8 ? bits - shift : 8);
+        const uint32_t shift = pass * width;
+        const int nbits = bits <= shift ? 1 : (int)(bits - shift < width ? bits - shift : width);
         uint32_t* kout = last ? nullptr : ((pass & 1) ? k1 : k0);
         uint32_t* vout = last ? row_ids_dev : ((pass & 1) ? v1 : v0);
         uint32_t* wout = last ? nullptr : ((pass & 1) ? w1 : w0);
         PayIO io{x, xout, esz, win, wout};
-        if (first) hipLaunchKernelGGL((radix_hist_kernel<true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
-        else hipLaunchKernelGGL((radix_hist_kernel<false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, n, shift, ntiles, hist);
+        if (first) hipLaunchKernelGGL((radix_hist_kernel<true>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, n, shift, dmask, ntiles, hist);
+        else hipLaunchKernelGGL((radix_hist_kernel<false>), dim3(grid8), dim3(RB), 0, ctx->stream, kin, n, shift, dmask, ntiles, hist);
         AQG_TRY(aqg_exclusive_scan_u32(ctx, hist, hcount, bsum));
-        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout, nbits, io); };
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(grid8), dim3(RB), 0, ctx->stream, kin, vin, n, shift, ntiles, hist, kout, vout, nbits, dmask, io); };
         if (first && last) aqg_kernel_timer_begin(ctx);
         if (x) {
             if (first && last) go(&radix_scatter_kernel<true, true, 1>);
