@@ -737,6 +737,18 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
             dpk[r >> 2] |= d << (8 * (r & 3));
             if (FULL || trow<TB>(r) < nrows) atomicAdd(&lb[d], 1u);
         }
+        if constexpr (PACK) {     // plane 0 = the key word with the narrow value columns in its spare bits, every row verified.  Here, while the
+            uint32_t bad = 0;     // positions are not live yet: behind the scan the sixteen field values spilled (0.3 extra bytes moved per byte)
+#pragma unroll
+            for (int r = 0; r < TR; ++r) bad |= kw[r] > pl.pk.kmax ? 1u : 0u;
+            for (int f = 0; f < pl.pk.n; ++f) {
+                uint32_t x[TR];
+                load_rows_t<TB, FULL>(pl.pk.src[f], rb, nrows, 0, x);
+#pragma unroll
+                for (int r = 0; r < TR; ++r) { const uint32_t y = x[r] - pl.pk.min[f]; bad |= y > pl.pk.fmask[f] ? 1u : 0u; kw[r] |= (y & pl.pk.fmask[f]) << pl.pk.shift[f]; }
+            }
+            if (bad) *pl.pk.flag = 1u;                        // (rows beyond a partial tile repeat its last row: no false alarm)
+        }
     } else {
 #pragma unroll
         for (int h = 0; h < TR; h += HH) {
@@ -774,18 +786,6 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
     __syncthreads();
     uint32_t dlt[TR];                                         // destination row minus staged position, per output position
     if constexpr (FUSE0) {
-        if constexpr (PACK) {                                 // plane 0 = the key word with the narrow value columns in its spare bits, every row verified
-            uint32_t bad = 0;
-#pragma unroll
-            for (int r = 0; r < TR; ++r) bad |= kw[r] > pl.pk.kmax ? 1u : 0u;
-            for (int f = 0; f < pl.pk.n; ++f) {
-                uint32_t x[TR];
-                load_rows_t<TB, FULL>(pl.pk.src[f], rb, nrows, 0, x);
-#pragma unroll
-                for (int r = 0; r < TR; ++r) { const uint32_t y = x[r] - pl.pk.min[f]; bad |= y > pl.pk.fmask[f] ? 1u : 0u; kw[r] |= (y & pl.pk.fmask[f]) << pl.pk.shift[f]; }
-            }
-            if (bad) *pl.pk.flag = 1u;                        // (rows beyond a partial tile repeat its last row: no false alarm)
-        }
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
             if (FULL || trow<TB>(r) < nrows) {
@@ -842,18 +842,6 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
             if (Q.kind == PL_ROWIDX) {
 #pragma unroll
                 for (int r = 0; r < HH; ++r) v[r] = rb + trow<TB>(h + r);
-            } else if (PACK && Q.kind == PL_PACK) {    // the key word with the narrow value columns in its spare bits, every row verified
-                load_rows_t<TB, FULL>(Q.src, rb, nrows, h, v);
-                uint32_t bad = 0;
-#pragma unroll
-                for (int r = 0; r < HH; ++r) bad |= v[r] > pl.pk.kmax ? 1u : 0u;
-                for (int f = 0; f < pl.pk.n; ++f) {
-                    uint32_t x[HH];
-                    load_rows_t<TB, FULL>(pl.pk.src[f], rb, nrows, h, x);
-#pragma unroll
-                    for (int r = 0; r < HH; ++r) { const uint32_t y = x[r] - pl.pk.min[f]; bad |= y > pl.pk.fmask[f] ? 1u : 0u; v[r] |= (y & pl.pk.fmask[f]) << pl.pk.shift[f]; }
-                }
-                if (bad) *pl.pk.flag = 1u;               // (rows beyond a partial tile repeat its last row: no false alarm)
             } else if (Q.src_stride_dw == 1) {
                 load_rows_t<TB, FULL>(Q.src, rb, nrows, h, v);
             } else {                                   // one dword of every element of a wider record (halves of 8-byte columns, fields of AoS records)
