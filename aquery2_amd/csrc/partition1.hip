@@ -609,7 +609,13 @@ struct P2Level {
     uint32_t kclear;              // bits of the key word that are not key (packed value fields): cleared before hashing (0: none)
     uint32_t kmin, xmax;          // BIN_RANGED: the bin is umulhi(key - kmin, P) -- order-preserving bins over a dense key domain
     uint32_t* flag;               // BIN_RANGED: set when a key lies outside [kmin, kmin + xmax] (the range came from a sample)
+    // XCD-local segments (null: off).  Workgroups go to the eight XCDs round-robin (blockIdx & 7), every XCD has its own L2, and a tile
+    // writes one run per bin at an arbitrary alignment: the partial lines at the ends of neighbouring runs meet in ONE L2 -- and leave it
+    // as whole lines -- only if the same XCD writes both.  With this map XCD x takes the segments x, x + 8, ... one after the other:
+    // xtp[x * XTP_STRIDE + j] = tiles of its first j segments, xtp[8 * XTP_STRIDE] = 1 when the launch grid covers the fullest XCD.
+    const uint32_t* xtp;
 };
+constexpr uint32_t XTP_STRIDE = 16;   // (<= 128 segments: up to 16 per XCD)
 // how a key word becomes a bin: BIN_RAW umulhi(word, P) (dense group ids, row ids), BIN_HASHED umulhi(hash(word), P), BIN_RANGED
 enum : int { BIN_RAW = 0, BIN_HASHED = 1, BIN_RANGED = 2 };
 
@@ -655,8 +661,9 @@ __global__ void __launch_bounds__(1024) p2_hist_kernel(const key_t_<K64>* __rest
 __global__ void __launch_bounds__(1024) p2_setup_kernel(const uint32_t* __restrict__ ftot, uint32_t P, uint32_t n, uint32_t tile_rows,
                                                         uint32_t* __restrict__ fstart /* [P + 1] */, uint32_t* __restrict__ cur2 /* [P] */,
                                                         uint32_t* __restrict__ seg1 /* [2] */, uint32_t* __restrict__ tp1 /* [2] */, uint32_t* __restrict__ cur1 /* [P / 64] */,
-                                                        uint32_t* __restrict__ seg2 /* [P / 64 + 1] */, uint32_t* __restrict__ tp2 /* [P / 64 + 1] */) {
-    __shared__ uint32_t wsum[16], fs[4097], tcount[65];
+                                                        uint32_t* __restrict__ seg2 /* [P / 64 + 1] */, uint32_t* __restrict__ tp2 /* [P / 64 + 1] */,
+                                                        uint32_t* __restrict__ xtp /* [8 * XTP_STRIDE + 1] or null */, uint32_t grid_per_xcd) {
+    __shared__ uint32_t wsum[16], fs[4097], tcount[65], stile[64], xmax[8];
     uint32_t c[4], s = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const uint32_t b = threadIdx.x * 4 + k; c[k] = b < P ? ftot[b] : 0; s += c[k]; }
@@ -682,6 +689,22 @@ __global__ void __launch_bounds__(1024) p2_setup_kernel(const uint32_t* __restri
         tp2[threadIdx.x] = ti - t;
         if (threadIdx.x == 63) tcount[0] = ti;
         if (threadIdx.x + 1 == B1) tp2[B1] = ti;
+        stile[threadIdx.x] = t;
+    }
+    if (xtp) {                                                   // level 2 by XCD: segments x, x + 8, ... and their tile prefixes
+        __syncthreads();
+        if (threadIdx.x < 8) {
+            uint32_t run = 0, j = 0;
+            for (uint32_t sgm = threadIdx.x; sgm < B1; sgm += 8, ++j) { xtp[threadIdx.x * XTP_STRIDE + j] = run; run += stile[sgm]; }
+            xtp[threadIdx.x * XTP_STRIDE + j] = run;
+            xmax[threadIdx.x] = run;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t m = 0;
+            for (int x = 0; x < 8; ++x) m = xmax[x] > m ? xmax[x] : m;
+            xtp[8 * XTP_STRIDE] = B1 <= 8 * (XTP_STRIDE - 1) && m <= grid_per_xcd ? 1u : 0u;     // (a skewed table: the plain walk)
+        }
     }
 }
 
@@ -696,12 +719,25 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
     __shared__ uint8_t tb[(TPT + 127) / 128];                   // FUSE0: the bin at every 128th staged position
     uint32_t seg, rb, nrows;
     if constexpr (FULL) {
+        uint64_t b;
+        if (lv.xtp && lv.xtp[8 * XTP_STRIDE]) {                  // XCD x walks its own segments
+            const uint32_t x = blockIdx.x & 7, k = blockIdx.x >> 3;
+            if (x >= lv.nseg) return;
+            const uint32_t* tp = lv.xtp + x * XTP_STRIDE;
+            const uint32_t cnt = (lv.nseg - x + 7) >> 3;
+            if (k >= tp[cnt]) return;
+            uint32_t lo = 0, hi = cnt;                           // largest j with tp[j] <= k
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tp[mid] <= k) lo = mid; else hi = mid; }
+            seg = x + 8 * lo;
+            b = (uint64_t)lv.seg_start[seg] + (uint64_t)(k - tp[lo]) * TPT;
+        } else {
         const uint32_t t = blockIdx.x;
         if (t >= lv.tile_prefix[lv.nseg]) return;
         uint32_t lo = 0, hi = lv.nseg;                           // largest segment with tile_prefix[seg] <= t
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (lv.tile_prefix[mid] <= t) lo = mid; else hi = mid; }
         seg = lo;
-        const uint64_t b = (uint64_t)lv.seg_start[seg] + (uint64_t)(t - lv.tile_prefix[seg]) * TPT;
+        b = (uint64_t)lv.seg_start[seg] + (uint64_t)(t - lv.tile_prefix[seg]) * TPT;
+        }
         if (b + TPT > lv.seg_start[seg + 1]) return;             // the partial tile of the segment: the tail launch
         rb = (uint32_t)b; nrows = TPT;
     } else {
@@ -1487,6 +1523,8 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     AQG_TRY(aqg_ws_get(ctx, 64, &cur1));
     AQG_TRY(aqg_ws_get(ctx, 65, &seg2));
     AQG_TRY(aqg_ws_get(ctx, 65, &tp2));
+    uint32_t* xtp;
+    AQG_TRY(aqg_ws_get(ctx, 8 * XTP_STRIDE + 1, &xtp));
     AQG_HIP(ctx, hipMemsetAsync(ftot, 0, (size_t)P * 4, ctx->stream));
 
     auto planes = [&](bool level1) {
@@ -1523,12 +1561,15 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         const unsigned hgrid = aqg_grid(ctx, n, 1024, HB, 4);
         if (rp.on) { if constexpr (!K) hipLaunchKernelGGL((p2_hist_kernel<false, true>), dim3(hgrid), dim3(1024), (size_t)P * 4, ctx->stream, static_cast<const uint32_t*>(keycol), n, rp.M, ftot, rp.kmin, rp.D - 1); }
         else hipLaunchKernelGGL((p2_hist_kernel<K>), dim3(hgrid), dim3(1024), (size_t)P * 4, ctx->stream, static_cast<const key_t_<K>*>(keycol), n, P, ftot);
-        hipLaunchKernelGGL(p2_setup_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)ftot, P, n, (uint32_t)P2_PT, fstart, cur2, seg1, tp1, cur1, seg2, tp2);
+        static const bool xcd_off = getenv("AQG_DISABLE_XCD_MAP") != nullptr;                   // A/B measurements only
+        const unsigned xgrid = xcd_off ? 0u : ((tiles2 + 7) / 8 * 5 / 4 + 8);                       // workgroups per XCD of the level-2 launch (a quarter of slack)
+        hipLaunchKernelGGL(p2_setup_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)ftot, P, n, (uint32_t)P2_PT, fstart, cur2, seg1, tp1, cur1, seg2, tp2, xcd_off ? (uint32_t*)nullptr : xtp, xgrid);
         // the bin of a key word at both levels: the hash or (range partitions) the offset in the domain, scaled to P fine partitions;
         // level 1 takes the coarse partition (fine >> 6), level 2 the fine one inside it (fine & 63)
         const uint32_t scale = rp.on ? rp.M : P;
         P2Level l1{seg1, tp1, cur1, 1u, scale, 6u, 0xFFFFFFFFu, B1, 0u, 0u, rp.kmin, rp.on ? rp.D - 1 : 0u, out.flags + 6};
-        P2Level l2{seg2, tp2, cur2, B1, scale, 0u, 63u, 64u, 64u, pp.kclear, rp.kmin, rp.on ? rp.D - 1 : 0u, out.flags + 6};
+        P2Level l2{seg2, tp2, cur2, B1, scale, 0u, 63u, 64u, 64u, pp.kclear, rp.kmin, rp.on ? rp.D - 1 : 0u, out.flags + 6, xcd_off ? (const uint32_t*)nullptr : xtp};
+        const unsigned grid2 = xcd_off || 8 * xgrid < tiles2 ? tiles2 : 8 * xgrid;                  // (covers the plain walk too, should the setup decline the map)
         auto level = [&](auto mode, auto packing, const key_t_<K>* src, const Planes& pl, const P2Level& lv, unsigned tiles, unsigned tails) -> int {
             constexpr int MODE = decltype(mode)::value;
             constexpr bool PK = decltype(packing)::value;
@@ -1549,8 +1590,8 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         else if (rp.on) AQG_TRY(level(Ranged{}, std::false_type{}, k1, planes(true), l1, tiles1, 1u));
         else if (pp.n) AQG_TRY(level(Hashed{}, std::true_type{}, k1, planes(true), l1, tiles1, 1u));
         else AQG_TRY(level(Hashed{}, std::false_type{}, k1, planes(true), l1, tiles1, 1u));
-        if (rp.on) AQG_TRY(level(Ranged{}, std::false_type{}, k2, planes(false), l2, tiles2, B1));
-        else AQG_TRY(level(Hashed{}, std::false_type{}, k2, planes(false), l2, tiles2, B1));
+        if (rp.on) AQG_TRY(level(Ranged{}, std::false_type{}, k2, planes(false), l2, grid2, B1));
+        else AQG_TRY(level(Hashed{}, std::false_type{}, k2, planes(false), l2, grid2, B1));
         return aqg_check_launch(ctx, "two-level partition scatter");
     };
     if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
