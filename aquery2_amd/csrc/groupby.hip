@@ -1390,7 +1390,11 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         const size_t mark = ctx->ws_off;
         memset(&prows, 0, sizeof prows);
         h->plan_bits = (use_wpart ? AQG_PLAN_PART_WIDE : p1_bins ? AQG_PLAN_PART_ONE : p2_parts ? AQG_PLAN_PART_TWO : AQG_PLAN_PART_ROUND1) | (sorted_tail ? AQG_PLAN_SORTED_TAIL : 0u);
-        if (use_wpart) AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed, hint));
+        if (use_wpart) {
+            int pack = h->no_pack ? 0 : 1;
+            AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed, hint, &pack));
+            if (pack) h->plan_bits |= AQG_PLAN_PACKED_KEYS;
+        }
         else if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap, for_build ? &prows : nullptr));
         else if (p2_parts) {
             int pack = h->no_pack ? 0 : 1;
@@ -1447,6 +1451,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
     uint32_t G = 0;
     auto judge_flags = [&]() -> int {
         if (dense && fl[3]) { h->dense_exact = true; h->range_valid = false; return AQG_ERR_RANGE_MISS; }
+        if (use_wpart && fl[6]) { h->no_pack = true; return AQG_ERR_RANGE_MISS; }      // a key outside the sampled range of its packed field: once more, unpacked
         if (use_wpart && fl[0]) {
             // a partition larger than LDS holds (fl[5] rows).  A little over: chance (a million partitions sized at mean + 6 sigma) --
             // ONE more try with another seed of the partition hash; far over, or over again: a tuple that dominates the input, which no
@@ -1458,7 +1463,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
             if (h->wide_seed == 0 && fl[5] <= rcap + rcap / 2) h->wide_seed = 0x5BD1E995u; else h->no_wide_part = true;
             return AQG_ERR_RANGE_MISS;
         }
-        if (use_part && fl[6]) { h->no_pack = true; return AQG_ERR_RANGE_MISS; }     // a value outside the sampled range of its packed field: once more, unpacked
+        if ((use_part || use_wpart) && fl[6]) { h->no_pack = true; return AQG_ERR_RANGE_MISS; }     // a value outside the sampled range of its packed field: once more, unpacked
         if (fl[0]) return AQG_ERR_OVERFLOW;
         G = fl[1];
         if (small_rank && G > 4096) return AQG_ERR_OVERFLOW;

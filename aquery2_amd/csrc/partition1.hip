@@ -845,7 +845,7 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
             if (FULL || j < nrows) { b = tb[j >> 7]; while (lb[b] <= j) ++b; }
             dlt[i] = FULL || j < nrows ? gd[b] : 0;
         }
-        {
+        if (pl.p[0].dst) {                                     // (null: the key plane only ranks the rows -- nobody reads it behind this level)
             const Plane& Q = pl.p[0];
             uint32_t* dst = Q.dst + Q.dst_off_dw;
             const uint32_t dstride = (uint32_t)Q.dst_stride_dw;
@@ -932,8 +932,16 @@ __device__ inline uint32_t pw_hash_row(const uint32_t* k, int nk, uint32_t seed)
     for (int j = 0; j < nk; ++j) { a = pw_mix32(a, k[j], 0xCC9E2D51u, 0x1B873593u); b = pw_mix32(b, k[j], 0x9E3779B1u, 0x85EBCA77u); }
     return pw_fin32(a ^ pw_fin32(b));
 }
-__global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, uint32_t seed, uint32_t* __restrict__ out) {
+// PACKW: the key columns also leave this pass PACKED -- column k as the field ((value - min[k]) & mask[k]) << shift[k] of dword plane
+// word[k] -- under ranges sampled from the first 2^20 rows; every row is verified here (a miss sets *flag: the call repeats unpacked).
+// The six id columns of h2o Q10 (7 + 7 + 24 + 7 + 7 + 24 bits) travel as three dword planes instead of six through every level and
+// through pw_agg's LDS; tuple equality on the packed planes IS tuple equality (the map is injective on verified rows), and the result's
+// key columns are fetched through the groups' first rows as before.
+struct PackW { int nout; uint32_t min[MAXKEYS], mask[MAXKEYS]; int word[MAXKEYS], shift[MAXKEYS]; uint32_t* out[4]; uint32_t* flag; };
+template <bool PACKW>
+__global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, uint32_t seed, uint32_t* __restrict__ out, PackW pk) {
     const uint32_t nchunk = n >> 2;
+    uint32_t bad = 0;
     for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < nchunk; c += gridDim.x * 256) {
         pack<uint32_t, 4> v[MAXKEYS];
 #pragma unroll
@@ -951,13 +959,46 @@ __global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, u
 #pragma unroll
         for (int j = 0; j < 4; ++j) h.v[j] = pw_fin32(a.v[j] ^ pw_fin32(b.v[j]));
         *reinterpret_cast<pack<uint32_t, 4>*>(out + (size_t)c * 4) = h;
+        if constexpr (PACKW) {
+#pragma unroll
+            for (int k = 0; k < MAXKEYS; ++k) {
+                if (k < ks.n) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[k].v[j] -= pk.min[k]; bad |= v[k].v[j] > pk.mask[k] ? 1u : 0u; v[k].v[j] = (v[k].v[j] & pk.mask[k]) << pk.shift[k]; }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (o < pk.nout) {
+                    pack<uint32_t, 4> w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w.v[j] = 0;
+#pragma unroll
+                    for (int k = 0; k < MAXKEYS; ++k) {
+                        if (k < ks.n && pk.word[k] == o) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) w.v[j] |= v[k].v[j];
+                        }
+                    }
+                    *reinterpret_cast<pack<uint32_t, 4>*>(pk.out[o] + (size_t)c * 4) = w;
+                }
+            }
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const size_t i = ((size_t)nchunk << 2) + threadIdx.x;
         uint32_t k[MAXKEYS];
         for (int j = 0; j < ks.n; ++j) k[j] = ks.col[j][i];
         out[i] = pw_hash_row(k, ks.n, seed);
+        if constexpr (PACKW) {
+            for (int o = 0; o < pk.nout; ++o) {
+                uint32_t w = 0;
+                for (int j = 0; j < ks.n; ++j) if (pk.word[j] == o) { const uint32_t y = k[j] - pk.min[j]; bad |= y > pk.mask[j] ? 1u : 0u; w |= (y & pk.mask[j]) << pk.shift[j]; }
+                pk.out[o][i] = w;
+            }
+        }
     }
+    if constexpr (PACKW) { if (bad) *pk.flag = 1u; }
 }
 __global__ void __launch_bounds__(256) pn_gather_strided_kernel(const uint32_t* __restrict__ src, uint32_t stride, uint32_t count, uint32_t* __restrict__ dst) {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) dst[i] = src[(size_t)i * stride];
@@ -1654,7 +1695,55 @@ size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
     return ((size_t)n + 64) * per_row + 256 * (16 + 8 * MAXACC + 8 * MAXKEYS) + ((size_t)w.P + 4096) * 24 + ((size_t)n / P2_PT + (size_t)w.P + 64) * 8 + 65536;
 }
 
-int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap, uint32_t seed, uint32_t hint) {
+// the packing of wide tuples (PackW): fields by first fit, widest first; worth it when a third of the dword planes goes
+static bool plan_packw(aqg_ctx* ctx, const KeySpec& ks, uint32_t n, PackW* pk, int* err) {
+    memset(pk, 0, sizeof *pk);
+    *err = AQG_OK;
+    static const bool off = getenv("AQG_DISABLE_WIDE_PACK") != nullptr;      // A/B measurements only
+    if (off || n < (1u << 22) || ks.nkeys < 3) return false;
+    for (int k = 0; k < ks.nkeys; ++k) if (!(ks.dt[k] == AQG_INT32 || ks.dt[k] == AQG_UINT32) || ((uintptr_t)ks.col[k] & 15)) return false;
+    long long mins[MAXKEYS], maxs[MAXKEYS];
+    bool ok = false;
+    *err = aqg_key_ranges(ctx, ks, 1u << 20, mins, maxs, &ok);              // (a sample: every row is verified while it is packed)
+    if (*err != AQG_OK || !ok) return false;
+    int bits[MAXKEYS], order[MAXKEYS];
+    for (int k = 0; k < ks.nkeys; ++k) {
+        // the sample rarely holds a column's extremes (ids 1 .. 1e7: the first 2^20 rows start near 10): a little room on both sides, and a
+        // non-negative column that starts near zero is measured from zero -- a value BELOW the offset would wrap into a miss
+        const long long span = maxs[k] - mins[k], room = span / 64 + 8;
+        mins[k] = mins[k] >= 0 && mins[k] <= span + room ? 0 : mins[k] - room;
+        maxs[k] += room;
+        const unsigned long long range = (unsigned long long)(maxs[k] - mins[k]);
+        int b = 1;
+        while (b < 32 && (1ull << b) <= range) ++b;
+        bits[k] = b; order[k] = k;
+    }
+    for (int i = 1; i < ks.nkeys; ++i) for (int j = i; j > 0 && bits[order[j]] > bits[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    auto fit = [&](int extra, int* word, int* shift) -> int {                // dword planes needed with `extra` bits of slack per field
+        int used[MAXKEYS] = {0}, nw = 0;
+        for (int i = 0; i < ks.nkeys; ++i) {
+            const int k = order[i], b = bits[k] + extra > 32 ? 32 : bits[k] + extra;
+            int o = 0;
+            while (o < nw && used[o] + b > 32) ++o;
+            if (o == nw) ++nw;
+            word[k] = o; shift[k] = used[o]; used[o] += b;
+        }
+        return nw;
+    };
+    int word[MAXKEYS], shift[MAXKEYS];
+    const int tight = fit(0, word, shift);
+    if (tight > 4 || tight * 3 > ks.nkeys * 2) return false;
+    int extra = 0;
+    if (fit(1, word, shift) == tight) extra = 1; else fit(0, word, shift);     // a bit of slack per field when it costs no plane
+    pk->nout = tight;
+    for (int k = 0; k < ks.nkeys; ++k) {
+        const int b = bits[k] + extra > 32 ? 32 : bits[k] + extra;
+        pk->min[k] = (uint32_t)mins[k]; pk->mask[k] = b >= 32 ? 0xFFFFFFFFu : (1u << b) - 1; pk->word[k] = word[k]; pk->shift[k] = shift[k];
+    }
+    return true;
+}
+
+int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap, uint32_t seed, uint32_t hint, int* pack) {
     const WidePlan w = pw_plan(ks, as, n, hint);
     if (!w.ok) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "wide-tuple partitioned group-by: the input does not fit 128 x 128 x 128 partitions");
     ValCols vc;
@@ -1663,6 +1752,8 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     // the partition key: a 32-bit hash of the tuple
     uint32_t* h32;
     AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &h32));
+    PackW pk;
+    bool packed = false;
     {
         Keys32 k32;
         memset(&k32, 0, sizeof k32);
@@ -1673,13 +1764,27 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         }
         k32.n = ks.nkeys;
         static const bool generic_hash = getenv("AQG_PW_GENERIC_HASH") != nullptr;
-        if (all32 && !generic_hash) hipLaunchKernelGGL(pw_hash32_kernel, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 16)), dim3(256), 0, ctx->stream, k32, n, seed, h32);
+        memset(&pk, 0, sizeof pk);
+        if (all32 && !generic_hash && pack && *pack) {
+            int err = AQG_OK;
+            packed = plan_packw(ctx, ks, n, &pk, &err);
+            AQG_TRY(err);
+        }
+        if (packed) {
+            for (int o = 0; o < pk.nout; ++o) AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &pk.out[o]));
+            pk.flag = out.flags + 6;
+            hipLaunchKernelGGL(pw_hash32_kernel<true>, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 16)), dim3(256), 0, ctx->stream, k32, n, seed, h32, pk);
+        }
+        else if (all32 && !generic_hash) hipLaunchKernelGGL(pw_hash32_kernel<false>, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 16)), dim3(256), 0, ctx->stream, k32, n, seed, h32, pk);
         else hipLaunchKernelGGL(pw_hash_kernel, dim3(g4), dim3(256), 0, ctx->stream, ks, n, seed, h32);
     }
+    if (pack) *pack = packed ? 1 : 0;
+    const int nkd = packed ? pk.nout : w.nkd;             // key dword planes that travel (R, P and the LDS size stay those of the unpacked plan)
     // source planes: the key columns as dwords (1- / 2-byte ones widened, 8-byte ones as two planes), then the distinct value columns
     struct Src { const void* p; int stride, off, bytes; };
     std::vector<Src> ksrc, vsrc;
-    for (int k = 0; k < ks.nkeys; ++k) {
+    if (packed) for (int o = 0; o < pk.nout; ++o) ksrc.push_back({pk.out[o], 1, 0, 4});
+    for (int k = 0; k < ks.nkeys && !packed; ++k) {
         const int esz = (int)aqg_dtype_size(ks.dt[k]);
         const void* col = ks.col[k];
         if (esz < 4) {
@@ -1707,7 +1812,7 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     for (int i = 0; i < 2; ++i) {
         AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &set[i].hash));
         AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &set[i].rows));
-        for (int k = 0; k < w.nkd; ++k) AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &set[i].kd[k]));
+        for (int k = 0; k < nkd; ++k) AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &set[i].kd[k]));
         for (int u = 0; u < vc.n; ++u) AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * vsrc[u].bytes, &set[i].val[u]));
     }
     auto planes = [&](int level, const Set* from, const Set& to) {
@@ -1718,9 +1823,9 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
             Q.kind = kind; Q.src = static_cast<const uint32_t*>(s_); Q.src_stride_dw = sstride; Q.src_off_dw = soff;
             Q.dst = static_cast<uint32_t*>(d); Q.dst_stride_dw = dstride; Q.dst_off_dw = doff;
         };
-        add(PL_LOAD, level == 1 ? h32 : from->hash, 1, 0, to.hash, 1, 0);
+        add(PL_LOAD, level == 1 ? h32 : from->hash, 1, 0, level == w.L ? nullptr : to.hash, 1, 0);     // (nobody reads the hash behind the last level)
         if (level == 1) add(PL_ROWIDX, nullptr, 0, 0, to.rows, 1, 0); else add(PL_LOAD, from->rows, 1, 0, to.rows, 1, 0);
-        for (int k = 0; k < w.nkd; ++k) {
+        for (int k = 0; k < nkd; ++k) {
             if (level == 1) add(PL_LOAD, ksrc[k].p, ksrc[k].stride, ksrc[k].off, to.kd[k], 1, 0);
             else add(PL_LOAD, from->kd[k], 1, 0, to.kd[k], 1, 0);
         }
@@ -1731,7 +1836,7 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         }
         return pl;
     };
-    if (2 + w.nkd + 2 * vc.n > MAXPL) return aqg_fail(ctx, AQG_ERR_ARG, "wide-tuple partitioned group-by: too many planes");
+    if (2 + nkd + 2 * vc.n > MAXPL) return aqg_fail(ctx, AQG_ERR_ARG, "wide-tuple partitioned group-by: too many planes");
     // level bookkeeping: segments of level l = the bins of level l - 1
     uint32_t *seg, *tp, *cnt, *cur, *bsum;
     const size_t maxseg = (size_t)w.P + 2;
@@ -1776,8 +1881,8 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     // ---- aggregate every partition inside LDS -----------------------------------------------------------------------------------------
     WideIn in;
     memset(&in, 0, sizeof in);
-    in.nkd = w.nkd;
-    for (int k = 0; k < w.nkd; ++k) in.kplane[k] = from->kd[k];
+    in.nkd = nkd;
+    for (int k = 0; k < nkd; ++k) in.kplane[k] = from->kd[k];
     in.rows = from->rows;
     AggOps ops;
     memset(&ops, 0, sizeof ops);

@@ -182,6 +182,26 @@ def test_wide_tuple_partition_plan_with_and_without_the_ordering_tail():
     run_forced({"AQG_SORTED_TAIL_MIN": "1"}, WIDE % "capi.PLAN_PART_WIDE | capi.PLAN_SORTED_TAIL")
 
 
+WIDEPACK = r"""
+n = 4_400_021                                                  # (key packing is planned from 2^22 rows on)
+r = rng.integers(0, 1_900_000, n)                              # ~2.3 rows per tuple
+ids = [(r % 100 + 1).astype(np.int32), (r // 100 % 1000 - 500).astype(np.int32), (r // 100_000 + 7).astype(np.int32), ((r * 7) % 13).astype(np.int32), (r % 3).astype(np.uint32)]
+v1, v3 = rng.integers(-9, 10, n).astype(np.int32), np.round(rng.uniform(0, 100, n), 3).astype(np.float32)
+W, PK = capi.PLAN_PART_WIDE, capi.PLAN_PACKED_KEYS
+check(ids, [ck.RED_SUM, ck.RED_COUNT, ck.RED_SUM], [v1, v1, v3], 1_800_000, W | PK)          # 7 + 10 + 5 + 4 + 2 bits: one dword plane instead of five
+big = [c.copy() for c in ids]; big[2] = (big[2].astype(np.int64) * 40_000_000).astype(np.int32)   # a column that needs all its 32 bits takes a plane by itself, the other four share one
+check(big, [ck.RED_SUM, ck.RED_COUNT], [v1, v1], 1_800_000, W | PK)
+late = [c.copy() for c in ids]; late[1][n - 3] = 70_000       # a key outside the range of the sampled first 2^20 rows: caught while packing, the call repeats unpacked
+check(late, [ck.RED_SUM, ck.RED_MIN], [v3, v1], 1_800_000, W)
+"""
+
+
+def test_wide_tuples_travel_packed_under_sampled_ranges():
+    """tuples wider than 8 bytes whose 4-byte integer columns have narrow sampled ranges (h2o Q10's six id columns need 76 bits, not 192): the
+    hash pass also writes the columns packed into fewer dword planes, every row verified; a miss repeats the call unpacked"""
+    run_forced({}, WIDEPACK)
+
+
 def test_h2o_q10_at_1e8_rows_default_thresholds_groups_of_two():
     """h2o Q10 `sum(v3), count(*) BY id1 .. id6` (benchmark/h2o/groupby.sql:23) at 1e8 rows with the DEFAULT thresholds: hint 1e8 >= 2^24, so
     the call takes the wide-tuple partitions AND the ordering tail.  The table is the first 5e7 rows of the seed-42 columns (all tuples
@@ -202,7 +222,7 @@ def test_h2o_q10_at_1e8_rows_default_thresholds_groups_of_two():
         ids = [doubled(c, np.int32) for c in (ck.GEN_ID1, ck.GEN_ID2, ck.GEN_ID3, ck.GEN_ID4, ck.GEN_ID5, ck.GEN_ID6)]
         v3 = doubled(ck.GEN_V3, np.float32)
         gb = d.groupby_agg(ids, [ck.RED_SUM, ck.RED_COUNT], [v3, v3], hint=n)
-        assert gb.plan == capi.PLAN_PART_WIDE | capi.PLAN_SORTED_TAIL, gb.plan
+        assert gb.plan == capi.PLAN_PART_WIDE | capi.PLAN_SORTED_TAIL | capi.PLAN_PACKED_KEYS, gb.plan      # (six id columns in three dword planes)
         assert gb.ngroups == half, gb.ngroups                         # (seed 42: the first 5e7 tuples are all distinct)
         tmp = d.empty(half, np.int32)
         for k in range(6):
