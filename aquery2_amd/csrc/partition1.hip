@@ -755,9 +755,7 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
     // and store the key word there.  The other form ranks rows while counting and re-reads the keys for their plane: 4 bytes per row
     // and level (h2o Q5 at 1e9 rows: 4 of a level's 28 GB).
     constexpr bool FUSE0 = !K64 && TR <= 16;
-    static_assert(TB * TR <= 65536, "staged positions are kept as 16-bit halves");
-    uint32_t pos[FUSE0 ? 1 : TR];                             // !FUSE0: (bin << 15) | rank while the bins are counted
-    uint32_t ppos[(TR + 1) / 2];                              // the staged positions, two per register (sixteen registers matter: see the plane loop)
+    uint32_t pos[TR];                                         // !FUSE0: (bin << 15) | rank; then the staged position
     uint32_t kw[FUSE0 ? TR : 1], dpk[FUSE0 ? (TR + 3) / 4 : 1];   // FUSE0: the key words and their bins (a byte each)
     uint32_t outside = 0;
     if constexpr (FUSE0) {
@@ -828,9 +826,9 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
         for (int r = 0; r < TR; ++r) {
             if (FULL || trow<TB>(r) < nrows) {
                 const uint32_t p = atomicAdd(&lb[(dpk[r >> 2] >> (8 * (r & 3))) & 0xFFu], 1u);     // the bin's cursor: exclusive start -> end
-                if (r & 1) ppos[r >> 1] |= p << 16; else ppos[r >> 1] = p;
+                pos[r] = p;
                 stage[p] = kw[r];
-            } else if (!(r & 1)) ppos[r >> 1] = 0;
+            } else pos[r] = 0xFFFFFFFFu;
         }
         __syncthreads();
         // lb[d] is now the END of bin d in the staged order: the bin of an output position = the first bin that ends behind it, found
@@ -847,41 +845,51 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
             if (FULL || j < nrows) { b = tb[j >> 7]; while (lb[b] <= j) ++b; }
             dlt[i] = FULL || j < nrows ? gd[b] : 0;
         }
+        if (pl.p[0].dst) {                                     // (null: the key plane only ranks the rows -- nobody reads it behind this level)
+            const Plane& Q = pl.p[0];
+            uint32_t* dst = Q.dst + Q.dst_off_dw;
+            const uint32_t dstride = (uint32_t)Q.dst_stride_dw;
+#pragma unroll
+            for (int i = 0; i < TR; ++i) {
+                const uint32_t j = i * TB + threadIdx.x;
+                if (FULL || j < nrows) dst[(size_t)(j + dlt[i]) * dstride] = stage[j];
+            }
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < TR; ++r) {
-            uint32_t p = 0;
             if (FULL || pos[r] != 0xFFFFFFFFu) {
-                const uint32_t d = pos[r] >> 15;
-                p = lb[d] + (pos[r] & 0x7FFFu);
+                const uint32_t d = pos[r] >> 15, p = lb[d] + (pos[r] & 0x7FFFu);
+                pos[r] = p;
                 stage[p] = d;
             }
-            if (r & 1) ppos[r >> 1] |= p << 16; else ppos[r >> 1] = p;
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < TR; ++i) { const uint32_t j = i * TB + threadIdx.x; dlt[i] = FULL || j < nrows ? gd[stage[j]] : 0; }
     }
-    // The planes, software-pipelined: a plane's rows are loaded while the plane before it streams out of `stage` (its own values are in
-    // LDS by then, so the registers are free) -- a workgroup's load latency hides behind its own stores instead of standing alone
-    // between two barriers.
-    static_assert(TR <= 16 || !FULL, "the pipelined plane loop holds a whole plane's rows of a lane in registers");
-    auto load_plane = [&](int ci, uint32_t (&v)[TR]) {
+#pragma nounroll
+    for (int ci = FUSE0 ? 1 : 0; ci < pl.n; ++ci) {
         const Plane& Q = pl.p[ci];
-        if (Q.kind == PL_ROWIDX) {
+        __syncthreads();                       // the previous plane (or the bin ids) has left `stage`
 #pragma unroll
-            for (int r = 0; r < TR; ++r) v[r] = rb + trow<TB>(r);
-        } else if (Q.src_stride_dw == 1) {
-            load_rows_t<TB, FULL>(Q.src, rb, nrows, 0, v);
-        } else {                                       // one dword of every element of a wider record (halves of 8-byte columns, fields of AoS records)
-            const uint32_t* tp = Q.src + (size_t)Q.src_stride_dw * rb + Q.src_off_dw;
+        for (int h = 0; h < TR; h += HH) {
+            uint32_t v[HH];
+            if (Q.kind == PL_ROWIDX) {
 #pragma unroll
-            for (int r = 0; r < TR; ++r) { const uint32_t o = trow<TB>(r); v[r] = tp[(size_t)Q.src_stride_dw * (FULL || o < nrows ? o : nrows - 1)]; }
+                for (int r = 0; r < HH; ++r) v[r] = rb + trow<TB>(h + r);
+            } else if (Q.src_stride_dw == 1) {
+                load_rows_t<TB, FULL>(Q.src, rb, nrows, h, v);
+            } else {                                   // one dword of every element of a wider record (halves of 8-byte columns, fields of AoS records)
+                const uint32_t* tp = Q.src + (size_t)Q.src_stride_dw * rb + Q.src_off_dw;
+#pragma unroll
+                for (int r = 0; r < HH; ++r) { const uint32_t o = trow<TB>(h + r); v[r] = tp[(size_t)Q.src_stride_dw * (FULL || o < nrows ? o : nrows - 1)]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < HH; ++r) if (FULL || pos[h + r] != 0xFFFFFFFFu) stage[pos[h + r]] = v[r];
         }
-    };
-    auto stream_out = [&](int ci) {
-        const Plane& Q = pl.p[ci];
-        if (!Q.dst) return;                            // (a plane that only ranks the rows: nobody reads it behind this level)
+        __syncthreads();
         uint32_t* dst = Q.dst + Q.dst_off_dw;
         const uint32_t dstride = (uint32_t)Q.dst_stride_dw;
 #pragma unroll
@@ -889,21 +897,6 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
             const uint32_t j = i * TB + threadIdx.x;
             if (FULL || j < nrows) dst[(size_t)(j + dlt[i]) * dstride] = stage[j];
         }
-    };
-    uint32_t v[TR];
-    const int first = FUSE0 ? 1 : 0;
-    if (first < pl.n) load_plane(first, v);            // in flight while plane 0 (FUSE0) leaves
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (FUSE0) stream_out(0);
-#pragma nounroll
-    for (int ci = first; ci < pl.n; ++ci) {
-        __syncthreads();                               // the previous plane (or the bin ids) has left `stage`
-#pragma unroll
-        for (int r = 0; r < TR; ++r) if (FULL || trow<TB>(r) < nrows) stage[(ppos[r >> 1] >> (16 * (r & 1))) & 0xFFFFu] = v[r];
-        __syncthreads();
-        if (ci + 1 < pl.n) load_plane(ci + 1, v);      // the next plane's rows: in flight while this one streams out
-        __builtin_amdgcn_sched_barrier(0);
-        stream_out(ci);
     }
 }
 
