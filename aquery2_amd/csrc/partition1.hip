@@ -614,6 +614,7 @@ struct P2Level {
     // as whole lines -- only if the same XCD writes both.  With this map XCD x takes the segments x, x + 8, ... one after the other:
     // xtp[x * XTP_STRIDE + j] = tiles of its first j segments, xtp[8 * XTP_STRIDE] = 1 when the launch grid covers the fullest XCD.
     const uint32_t* xtp;
+    uint32_t* xq;                 // the eight queue heads (one per 128-byte line, zeroed by the setup)
 };
 constexpr uint32_t XTP_STRIDE = 16;   // (<= 128 segments: up to 16 per XCD)
 // how a key word becomes a bin: BIN_RAW umulhi(word, P) (dense group ids, row ids), BIN_HASHED umulhi(hash(word), P), BIN_RANGED
@@ -704,6 +705,7 @@ __global__ void __launch_bounds__(1024) p2_setup_kernel(const uint32_t* __restri
             uint32_t m = 0;
             for (int x = 0; x < 8; ++x) m = xmax[x] > m ? xmax[x] : m;
             xtp[8 * XTP_STRIDE] = B1 <= 8 * (XTP_STRIDE - 1) && m <= grid_per_xcd ? 1u : 0u;     // (a skewed table: the plain walk)
+            for (int x = 0; x < 8; ++x) xtp[8 * XTP_STRIDE + 32 + x * 32] = 0u;                   // the queue heads
         }
     }
 }
@@ -721,11 +723,30 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
     if constexpr (FULL) {
         uint64_t b;
         if (lv.xtp && lv.xtp[8 * XTP_STRIDE]) {                  // XCD x walks its own segments
-            const uint32_t x = blockIdx.x & 7, k = blockIdx.x >> 3;
-            if (x >= lv.nseg) return;
+            // Which XCD this workgroup runs on is read from the hardware (the dispatcher's round-robin holds on some boxes and runs and not on
+            // others: with blockIdx & 7 as the XCD, the same binary took 14.9 or 16.9 ms for h2o Q5).  The workgroup pulls the next tile
+            // of ITS XCD's list from that list's queue head (one device-scope atomic); a list that has run dry sends it to the next one,
+            // so every tile is taken whatever the placement of the workgroups: placement changes the speed only.
+            if (threadIdx.x == 0) {
+                const uint32_t me = __builtin_amdgcn_s_getreg((20) | (0 << 6) | ((4 - 1) << 11)) & 7u;       // HW_REG_XCC_ID
+                uint32_t got = 0xFFFFFFFFu, gx = 0;
+                for (uint32_t a = 0; a < 8 && got == 0xFFFFFFFFu; ++a) {
+                    const uint32_t xx = (me + a) & 7u;
+                    if (xx >= lv.nseg) continue;
+                    const uint32_t total = lv.xtp[xx * XTP_STRIDE + ((lv.nseg - xx + 7) >> 3)];
+                    uint32_t* head = lv.xq + xx * 32;
+                    if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= total) continue;
+                    const uint32_t k = atomicAdd(head, 1u);
+                    if (k < total) { got = k; gx = xx; }
+                }
+                wtot = got; lb[0] = gx;
+            }
+            __syncthreads();
+            const uint32_t k = wtot, x = lb[0];
+            __syncthreads();
+            if (k == 0xFFFFFFFFu) return;
             const uint32_t* tp = lv.xtp + x * XTP_STRIDE;
             const uint32_t cnt = (lv.nseg - x + 7) >> 3;
-            if (k >= tp[cnt]) return;
             uint32_t lo = 0, hi = cnt;                           // largest j with tp[j] <= k
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tp[mid] <= k) lo = mid; else hi = mid; }
             seg = x + 8 * lo;
@@ -1565,7 +1586,7 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     AQG_TRY(aqg_ws_get(ctx, 65, &seg2));
     AQG_TRY(aqg_ws_get(ctx, 65, &tp2));
     uint32_t* xtp;
-    AQG_TRY(aqg_ws_get(ctx, 8 * XTP_STRIDE + 1, &xtp));
+    AQG_TRY(aqg_ws_get(ctx, 8 * XTP_STRIDE + 32 + 8 * 32, &xtp));     // tile prefixes per XCD | flag | eight queue heads on lines of their own
     AQG_HIP(ctx, hipMemsetAsync(ftot, 0, (size_t)P * 4, ctx->stream));
 
     auto planes = [&](bool level1) {
@@ -1609,7 +1630,7 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         // level 1 takes the coarse partition (fine >> 6), level 2 the fine one inside it (fine & 63)
         const uint32_t scale = rp.on ? rp.M : P;
         P2Level l1{seg1, tp1, cur1, 1u, scale, 6u, 0xFFFFFFFFu, B1, 0u, 0u, rp.kmin, rp.on ? rp.D - 1 : 0u, out.flags + 6};
-        P2Level l2{seg2, tp2, cur2, B1, scale, 0u, 63u, 64u, 64u, pp.kclear, rp.kmin, rp.on ? rp.D - 1 : 0u, out.flags + 6, xcd_off ? (const uint32_t*)nullptr : xtp};
+        P2Level l2{seg2, tp2, cur2, B1, scale, 0u, 63u, 64u, 64u, pp.kclear, rp.kmin, rp.on ? rp.D - 1 : 0u, out.flags + 6, xcd_off ? (const uint32_t*)nullptr : xtp, xcd_off ? (uint32_t*)nullptr : xtp + 8 * XTP_STRIDE + 32};
         const unsigned grid2 = xcd_off || 8 * xgrid < tiles2 ? tiles2 : 8 * xgrid;                  // (covers the plain walk too, should the setup decline the map)
         auto level = [&](auto mode, auto packing, const key_t_<K>* src, const Planes& pl, const P2Level& lv, unsigned tiles, unsigned tails) -> int {
             constexpr int MODE = decltype(mode)::value;
