@@ -732,12 +732,15 @@ __global__ void __launch_bounds__(256) emit_rows_kernel(AccSpec as, EmitSpec es,
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) emit_record_from<false>(RowRecord{as, i}, i, es, (uint64_t)i);     // (the key columns: plain copies)
 }
 __global__ void __launch_bounds__(256) emit_kernel(GTable gt, const uint32_t* __restrict__ occ, const uint32_t* __restrict__ gid_of_occ, EmitSpec es,
-                                                   const uint32_t* __restrict__ order, uint32_t gmax /* 0: no bound; else give up beyond it (ranks were not computed) */) {
+                                                   const uint32_t* __restrict__ order, uint32_t gmax /* 0: no bound; else give up beyond it (ranks were not computed) */,
+                                                   int occ_identity /* occ[i] == i (the record tables of the partition plans) */) {
     uint32_t G = gt.flags[1];
     if (gmax && G > gmax) return;
     for (uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < G; i0 += gridDim.x * blockDim.x) {
         const uint32_t i = order ? order[i0] : i0;
-        const uint32_t s = occ[i], g = gid_of_occ[i];
+        // with `order` the group id is the walk position itself (order[gid_of_occ[i]] = i), and a record table is its own occupancy
+        // list: two of the three random lines a group cost at 1e7 groups are not fetched
+        const uint32_t s = occ_identity ? i : occ[i], g = order ? i0 : gid_of_occ[i];
         emit_record(gt, s, g, es, s == gt.cap ? EMPTY64 : (*gt.key_p(s)));
     }
 }
@@ -1589,7 +1592,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
             AQG_TRY(aqg_ws_get(ctx, slots, &order));
             hipLaunchKernelGGL(emit_order_kernel, dim3(eg), dim3(256), 0, ctx->stream, (const uint32_t*)gid_of_occ, G, order);
         }
-        hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt, (const uint32_t*)occ, (const uint32_t*)gid_of_occ, es, (const uint32_t*)order, defer ? 4096u : 0u);
+        hipLaunchKernelGGL(emit_kernel, dim3(eg), dim3(256), 0, ctx->stream, gt, (const uint32_t*)occ, (const uint32_t*)gid_of_occ, es, (const uint32_t*)order, defer ? 4096u : 0u, (int)(n && (use_part || use_wpart)));
         AQG_TRY(aqg_check_launch(ctx, "emit_kernel"));
     }
     if (defer) {
