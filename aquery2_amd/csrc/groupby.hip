@@ -1261,7 +1261,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
     static const bool p1_off_env = getenv("AQG_DISABLE_P1") != nullptr;      // A/B measurements only
     const bool p1_off = p1_off_env && !for_build;
     static const uint32_t p1_max = getenv("AQG_P1_MAX") ? (uint32_t)atoi(getenv("AQG_P1_MAX")) : 1024u;
-    const uint32_t parts = use_part && !p1_off ? aqg_partition_parts(ks.total_bytes <= 4 ? 4 : 8, as, plan.need_count, hint) : 0;
+    int part_layout = AQG_P1_LAYOUT_DENSE_IDS;
+    const uint32_t parts = use_part && !p1_off ? aqg_partition_parts(ks.total_bytes <= 4 ? 4 : 8, as, plan.need_count, hint, &part_layout) : 0;
     const uint32_t p1_bins = parts && parts <= p1_max && parts <= AQG_P1_MAXBINS ? parts : 0;
     const uint32_t p2_parts = parts && !p1_bins && parts <= AQG_P2_MAXPARTS ? parts : 0;
     // tuples wider than 8 bytes with many groups (h2o Q10): hash-partitioned rows, every partition grouped inside LDS
@@ -1404,10 +1405,10 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
             AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed, hint, &pack));
             if (pack) h->plan_bits |= AQG_PLAN_PACKED_KEYS;
         }
-        else if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap, for_build ? &prows : nullptr));
+        else if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap, for_build ? &prows : nullptr, part_layout));
         else if (p2_parts) {
             int pack = h->no_pack ? 0 : 1;
-            AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap, for_build ? &prows : nullptr, &pack));
+            AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap, for_build ? &prows : nullptr, &pack, part_layout));
             if (pack & 1) h->plan_bits |= AQG_PLAN_PACKED_VALUES;
             if (pack & 2) h->plan_bits |= AQG_PLAN_RANGE_PARTITIONS;
         }

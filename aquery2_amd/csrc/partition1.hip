@@ -587,6 +587,178 @@ __global__ void __launch_bounds__(SB) p1_agg_direct_kernel(const uint32_t* __res
     }
 }
 
+// ---- hashed, accumulators indexed by the SLOT ---------------------------------------------------------------------------------------
+// p1_agg_kernel above keeps its accumulators dense (a 2-byte id per slot, accumulators per id) so that the table's slack does not
+// multiply them; the price is the chain probe -> id -> first row -> atomics, three dependent LDS round trips per row, a spin on ids not
+// yet published and a counter every insertion passes through.  Where the groups of a partition still fit with the accumulators INSIDE
+// the table (key | first row | count | accumulators per slot at load 0.6: h2o Q5's three sums up to ~1e7 groups in 4096 partitions), a
+// row needs ONE dependent round trip -- its probe -- and everything behind it is a fire-and-forget atomic on the slot found, as in the
+// direct-indexed kernel.  Slot `cap` belongs to the key that equals the empty mark, slot `cap + 1` takes the masked rows.
+template <int NACC, bool K64, bool V8>
+__global__ void __launch_bounds__(SB) p1_agg_slot_kernel(const void* __restrict__ rkeys, const uint32_t* __restrict__ rrows, AccSpec as, AggIn in, AggOps ops,
+                                                         const uint32_t* __restrict__ pstart, uint32_t pstride, uint32_t NB, uint32_t ntotal, uint32_t cap, int need_count,
+                                                         GTable out, uint32_t out_cap, uint32_t* __restrict__ part_base) {
+    using K = key_t_<K64>;
+    using VT = std::conditional_t<V8, uint64_t, uint32_t>;
+    constexpr int NA = NACC ? NACC : 1;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const uint32_t C2 = cap + 2;
+    uint64_t* lacc = reinterpret_cast<uint64_t*>(smem_raw);                       // [NACC][C2]
+    K* ktab = reinterpret_cast<K*>(lacc + (size_t)NACC * C2);                     // [C2] (8-byte keys: behind the accumulators, aligned)
+    uint32_t* lfirst = reinterpret_cast<uint32_t*>(ktab + C2);                    // [C2]
+    uint32_t* lcount = lfirst + C2;                                               // [C2] (only when need_count)
+    __shared__ uint32_t lused, lemit, gbase, lins;
+    const K EMPTYK = empty_key<K64>();
+    struct Batch { K key[AR]; uint32_t row[AR]; VT v[NA][AR]; };
+    auto load_full = [&](uint32_t i0, Batch& t) {                                 // (as in p1_agg_kernel: the only form the prefetch uses)
+        const uint32_t o = i0 + threadIdx.x * AR;
+        __builtin_memcpy(t.key, static_cast<const K*>(rkeys) + o, sizeof t.key);
+        __builtin_memcpy(t.row, rrows + o, sizeof t.row);
+        _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+            if (!in.col[a]) continue;
+            if (!V8 || in.esz[a] == 4) {
+                uint32_t w[AR];
+                __builtin_memcpy(w, static_cast<const uint32_t*>(in.col[a]) + o, sizeof w);
+                _Pragma("unroll") for (int q = 0; q < AR; ++q) t.v[a][q] = w[q];
+            } else {
+                if constexpr (V8) __builtin_memcpy(t.v[a], static_cast<const uint64_t*>(in.col[a]) + o, sizeof(uint64_t) * AR);
+            }
+        }
+    };
+    auto load_edge = [&](uint32_t i0, uint32_t e, Batch& t) {
+        const uint32_t o = i0 + threadIdx.x * AR;
+        _Pragma("unroll") for (int q = 0; q < AR; ++q) {
+            const uint32_t i = o + q < e ? o + q : e - 1;
+            t.key[q] = static_cast<const K*>(rkeys)[i]; t.row[q] = rrows[i];
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                if (!in.col[a]) continue;
+                if (!V8 || in.esz[a] == 4) t.v[a][q] = static_cast<const uint32_t*>(in.col[a])[i];
+                else if constexpr (V8) t.v[a][q] = static_cast<const uint64_t*>(in.col[a])[i];
+            }
+        }
+    };
+    const uint32_t limit = cap - (cap >> 3);                   // more keys than this in one partition: the host re-plans (probe chains grow without bound towards a full table)
+    for (uint32_t part = blockIdx.x; part < NB; part += gridDim.x) {
+        const uint32_t b = pstart[(size_t)part * pstride];
+        const uint32_t e = part + 1 < NB ? pstart[(size_t)(part + 1) * pstride] : ntotal;
+        if (b == e) continue;
+        constexpr uint32_t STEP = SB * AR;
+        const uint32_t nfull = (e - b) / STEP, nsteps = nfull + ((e - b) % STEP ? 1u : 0u);
+        const uint32_t safe_last = nfull ? b + (nfull - 1) * STEP : (b + STEP <= ntotal ? b : ntotal - STEP);
+        Batch cur;
+        load_full(nfull ? b : safe_last, cur);                 // in flight while the table is cleared
+        for (uint32_t g = threadIdx.x; g < C2; g += SB) {
+            ktab[g] = EMPTYK;
+            lfirst[g] = NOROW;
+            if (need_count) lcount[g] = 0;
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) lacc[(size_t)a * C2 + g] = acc_init(as.kind[a]);
+        }
+        if (threadIdx.x == 0) { lused = 0; lemit = 0; lins = 0; }
+        __syncthreads();
+        uint32_t i0 = b;
+        for (uint32_t st = 0; st < nsteps; ++st) {
+            const bool edge = st >= nfull;
+            if (edge) load_edge(i0, e, cur);
+            Batch nxt;
+            { const uint32_t inext = i0 + STEP; load_full(inext <= safe_last && st + 1 < nfull ? inext : safe_last, nxt); }
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t o = i0 + threadIdx.x * AR;
+            uint32_t slot[AR];
+            K key[AR], w[AR];
+#pragma unroll
+            for (int q = 0; q < AR; ++q) {
+                key[q] = cur.key[q];
+                if constexpr (!K64) key[q] &= ~in.kclear;
+                slot[q] = __umulhi(key_hash<K64>(key[q]) * NB, cap);
+                w[q] = ktab[slot[q]];                                      // AR probes in flight
+            }
+            uint32_t pend = 0;
+#pragma unroll
+            for (int q = 0; q < AR; ++q) {
+                if (edge && !(o + q < e)) slot[q] = cap + 1;               // (masked)
+                else if (key[q] == EMPTYK) slot[q] = cap;                  // the key that doubles as the empty mark
+                else if (w[q] != key[q]) pend |= 1u << q;
+            }
+            // rows that missed on their first probe walk their probe sequences together: one LDS round trip per step
+            for (uint32_t step = 0; pend && step <= cap; ++step) {
+#pragma unroll
+                for (int q = 0; q < AR; ++q) {
+                    if (!(pend & (1u << q))) continue;
+                    K c = w[q];
+                    if (c == EMPTYK) {
+                        if constexpr (K64) c = atomicCAS(reinterpret_cast<unsigned long long*>(&ktab[slot[q]]), (unsigned long long)EMPTYK, (unsigned long long)key[q]);
+                        else c = atomicCAS(&ktab[slot[q]], EMPTYK, key[q]);
+                        if (c == EMPTYK) { c = key[q]; if (atomicAdd(&lins, 1u) >= limit) out.flags[0] = 1; }
+                    }
+                    if (c == key[q]) { pend &= ~(1u << q); continue; }
+                    slot[q] = slot[q] + 1 == cap ? 0 : slot[q] + 1;
+                }
+#pragma unroll
+                for (int q = 0; q < AR; ++q) if (pend & (1u << q)) w[q] = ktab[slot[q]];
+            }
+            if (pend) {                                                    // a full table: the host re-plans
+                out.flags[0] = 1;
+#pragma unroll
+                for (int q = 0; q < AR; ++q) if (pend & (1u << q)) slot[q] = cap + 1;
+            }
+#pragma unroll
+            for (int q = 0; q < AR; ++q) atomicMin(&lfirst[slot[q]], cur.row[q]);
+            if (need_count) {
+#pragma unroll
+                for (int q = 0; q < AR; ++q) atomicAdd(&lcount[slot[q]], 1u);
+            }
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                uint64_t* acc = lacc + (size_t)a * C2;
+                VT x[AR];
+                bool from_key = false;
+                if constexpr (!K64) from_key = in.packed[a] != 0;
+                if (from_key) { if constexpr (!K64) { _Pragma("unroll") for (int q = 0; q < AR; ++q) x[q] = (VT)((((uint32_t)cur.key[q] >> in.pshift[a]) & in.pmask[a]) + in.pmin[a]); } }
+                else if (in.col[a]) { _Pragma("unroll") for (int q = 0; q < AR; ++q) x[q] = cur.v[a][q]; }
+                else { _Pragma("unroll") for (int q = 0; q < AR; ++q) x[q] = (VT)cur.row[q]; }
+#define AQG_ROWS(expr) _Pragma("unroll") for (int q = 0; q < AR; ++q) { expr; } break
+                switch (ops.opc[a]) {
+                case OPC_ADDI_I32: AQG_ROWS(atomicAdd(reinterpret_cast<unsigned long long*>(acc + slot[q]), (unsigned long long)(long long)(int32_t)(uint32_t)x[q]));
+                case OPC_ADDI_U32: AQG_ROWS(atomicAdd(reinterpret_cast<unsigned long long*>(acc + slot[q]), (unsigned long long)(uint32_t)x[q]));
+                case OPC_ADDF_F32: AQG_ROWS(atomicAdd(reinterpret_cast<double*>(acc + slot[q]), (double)__uint_as_float((uint32_t)x[q])));
+                case OPC_ADDF_F64: AQG_ROWS(atomicAdd(reinterpret_cast<double*>(acc + slot[q]), __builtin_bit_cast(double, (uint64_t)x[q])));
+                case OPC_MIN_I32: AQG_ROWS(atomicMin(reinterpret_cast<unsigned long long*>(acc + slot[q]), (unsigned long long)map_i((int32_t)(uint32_t)x[q])));
+                case OPC_MAX_I32: AQG_ROWS(atomicMax(reinterpret_cast<unsigned long long*>(acc + slot[q]), (unsigned long long)map_i((int32_t)(uint32_t)x[q])));
+                case OPC_MIN_U32: AQG_ROWS(atomicMin(reinterpret_cast<unsigned long long*>(acc + slot[q]), (unsigned long long)(uint32_t)x[q]));
+                case OPC_MAX_U32: AQG_ROWS(atomicMax(reinterpret_cast<unsigned long long*>(acc + slot[q]), (unsigned long long)(uint32_t)x[q]));
+                case OPC_MIN_F32: AQG_ROWS(atomicMin(reinterpret_cast<unsigned long long*>(acc + slot[q]), (unsigned long long)map_f((double)__uint_as_float((uint32_t)x[q]))));
+                case OPC_MAX_F32: AQG_ROWS(atomicMax(reinterpret_cast<unsigned long long*>(acc + slot[q]), (unsigned long long)map_f((double)__uint_as_float((uint32_t)x[q]))));
+                default: AQG_ROWS(acc_apply(acc + slot[q], as.kind[a], val_operand_bits(as.dt[a] == AQG_NONE ? AQG_UINT32 : as.dt[a], (uint64_t)x[q], as.kind[a], as.square[a], as.part[a])));
+                }
+#undef AQG_ROWS
+            }
+            cur = nxt;
+            i0 += STEP;
+        }
+        __syncthreads();
+        // the slots that saw a row become records, reserved with one global atomic per partition
+        uint32_t mine = 0;
+        for (uint32_t j = threadIdx.x; j <= cap; j += SB) mine += lfirst[j] != NOROW ? 1u : 0u;
+        mine = wave_reduce(mine, OpAdd{});
+        if (lane_id() == 0 && mine) atomicAdd(&lused, mine);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            gbase = atomicAdd(&out.flags[1], lused);
+            if (part_base) { part_base[2 * (size_t)part] = gbase; part_base[2 * (size_t)part + 1] = lused; }
+        }
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j <= cap; j += SB) {
+            if (lfirst[j] == NOROW) continue;
+            const uint32_t g = gbase + atomicAdd(&lemit, 1u);
+            if (g >= out_cap) { out.flags[0] = 1; continue; }
+            *out.key_p(g) = j == cap ? (K64 ? EMPTY64 : (uint64_t)EMPTY32) : (uint64_t)ktab[j];
+            *out.first_p(g) = lfirst[j];
+            *out.count_p(g) = need_count ? lcount[j] : 0;
+            _Pragma("unroll") for (int a = 0; a < NACC; ++a) *out.acc_p(a, g) = lacc[(size_t)a * C2 + j];
+        }
+        __syncthreads();
+    }
+}
+
 
 // ==== two levels (more partitions than one level writes well) ==================================================================
 // The run a tile writes per bin and plane is (LDS staging bytes / bins) long: 3000 bins leave 44-byte runs, and partial lines are
@@ -1219,8 +1391,32 @@ static void p1_capacity(int ksz, const AccSpec& as, int need_count, uint32_t* gm
     *cap = ((uint32_t)((uint64_t)g * 1000 / lf) + 7) & ~7u;
 }
 
-// number of partitions for `hint` expected groups: mean + 5 sigma of a partition's group count must fit gmax (0: no plan)
-uint32_t aqg_partition_parts(int ksz, const AccSpec& as, int need_count, uint32_t hint) {
+// the slot-indexed layout (p1_agg_slot_kernel): slots one partition's LDS holds, and the groups it is planned for (load 0.6)
+static void p1_slot_capacity(int ksz, const AccSpec& as, int need_count, uint32_t* cap, uint32_t* groups) {
+    const size_t per = (size_t)ksz + 4 + (need_count ? 4 : 0) + 8 * (size_t)as.nacc;
+    size_t c = (AGG_LDS - 64) / per;
+    if (c > 32768) c = 32768;
+    *cap = (uint32_t)(c > 16 ? c - 2 : 0) & ~7u;
+    *groups = (uint32_t)((uint64_t)*cap * 600 / 1000);
+}
+// number of partitions for `hint` expected groups: mean + 5 sigma of a partition's group count must fit gmax (0: no plan).
+// *layout (optional): AQG_P1_LAYOUT_SLOT when the accumulators can sit inside the key table within the two-level plan's partition limit
+// (one dependent LDS round trip per row instead of three), else AQG_P1_LAYOUT_DENSE_IDS (fewer, fuller partitions)
+uint32_t aqg_partition_parts(int ksz, const AccSpec& as, int need_count, uint32_t hint, int* layout) {
+    if (layout) {
+        *layout = AQG_P1_LAYOUT_DENSE_IDS;
+        static const bool slot_off = getenv("AQG_DISABLE_SLOT_LAYOUT") != nullptr;     // A/B measurements only
+        static const int forced = getenv("AQG_P1_BINS") ? atoi(getenv("AQG_P1_BINS")) : 0;
+        uint32_t scap, sgroups;
+        p1_slot_capacity(ksz, as, need_count, &scap, &sgroups);
+        if (!slot_off && !forced && sgroups >= 256) {
+            double mu = (double)sgroups;
+            for (int it = 0; it < 8; ++it) mu = (double)sgroups - 5.0 * sqrt(mu);
+            uint64_t bins = (uint64_t)((double)hint / mu) + 1;
+            if (bins < 256) bins = 256;
+            if (bins <= AQG_P2_MAXPARTS - 64) { *layout = AQG_P1_LAYOUT_SLOT; return (uint32_t)bins; }
+        }
+    }
     uint32_t gmax, cap;
     p1_capacity(ksz, as, need_count, &gmax, &cap);
     // mu + 5 sqrt(mu) <= gmax - 1
@@ -1391,9 +1587,40 @@ static int p1_launch_agg_direct(aqg_ctx* ctx, const AccSpec& as, const ValCols& 
 
 static int p1_launch_agg(aqg_ctx* ctx, int ksz, const AccSpec& as, const ValCols& vc, const void* pkeys, const void* prows, void* const* pvals,
                          const uint32_t* pstart, uint32_t pstride, uint32_t nparts, uint32_t n, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr,
-                         const PackPlan* pp = nullptr) {
+                         const PackPlan* pp = nullptr, int layout = AQG_P1_LAYOUT_DENSE_IDS) {
     AggIn in; AggOps ops; bool v8;
     p1_agg_args(as, vc, pvals, pp, &in, &ops, &v8);
+    if (layout == AQG_P1_LAYOUT_SLOT) {
+        uint32_t scap, sgroups;
+        p1_slot_capacity(ksz, as, need_count, &scap, &sgroups);
+        const size_t lds = (size_t)(scap + 2) * ((size_t)ksz + 4 + (need_count ? 4 : 0) + 8 * (size_t)as.nacc) + 16;
+        const unsigned grid = nparts < (unsigned)ctx->num_cu ? nparts : (unsigned)ctx->num_cu;
+        uint32_t* part_base = nullptr;
+        if (pr) {
+            AQG_TRY(aqg_ws_get(ctx, 2 * (size_t)nparts + 2, &part_base));
+            AQG_HIP(ctx, hipMemsetAsync(part_base, 0, (2 * (size_t)nparts + 2) * 4, ctx->stream));
+            pr->keys = pkeys; pr->rows = static_cast<const uint32_t*>(prows); pr->pstart = pstart; pr->pstride = pstride; pr->nparts = nparts; pr->ntotal = n;
+            pr->ksz = ksz; pr->part_base = part_base; pr->cap = scap; pr->valid = true;
+        }
+        auto launch = [&](auto kern) -> int {
+            AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
+            aqg_kernel_timer_begin(ctx);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(SB), lds, ctx->stream, pkeys, static_cast<const uint32_t*>(prows), as, in, ops, pstart, pstride, nparts, n, scap, need_count, out, out_cap, part_base);
+            aqg_kernel_timer_end(ctx);
+            return aqg_check_launch(ctx, "p1_agg_slot_kernel");
+        };
+        auto pick = [&](auto nacc) -> int {
+            constexpr int N = decltype(nacc)::value;
+            if (ksz == 4) return v8 ? launch(&p1_agg_slot_kernel<N, false, true>) : launch(&p1_agg_slot_kernel<N, false, false>);
+            return v8 ? launch(&p1_agg_slot_kernel<N, true, true>) : launch(&p1_agg_slot_kernel<N, true, false>);
+        };
+#define AQG_P1_CASE(N) case N: return pick(std::integral_constant<int, N>{});
+        switch (as.nacc) {
+        AQG_P1_CASE(0) AQG_P1_CASE(1) AQG_P1_CASE(2) AQG_P1_CASE(3) AQG_P1_CASE(4) AQG_P1_CASE(5) AQG_P1_CASE(6) AQG_P1_CASE(7)
+        default: return pick(std::integral_constant<int, 8>{});
+        }
+#undef AQG_P1_CASE
+    }
     uint32_t gmax, cap;
     p1_capacity(ksz, as, need_count, &gmax, &cap);
     const size_t lds = (size_t)gmax * (4 + (need_count ? 4 : 0) + 8 * (size_t)as.nacc) + (size_t)cap * (ksz + 2) + 16;
@@ -1440,7 +1667,7 @@ size_t aqg_partition1_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
 
 // Partitioned aggregation of (ks, as) over n rows into the compact record table `out` (AoS records, `out_cap` slots,
 // flags[1] = number of groups written, flags[0] = overflow).  Needs packed (<= 8 byte) keys and nbins from aqg_partition1_bins.
-int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap, PartRows* pr) {
+int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap, PartRows* pr, int layout) {
     if (nbins < 1 || nbins > AQG_P1_MAXBINS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "one-level partitioned group-by: 1..3584 bins");
     const int ksz = ks.total_bytes <= 4 ? 4 : 8;
     Chunks ch;
@@ -1513,7 +1740,7 @@ int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     };
     if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
 
-    return p1_launch_agg(ctx, ksz, as, vc, pkeys, prows, pvals, hist, ch.nchunks, nbins, n, need_count, out, out_cap, pr);
+    return p1_launch_agg(ctx, ksz, as, vc, pkeys, prows, pvals, hist, ch.nchunks, nbins, n, need_count, out, out_cap, pr, nullptr, layout);
 }
 
 
@@ -1532,7 +1759,7 @@ size_t aqg_partition2_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
     return ((size_t)n + 64) * per_row + 256 * (8 + 4 * MAXACC) + (size_t)p2_round_parts(parts) * 16 + 65536;
 }
 
-int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr, int* pack) {
+int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr, int* pack, int layout) {
     const int ksz = ks.total_bytes <= 4 ? 4 : 8;
     ValCols vc;
     p1_val_cols(as, &vc);
@@ -1658,7 +1885,7 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     };
     if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
     if (rp.on) return p1_launch_agg_direct(ctx, as, vc, keysB, rowsB, valsB, fstart, n, need_count, out, out_cap, pp.n ? &pp : nullptr, rp);
-    return p1_launch_agg(ctx, ksz, as, vc, keysB, rowsB, valsB, fstart, 1u, P, n, need_count, out, out_cap, pr, pp.n ? &pp : nullptr);
+    return p1_launch_agg(ctx, ksz, as, vc, keysB, rowsB, valsB, fstart, 1u, P, n, need_count, out, out_cap, pr, pp.n ? &pp : nullptr, layout);
 }
 
 // ---- wide tuples: host ----------------------------------------------------------------------------------------------------------------

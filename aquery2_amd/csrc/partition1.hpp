@@ -5,13 +5,14 @@
 constexpr uint32_t AQG_P1_MAXBINS = 3584;    // one level: scatter LDS = 128 KB of staging + 8 B per bin
 constexpr uint32_t AQG_P2_MAXPARTS = 4096;   // two levels: 64 x 64 bins
 // partitions needed for `hint` expected groups (mean + 5 sigma of a partition's groups fit its LDS tables); 0: none
-uint32_t aqg_partition_parts(int ksz, const AccSpec& as, int need_count, uint32_t hint);
+enum : int { AQG_P1_LAYOUT_DENSE_IDS = 0, AQG_P1_LAYOUT_SLOT = 1 };   // where a partition's accumulators sit in LDS (p1_agg_kernel / p1_agg_slot_kernel)
+uint32_t aqg_partition_parts(int ksz, const AccSpec& as, int need_count, uint32_t hint, int* layout = nullptr);
 // where a partition plan left the rows {key word, row id} and which records every partition wrote: what the build's id pass needs
 struct PartRows { const void* keys; const uint32_t* rows; const uint32_t* pstart; uint32_t pstride, nparts, ntotal; int ksz; uint32_t* part_base; uint32_t cap; bool valid; };
 size_t aqg_partition1_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t nbins);
-int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr);
+int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr, int layout = 0);
 size_t aqg_partition2_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t parts);
-int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr, int* pack = nullptr);   // *pack: in, packing allowed; out, value columns that travelled inside the key word
+int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr, int* pack = nullptr, int layout = 0);   // *pack: in, packing allowed; out, bit 0 value columns travelled inside the key word, bit 1 range partitions
 // the build's id pass over the partitioned rows: reversemap[row] = dense id of the row's key (slot_gid: record -> dense id)
 int aqg_partition_assign(aqg_ctx* ctx, const PartRows& pr, GTable gt, const uint32_t* slot_gid, uint32_t* reversemap);
 size_t aqg_partition_assign_ws_bytes(uint32_t n);
