@@ -397,10 +397,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          # `traffic` is a PMC counter of THIS run or null: bench.py collects none (counters need their own rocprofv3
                          # passes).  The profiled figure at 1e9 rows (FETCH_SIZE x2 + WRITE_SIZE, separate passes) is carried with
-                         # the file it comes from: Q1 8.0255 GB read + 0.0121 GB written, join 12.001 + 0.018.
+                         # the file it comes from: Q1 8.024 GB read + 0.012 GB written, join 12.001 + 0.018.
                          "traffic": None,
-                         "traffic_profiled": {"bytes_at_1e9_rows": 12.019e9 if join else 8.0376e9,
-                                              "source": "profiles/r1_groupby_join_1e9_pmc.md" if join else "profiles/r2_bench_q1_1e9_pmc.md"},
+                         "traffic_profiled": {"bytes_at_1e9_rows": 12.019e9 if join else 8.036e9,
+                                              "source": "profiles/r1_groupby_join_1e9_pmc.md" if join else "profiles/r3_bench_q1_1e9_pmc.md"},
                          "kernel": "starjoin_kernel" if join else "agg32_kernel<1,false,false,4>", "kernel_ms": k_ms, "algorithmic_bytes": bpr * n},
         }
         if world == 1 and comm is None and args.cpu_sample > 0 and not join:
