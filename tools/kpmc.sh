@@ -2,14 +2,14 @@
 # run on the GPU box: SQ counters of the kernels whose name contains $1 while `python3 tools/q5_probe.py 1e9 $2` runs
 # (counters in their own passes, no kernel trace beside them)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-PAT=${1:-p1_agg}; W=${2:-q5}; O=gpurun_out/kpmc
+PAT=${1:-p1_agg}; W=${2:-q5}; O=gpurun_out/kpmc; CMD=${3:-"tools/q5_probe.py 1e9 $W"}
 rm -rf $O; mkdir -p $O
 i=0
 for pmc in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_SCA" \
            "SQ_WAVES SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -k 10 200 rocprofv3 --pmc $pmc --output-format csv -d $O/p$i -o p -- python3 tools/q5_probe.py 1e9 $W > $O/p$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $O/p$i.log; }
+  timeout -k 10 200 rocprofv3 --pmc $pmc --output-format csv -d $O/p$i -o p -- python3 $CMD > $O/p$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $O/p$i.log; }
 done
 python3 - "$PAT" <<'PY'
 import csv, glob, collections, sys

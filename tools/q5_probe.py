@@ -10,6 +10,7 @@ d = A.Device(0)
 K = 100
 col = lambda c: d.gen_column(c, 42, 0, n, n, K)
 id3, id6, v1, v2, v3 = (col(c) for c in (ck.GEN_ID3, ck.GEN_ID6, ck.GEN_V1, ck.GEN_V2, ck.GEN_V3))
+print('ptrs', ' '.join(f'{c.ptr:#x}' for c in (id3, id6, v1, v2, v3)), flush=True)
 shapes = {"q3": ([id3], [ck.RED_SUM, ck.RED_AVG], [v1, v3], 12), "q5": ([id6], [ck.RED_SUM] * 3, [v1, v2, v3], 16), "q7": ([id3], [ck.RED_MAX, ck.RED_MIN], [v1, v2], 12)}
 for w in which:
     keys, ops, vals, bpr = shapes[w]
