@@ -1402,7 +1402,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         h->plan_bits = (use_wpart ? AQG_PLAN_PART_WIDE : p1_bins ? AQG_PLAN_PART_ONE : p2_parts ? AQG_PLAN_PART_TWO : AQG_PLAN_PART_ROUND1) | (sorted_tail ? AQG_PLAN_SORTED_TAIL : 0u);
         if (use_wpart) {
             int pack = h->no_pack ? 0 : 1;
-            AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed, hint, &pack));
+            AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed, hint, &pack, &h->wide_rows));
             if (pack) h->plan_bits |= AQG_PLAN_PACKED_KEYS;
         }
         else if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap, for_build ? &prows : nullptr, part_layout));
@@ -1468,7 +1468,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
             // seed spreads -- the HBM table, same hint
             static const bool debug_flags = getenv("AQG_DEBUG_FLAGS") != nullptr;
             if (debug_flags) fprintf(stderr, "aqg: wide partition plan gave up: flags %u %u %u %u, partition %u holds %u rows (n %u, hint %u, seed %u)\n", fl[0], fl[1], fl[2], fl[3], fl[4], fl[5], n, hint, h->wide_seed);
-            const uint32_t rcap = aqg_partitionw_rows(ks, as, n, hint);
+            const uint32_t rcap = h->wide_rows ? h->wide_rows : aqg_partitionw_rows(ks, as, n, hint);
             if (!fl[5]) return AQG_ERR_OVERFLOW;     // no partition was too large: the record table (out_cap) was -- more groups than hinted, the caller grows the hint
             if (h->wide_seed == 0 && fl[5] <= rcap + rcap / 2) h->wide_seed = 0x5BD1E995u; else h->no_wide_part = true;
             return AQG_ERR_RANGE_MISS;

@@ -43,6 +43,7 @@ struct aqg_groupby {
     bool no_sorted_tail = false;                // the ordering tail met a partition outside its plan: the bitmap tail from now on
     bool no_pack = false;                       // a value column did not keep to the sampled range of its field in the key word: unpacked planes from now on
     bool no_wide_part = false;                  // a wide-tuple partition overflowed its LDS capacity (a dominant tuple, or twice by chance): HBM table from now on
+    uint32_t wide_rows = 0;                     // rows one partition of the last wide-tuple plan could hold (packed tuples: more than the unpacked plan's)
     uint32_t wide_seed = 0;                     // seed of the partition hash: bumped once when a partition overflowed by a little (chance, not a dominant tuple)
     bool dense_exact = false;         // a sampled key range missed values once: take exact ranges from now on
     // sampled key ranges of the last dense plan made through this handle: a call over the same columns takes them without the

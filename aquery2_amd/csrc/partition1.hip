@@ -1894,11 +1894,12 @@ static size_t pw_row_lds(int nkd, int nacc) { return 4 * (size_t)nkd + 4 + 4 + 8
 // `hint` = the expected number of groups: with m = n / hint rows per tuple the rows of a partition are not independent -- the tuples are --
 // and the spread of a partition's ROW count grows to sqrt(mean * m) (every tuple brings its m rows along); sizing by sqrt(mean) alone sent
 // every table of multi-row tuples through two overflowing attempts to the HBM table (3.2e6 rows, 1.26e6 tuples: partitions at mean + 7 sigma)
-static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t hint) {
+static WidePlan pw_plan(const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t hint, int packed_nkd = 0 /* key dword planes when the tuple travels packed */) {
     WidePlan best;
     memset(&best, 0, sizeof best);
     int nkd = 0;
     for (int k = 0; k < ks.nkeys; ++k) nkd += aqg_dtype_size(ks.dt[k]) <= 4 ? 1 : 2;
+    if (packed_nkd > 0 && packed_nkd < nkd) nkd = packed_nkd;
     if (nkd > 2 * MAXKEYS) return best;
     // workgroups per CU: three of 512 threads, two of 1024, one of 1024 -- the first that needs no more levels than the last
     // (four workgroups of 512 -- 39 KB each, 128 x 128 x 128 partitions of ~720 rows -- measured 39 ms against 24-26 for three)
@@ -1991,8 +1992,8 @@ static bool plan_packw(aqg_ctx* ctx, const KeySpec& ks, uint32_t n, PackW* pk, i
     return true;
 }
 
-int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap, uint32_t seed, uint32_t hint, int* pack) {
-    const WidePlan w = pw_plan(ks, as, n, hint);
+int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap, uint32_t seed, uint32_t hint, int* pack, uint32_t* rows_out) {
+    WidePlan w = pw_plan(ks, as, n, hint);
     if (!w.ok) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "wide-tuple partitioned group-by: the input does not fit 128 x 128 x 128 partitions");
     ValCols vc;
     p1_val_cols(as, &vc);
@@ -2027,7 +2028,12 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         else hipLaunchKernelGGL(pw_hash_kernel, dim3(g4), dim3(256), 0, ctx->stream, ks, n, seed, h32);
     }
     if (pack) *pack = packed ? 1 : 0;
-    const int nkd = packed ? pk.nout : w.nkd;             // key dword planes that travel (R, P and the LDS size stay those of the unpacked plan)
+    if (packed) {                                         // fewer key dwords per row: more rows per partition, fewer partitions (the workspace was sized for the unpacked plan: more of each)
+        const WidePlan wp = pw_plan(ks, as, n, hint, pk.nout);
+        if (wp.ok && wp.P <= w.P) w = wp;
+    }
+    if (rows_out) *rows_out = w.R;
+    const int nkd = packed ? pk.nout : w.nkd;             // key dword planes that travel
     // source planes: the key columns as dwords (1- / 2-byte ones widened, 8-byte ones as two planes), then the distinct value columns
     struct Src { const void* p; int stride, off, bytes; };
     std::vector<Src> ksrc, vsrc;
