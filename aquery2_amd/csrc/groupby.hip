@@ -1405,7 +1405,11 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
             AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed, hint, &pack, &h->wide_rows));
             if (pack) h->plan_bits |= AQG_PLAN_PACKED_KEYS;
         }
-        else if (p1_bins) AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap, for_build ? &prows : nullptr, part_layout));
+        else if (p1_bins) {
+            int ranged = h->no_pack ? 0 : 1;
+            AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap, for_build ? &prows : nullptr, part_layout, &ranged));
+            if (ranged) h->plan_bits |= AQG_PLAN_RANGE_PARTITIONS;
+        }
         else if (p2_parts) {
             int pack = h->no_pack ? 0 : 1;
             AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap, for_build ? &prows : nullptr, &pack, part_layout));

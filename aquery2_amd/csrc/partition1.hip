@@ -68,7 +68,20 @@ struct Planes { int n; Plane p[MAXPL]; PackSpec pk; };
 
 // Chunks of whole tiles cover rows [0, nfull); the rows behind the last whole tile, if any, are one more chunk (the TAIL chunk,
 // index nchunks - 1), scattered by its own small kernel so that the main kernel never sees a partial tile.
-struct Chunks { uint32_t n, nfull, chunk_rows, nchunks, nbins, has_tail; };
+struct Chunks {
+    uint32_t n, nfull, chunk_rows, nchunks, nbins, has_tail;
+    // range partitions (the one-level form of BIN_RANGED below): bin = umulhi(min(key - kmin, xmax), rmul); rflag is set by a key outside the sampled domain
+    uint32_t ranged, kmin, xmax, rmul; uint32_t* rflag;
+};
+template <bool K64> __device__ inline uint32_t key_hash(key_t_<K64> k);
+template <bool K64, bool RANGED> __device__ inline uint32_t p1_bin(const Chunks& ch, key_t_<K64> key, uint32_t& outside) {
+    if constexpr (RANGED && !K64) {
+        uint32_t x = (uint32_t)key - ch.kmin;
+        outside |= x > ch.xmax ? 1u : 0u;
+        x = x < ch.xmax ? x : ch.xmax;
+        return __umulhi(x, ch.rmul);
+    } else return __umulhi(key_hash<K64>(key), ch.nbins);
+}
 __device__ inline void chunk_range(const Chunks& ch, uint32_t c, uint64_t& b, uint64_t& e) {
     if (ch.has_tail && c + 1 == ch.nchunks) { b = ch.nfull; e = ch.n; return; }
     b = (uint64_t)c * ch.chunk_rows;
@@ -88,7 +101,7 @@ __global__ void __launch_bounds__(256) p1_widen_kernel(const void* __restrict__ 
 
 // ---- bin counts of every chunk -----------------------------------------------------------------------------------------------
 constexpr int HR = 16;   // rows per thread and step of the histogram pass
-template <bool K64>
+template <bool K64, bool RANGED = false>
 __global__ void __launch_bounds__(SB) p1_hist_kernel(const key_t_<K64>* __restrict__ keys, Chunks ch, uint32_t* __restrict__ hist /* [bin][chunk] */) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint32_t* cnt = reinterpret_cast<uint32_t*>(smem_raw);
@@ -102,7 +115,7 @@ __global__ void __launch_bounds__(SB) p1_hist_kernel(const key_t_<K64>* __restri
         if (nrows == SB * HR) load_rows<true>(keys, rb, nrows, 0, key); else load_rows<false>(keys, rb, nrows, 0, key);
 #pragma unroll
         for (int r = 0; r < HR; ++r)
-            if (tile_row(r) < nrows) atomicAdd(&cnt[__umulhi(key_hash<K64>(key[r]), ch.nbins)], 1u);
+            if (tile_row(r) < nrows) { uint32_t o_ = 0; atomicAdd(&cnt[p1_bin<K64, RANGED>(ch, key[r], o_)], 1u); }      // (a key outside the sampled domain: the scatter flags it)
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < ch.nbins; b += SB) hist[(size_t)b * ch.nchunks + blockIdx.x] = cnt[b];
@@ -113,8 +126,10 @@ __global__ void __launch_bounds__(SB) p1_hist_kernel(const key_t_<K64>* __restri
 // batches of H (all loads of a batch are issued before the first use: memory-level parallelism is what bounds these kernels,
 // and 32 rows at once did not fit 128 registers); the keys are not kept: the key planes load them again (from L2).
 constexpr int H = 16;
-template <bool K64, bool FULL>
-__device__ inline void scatter_tile(const key_t_<K64>* __restrict__ keys, const Planes& pl, uint32_t NB, uint64_t rb, uint32_t nrows, uint32_t* stage, uint32_t* lb, uint32_t* gd, uint32_t* wsum) {
+template <bool K64, bool FULL, bool RANGED = false>
+__device__ inline void scatter_tile(const key_t_<K64>* __restrict__ keys, const Planes& pl, const Chunks& ch, uint64_t rb, uint32_t nrows, uint32_t* stage, uint32_t* lb, uint32_t* gd, uint32_t* wsum) {
+    const uint32_t NB = ch.nbins;
+    uint32_t outside = 0;
     for (uint32_t b = threadIdx.x; b <= NB; b += SB) lb[b] = 0;
     __syncthreads();
     uint32_t pos[SR];                                         // (bin << 15) | rank, later the staged position
@@ -125,10 +140,11 @@ __device__ inline void scatter_tile(const key_t_<K64>* __restrict__ keys, const 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < H; ++r) {
-            const uint32_t d = __umulhi(key_hash<K64>(key[r]), NB);
+            const uint32_t d = p1_bin<K64, RANGED>(ch, key[r], outside);
             pos[h + r] = FULL || tile_row(h + r) < nrows ? (d << 15) | atomicAdd(&lb[d], 1u) : 0xFFFFFFFFu;
         }
     }
+    if constexpr (RANGED) { if (outside) *ch.rflag = 1u; }      // (rows beyond a partial tile repeat its last row: no false alarm)
     __syncthreads();
     {   // exclusive scan of the bin counts: a thread owns bins 4 tid .. 4 tid + 3 (NB <= 4096)
         uint32_t c[4], s = 0;
@@ -206,7 +222,7 @@ __device__ inline void scatter_tile(const key_t_<K64>* __restrict__ keys, const 
     __syncthreads();
 }
 
-template <bool K64>
+template <bool K64, bool RANGED = false>
 __global__ void __launch_bounds__(SB) p1_scatter_kernel(const key_t_<K64>* __restrict__ keys, Planes pl, Chunks ch, const uint32_t* __restrict__ hist_scanned) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);      // [PT] one plane of the tile, bin-major
@@ -217,10 +233,10 @@ __global__ void __launch_bounds__(SB) p1_scatter_kernel(const key_t_<K64>* __res
     uint64_t cb, ce;
     chunk_range(ch, blockIdx.x, cb, ce);
     for (uint32_t b = threadIdx.x; b < NB; b += SB) gd[b] = hist_scanned[(size_t)b * ch.nchunks + blockIdx.x];
-    for (uint64_t rb = cb; rb + PT <= ce; rb += PT) scatter_tile<K64, true>(keys, pl, NB, rb, PT, stage, lb, gd, wsum);
+    for (uint64_t rb = cb; rb + PT <= ce; rb += PT) scatter_tile<K64, true, RANGED>(keys, pl, ch, rb, PT, stage, lb, gd, wsum);
 }
 // the tail chunk: fewer rows than a tile (one workgroup, once per call)
-template <bool K64>
+template <bool K64, bool RANGED = false>
 __global__ void __launch_bounds__(SB) p1_scatter_tail_kernel(const key_t_<K64>* __restrict__ keys, Planes pl, Chunks ch, const uint32_t* __restrict__ hist_scanned) {
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);
@@ -229,7 +245,7 @@ __global__ void __launch_bounds__(SB) p1_scatter_tail_kernel(const key_t_<K64>* 
     __shared__ uint32_t wsum[SB / 64];
     const uint32_t NB = ch.nbins, c = ch.nchunks - 1;
     for (uint32_t b = threadIdx.x; b < NB; b += SB) gd[b] = hist_scanned[(size_t)b * ch.nchunks + c];
-    scatter_tile<K64, false>(keys, pl, NB, ch.nfull, ch.n - ch.nfull, stage, lb, gd, wsum);
+    scatter_tile<K64, false, RANGED>(keys, pl, ch, ch.nfull, ch.n - ch.nfull, stage, lb, gd, wsum);
 }
 
 // ---- aggregate each partition in LDS ---------------------------------------------------------------------------------------------
@@ -453,7 +469,7 @@ __global__ void __launch_bounds__(SB) p1_agg_kernel(const void* __restrict__ rke
 struct DirectSpec { uint32_t M, kmin, D, W; uint32_t* miss; };
 template <int NACC, bool V8>
 __global__ void __launch_bounds__(SB) p1_agg_direct_kernel(const uint32_t* __restrict__ rkeys, const uint32_t* __restrict__ rrows, AccSpec as, AggIn in, AggOps ops,
-                                                           const uint32_t* __restrict__ pstart, uint32_t NB, uint32_t ntotal, DirectSpec ds, int need_count,
+                                                           const uint32_t* __restrict__ pstart, uint32_t pstride, uint32_t NB, uint32_t ntotal, DirectSpec ds, int need_count,
                                                            GTable out, uint32_t out_cap) {
     using VT = std::conditional_t<V8, uint64_t, uint32_t>;
     constexpr int NA = NACC ? NACC : 1;
@@ -492,8 +508,8 @@ __global__ void __launch_bounds__(SB) p1_agg_direct_kernel(const uint32_t* __res
         }
     };
     for (uint32_t part = blockIdx.x; part < NB; part += gridDim.x) {
-        const uint32_t b = pstart[part];
-        const uint32_t e = part + 1 < NB ? pstart[part + 1] : ntotal;
+        const uint32_t b = pstart[(size_t)part * pstride];
+        const uint32_t e = part + 1 < NB ? pstart[(size_t)(part + 1) * pstride] : ntotal;
         if (b == e) continue;
         // the piece of the domain this partition owns: x in [lo, hi), lo = the smallest x with umulhi(x, M) >= part
         uint64_t lo64 = (((uint64_t)part << 32) + ds.M - 1) / ds.M, hi64 = ((((uint64_t)part + 1) << 32) + ds.M - 1) / ds.M;
@@ -1560,7 +1576,7 @@ static void plan_range(const PackPlan& pp, const AccSpec& as, int need_count, ui
     (void)parts_hashed;
 }
 static int p1_launch_agg_direct(aqg_ctx* ctx, const AccSpec& as, const ValCols& vc, const void* pkeys, const void* prows, void* const* pvals,
-                                const uint32_t* pstart, uint32_t n, int need_count, GTable out, uint32_t out_cap, const PackPlan* pp, const RangePlan& rp) {
+                                const uint32_t* pstart, uint32_t pstride, uint32_t n, int need_count, GTable out, uint32_t out_cap, const PackPlan* pp, const RangePlan& rp) {
     AggIn in; AggOps ops; bool v8;
     p1_agg_args(as, vc, pvals, pp, &in, &ops, &v8);
     const size_t lds = (size_t)(rp.W + 1) * (4 + (need_count ? 4 : 0) + 8 * (size_t)as.nacc) + 16;
@@ -1569,7 +1585,7 @@ static int p1_launch_agg_direct(aqg_ctx* ctx, const AccSpec& as, const ValCols& 
     auto launch = [&](auto kern) -> int {
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
         aqg_kernel_timer_begin(ctx);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(SB), lds, ctx->stream, static_cast<const uint32_t*>(pkeys), static_cast<const uint32_t*>(prows), as, in, ops, pstart, rp.P, n, ds, need_count, out, out_cap);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(SB), lds, ctx->stream, static_cast<const uint32_t*>(pkeys), static_cast<const uint32_t*>(prows), as, in, ops, pstart, pstride, rp.P, n, ds, need_count, out, out_cap);
         aqg_kernel_timer_end(ctx);
         return aqg_check_launch(ctx, "p1_agg_direct_kernel");
     };
@@ -1667,14 +1683,27 @@ size_t aqg_partition1_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
 
 // Partitioned aggregation of (ks, as) over n rows into the compact record table `out` (AoS records, `out_cap` slots,
 // flags[1] = number of groups written, flags[0] = overflow).  Needs packed (<= 8 byte) keys and nbins from aqg_partition1_bins.
-int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap, PartRows* pr, int layout) {
+int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap, PartRows* pr, int layout, int* ranged) {
     if (nbins < 1 || nbins > AQG_P1_MAXBINS) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "one-level partitioned group-by: 1..3584 bins");
     const int ksz = ks.total_bytes <= 4 ? 4 : 8;
+    ValCols vc;
+    p1_val_cols(as, &vc);
+    // a dense 4-byte key domain: range partitions and the direct-indexed aggregation, as in the two-level plan (no more bins than the
+    // hashed plan was given: the workspace is sized by them)
+    RangePlan rp;
+    memset(&rp, 0, sizeof rp);
+    if (ranged && *ranged && !pr) {
+        PackPlan pp;
+        AQG_TRY(plan_pack(ctx, ks, as, n, vc, &pp));          // (its sample of the key range; nothing is packed on this path)
+        plan_range(pp, as, need_count, nbins, &rp);
+        if (rp.on && rp.P > nbins) rp.on = false;
+    }
+    if (ranged) *ranged = rp.on ? 1 : 0;
+    if (rp.on) nbins = rp.P;
     Chunks ch;
     p1_geometry(ctx, n, &ch);
     ch.nbins = nbins;
-    ValCols vc;
-    p1_val_cols(as, &vc);
+    ch.ranged = rp.on ? 1u : 0u; ch.kmin = rp.kmin; ch.xmax = rp.on ? rp.D - 1 : 0u; ch.rmul = rp.M; ch.rflag = out.flags + 6;
 
     // the key as ONE column of 4- or 8-byte words: the user's column, or the packed tuple
     const void* keycol = ks.col[0];
@@ -1723,23 +1752,26 @@ int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     const size_t hist_lds = (size_t)nbins * 4;
     const size_t scat_lds = (size_t)PT * 4 + ((size_t)nbins * 2 + 1) * 4;
     const unsigned nmain = ch.nchunks - ch.has_tail;
-    auto run = [&](auto k64) -> int {
-        constexpr bool K = decltype(k64)::value;
+    auto run = [&](auto k64, auto rng) -> int {
+        constexpr bool K = decltype(k64)::value, R = decltype(rng)::value;
         const key_t_<K>* kc = static_cast<const key_t_<K>*>(keycol);
-        hipLaunchKernelGGL((p1_hist_kernel<K>), dim3(ch.nchunks), dim3(SB), hist_lds, ctx->stream, kc, ch, hist);
+        hipLaunchKernelGGL((p1_hist_kernel<K, R>), dim3(ch.nchunks), dim3(SB), hist_lds, ctx->stream, kc, ch, hist);
         AQG_TRY(aqg_exclusive_scan_u32(ctx, hist, hcount, bsum));
         if (nmain) {
-            AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p1_scatter_kernel<K>), scat_lds));
-            hipLaunchKernelGGL((p1_scatter_kernel<K>), dim3(nmain), dim3(SB), scat_lds, ctx->stream, kc, pl, ch, (const uint32_t*)hist);
+            AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p1_scatter_kernel<K, R>), scat_lds));
+            hipLaunchKernelGGL((p1_scatter_kernel<K, R>), dim3(nmain), dim3(SB), scat_lds, ctx->stream, kc, pl, ch, (const uint32_t*)hist);
         }
         if (ch.has_tail) {
-            AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p1_scatter_tail_kernel<K>), scat_lds));
-            hipLaunchKernelGGL((p1_scatter_tail_kernel<K>), dim3(1), dim3(SB), scat_lds, ctx->stream, kc, pl, ch, (const uint32_t*)hist);
+            AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p1_scatter_tail_kernel<K, R>), scat_lds));
+            hipLaunchKernelGGL((p1_scatter_tail_kernel<K, R>), dim3(1), dim3(SB), scat_lds, ctx->stream, kc, pl, ch, (const uint32_t*)hist);
         }
         return aqg_check_launch(ctx, "one-level partition scatter");
     };
-    if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
+    if (rp.on) AQG_TRY(run(std::false_type{}, std::true_type{}));
+    else if (ksz == 4) AQG_TRY(run(std::false_type{}, std::false_type{}));
+    else AQG_TRY(run(std::true_type{}, std::false_type{}));
 
+    if (rp.on) return p1_launch_agg_direct(ctx, as, vc, pkeys, prows, pvals, hist, ch.nchunks, n, need_count, out, out_cap, nullptr, rp);
     return p1_launch_agg(ctx, ksz, as, vc, pkeys, prows, pvals, hist, ch.nchunks, nbins, n, need_count, out, out_cap, pr, nullptr, layout);
 }
 
@@ -1884,7 +1916,7 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         return aqg_check_launch(ctx, "two-level partition scatter");
     };
     if (ksz == 4) AQG_TRY(run(std::false_type{})); else AQG_TRY(run(std::true_type{}));
-    if (rp.on) return p1_launch_agg_direct(ctx, as, vc, keysB, rowsB, valsB, fstart, n, need_count, out, out_cap, pp.n ? &pp : nullptr, rp);
+    if (rp.on) return p1_launch_agg_direct(ctx, as, vc, keysB, rowsB, valsB, fstart, 1u, n, need_count, out, out_cap, pp.n ? &pp : nullptr, rp);
     return p1_launch_agg(ctx, ksz, as, vc, keysB, rowsB, valsB, fstart, 1u, P, n, need_count, out, out_cap, pr, pp.n ? &pp : nullptr, layout);
 }
 

@@ -7,7 +7,7 @@ import checker as ck
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100_000_000
 which = sys.argv[2].split(",") if len(sys.argv) > 2 else ["q5"]
 d = A.Device(0)
-K = 100
+K = int(float(sys.argv[3])) if len(sys.argv) > 3 else 100                  # rows per group
 col = lambda c: d.gen_column(c, 42, 0, n, n, K)
 id3, id6, v1, v2, v3 = (col(c) for c in (ck.GEN_ID3, ck.GEN_ID6, ck.GEN_V1, ck.GEN_V2, ck.GEN_V3))
 print('ptrs', ' '.join(f'{c.ptr:#x}' for c in (id3, id6, v1, v2, v3)), flush=True)
