@@ -1408,7 +1408,8 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         else if (p1_bins) {
             int ranged = h->no_pack ? 0 : 1;
             AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap, for_build ? &prows : nullptr, part_layout, &ranged));
-            if (ranged) h->plan_bits |= AQG_PLAN_RANGE_PARTITIONS;
+            if (ranged & 2) h->plan_bits |= AQG_PLAN_RANGE_PARTITIONS;
+            if (ranged & 1) h->plan_bits |= AQG_PLAN_PACKED_VALUES;
         }
         else if (p2_parts) {
             int pack = h->no_pack ? 0 : 1;

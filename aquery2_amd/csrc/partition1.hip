@@ -196,6 +196,18 @@ __device__ inline void scatter_tile(const key_t_<K64>* __restrict__ keys, const 
             if (P.kind == PL_ROWIDX) {
 #pragma unroll
                 for (int r = 0; r < H; ++r) v[r] = (uint32_t)rb + tile_row(h + r);
+            } else if (P.kind == PL_PACK) {            // the key word with the narrow value columns in its spare bits, every row verified (PackSpec)
+                load_rows<FULL>(P.src, rb, nrows, h, v);
+                uint32_t bad = 0;
+#pragma unroll
+                for (int r = 0; r < H; ++r) bad |= v[r] > pl.pk.kmax ? 1u : 0u;
+                for (int f = 0; f < pl.pk.n; ++f) {
+                    uint32_t x[H];
+                    load_rows<FULL>(pl.pk.src[f], rb, nrows, h, x);
+#pragma unroll
+                    for (int r = 0; r < H; ++r) { const uint32_t y = x[r] - pl.pk.min[f]; bad |= y > pl.pk.fmask[f] ? 1u : 0u; v[r] |= (y & pl.pk.fmask[f]) << pl.pk.shift[f]; }
+                }
+                if (bad) *pl.pk.flag = 1u;             // (rows beyond a partial tile repeat its last row: no false alarm)
             } else if (P.src_stride_dw == 1) {
                 load_rows<FULL>(P.src, rb, nrows, h, v);
             } else {                                   // one half of every element of an 8-byte column
@@ -1691,14 +1703,15 @@ int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     // a dense 4-byte key domain: range partitions and the direct-indexed aggregation, as in the two-level plan (no more bins than the
     // hashed plan was given: the workspace is sized by them)
     RangePlan rp;
+    PackPlan pp;
     memset(&rp, 0, sizeof rp);
+    memset(&pp, 0, sizeof pp);
     if (ranged && *ranged && !pr) {
-        PackPlan pp;
-        AQG_TRY(plan_pack(ctx, ks, as, n, vc, &pp));          // (its sample of the key range; nothing is packed on this path)
+        AQG_TRY(plan_pack(ctx, ks, as, n, vc, &pp));          // narrow value columns inside the key word, and the sample of the key range
         plan_range(pp, as, need_count, nbins, &rp);
         if (rp.on && rp.P > nbins) rp.on = false;
     }
-    if (ranged) *ranged = rp.on ? 1 : 0;
+    if (ranged) *ranged = (rp.on ? 2 : 0) | (pp.n ? 1 : 0);
     if (rp.on) nbins = rp.P;
     Chunks ch;
     p1_geometry(ctx, n, &ch);
@@ -1720,6 +1733,8 @@ int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * 4, &prows));
     const void* vsrc[MAXACC];
     for (int u = 0; u < vc.n; ++u) {
+        pvals[u] = nullptr; vsrc[u] = nullptr;
+        if (pack_field_of(pp, vc.col[u]) >= 0) continue;                     // travels in the key word
         AQG_TRY(aqg_ws_alloc(ctx, ((size_t)n + 64) * part_val_bytes(vc.dt[u]), &pvals[u]));
         vsrc[u] = vc.col[u];
         const int esz = (int)aqg_dtype_size(vc.dt[u]);
@@ -1742,10 +1757,16 @@ int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         P.kind = kind; P.src = static_cast<const uint32_t*>(s); P.src_stride_dw = sstride; P.src_off_dw = soff;
         P.dst = static_cast<uint32_t*>(d); P.dst_stride_dw = dstride; P.dst_off_dw = doff;
     };
-    if (ksz == 4) add(PL_LOAD, keycol, 1, 0, pkeys, 1, 0);
+    if (ksz == 4 && pp.n) {
+        add(PL_PACK, keycol, 1, 0, pkeys, 1, 0);
+        pl.pk.n = pp.n; pl.pk.kmax = pp.kmax; pl.pk.flag = out.flags + 6;
+        for (int f = 0; f < pp.n; ++f) { pl.pk.src[f] = static_cast<const uint32_t*>(pp.col[f]); pl.pk.min[f] = pp.min[f]; pl.pk.shift[f] = pp.shift[f]; pl.pk.fmask[f] = pp.fmask[f]; }
+    }
+    else if (ksz == 4) add(PL_LOAD, keycol, 1, 0, pkeys, 1, 0);
     else { add(PL_LOAD, keycol, 2, 0, pkeys, 2, 0); add(PL_LOAD, keycol, 2, 1, pkeys, 2, 1); }
     add(PL_ROWIDX, nullptr, 0, 0, prows, 1, 0);
     for (int u = 0; u < vc.n; ++u) {
+        if (!pvals[u]) continue;                                             // (packed)
         if (part_val_bytes(vc.dt[u]) == 4) add(PL_LOAD, vsrc[u], 1, 0, pvals[u], 1, 0);
         else { add(PL_LOAD, vsrc[u], 2, 0, pvals[u], 2, 0); add(PL_LOAD, vsrc[u], 2, 1, pvals[u], 2, 1); }
     }
@@ -1771,8 +1792,8 @@ int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     else if (ksz == 4) AQG_TRY(run(std::false_type{}, std::false_type{}));
     else AQG_TRY(run(std::true_type{}, std::false_type{}));
 
-    if (rp.on) return p1_launch_agg_direct(ctx, as, vc, pkeys, prows, pvals, hist, ch.nchunks, n, need_count, out, out_cap, nullptr, rp);
-    return p1_launch_agg(ctx, ksz, as, vc, pkeys, prows, pvals, hist, ch.nchunks, nbins, n, need_count, out, out_cap, pr, nullptr, layout);
+    if (rp.on) return p1_launch_agg_direct(ctx, as, vc, pkeys, prows, pvals, hist, ch.nchunks, n, need_count, out, out_cap, pp.n ? &pp : nullptr, rp);
+    return p1_launch_agg(ctx, ksz, as, vc, pkeys, prows, pvals, hist, ch.nchunks, nbins, n, need_count, out, out_cap, pr, pp.n ? &pp : nullptr, layout);
 }
 
 

@@ -10,7 +10,7 @@ uint32_t aqg_partition_parts(int ksz, const AccSpec& as, int need_count, uint32_
 // where a partition plan left the rows {key word, row id} and which records every partition wrote: what the build's id pass needs
 struct PartRows { const void* keys; const uint32_t* rows; const uint32_t* pstart; uint32_t pstride, nparts, ntotal; int ksz; uint32_t* part_base; uint32_t cap; bool valid; };
 size_t aqg_partition1_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t nbins);
-int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr, int layout = 0, int* ranged = nullptr);   // *ranged: in, range partitions allowed; out, taken
+int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t nbins, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr, int layout = 0, int* ranged = nullptr);   // *ranged: in, packing / range partitions allowed; out, bit 0 value columns inside the key word, bit 1 range partitions
 size_t aqg_partition2_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t parts);
 int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t parts, int need_count, GTable out, uint32_t out_cap, PartRows* pr = nullptr, int* pack = nullptr, int layout = 0);   // *pack: in, packing allowed; out, bit 0 value columns travelled inside the key word, bit 1 range partitions
 // the build's id pass over the partitioned rows: reversemap[row] = dense id of the row's key (slot_gid: record -> dense id)

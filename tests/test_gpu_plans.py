@@ -113,11 +113,11 @@ check([near], [ck.RED_SUM, ck.RED_SUM], [v3, v3], 500_000, PT | RG)
 
 def test_one_level_plan_over_a_dense_key_domain_takes_range_partitions():
     """the same shapes at the default thresholds: 4e5 groups take ONE partition level, and a dense key domain takes its range form too
-    (p1_hist / p1_scatter with order-preserving bins, p1_agg_direct_kernel over the [bin][chunk] starts); no value packing on this path"""
-    one = RANGED.replace("PT, PK, RG = capi.PLAN_PART_TWO, capi.PLAN_PACKED_VALUES, capi.PLAN_RANGE_PARTITIONS", "PT, PK, RG = capi.PLAN_PART_ONE, 0, capi.PLAN_RANGE_PARTITIONS")
-    # (a domain of 1.5e7 values for 4e5 groups would need more bins than the hashed plan was given: hashed here)
-    one = one.replace("check([sparse], [ck.RED_SUM, ck.RED_SUM], [v1, v3], 500_000, PT | PK | RG)", "check([sparse], [ck.RED_SUM, ck.RED_SUM], [v1, v3], 500_000, PT)")
-    assert one.count("500_000, PT)") == 3
+    (p1_hist / p1_scatter with order-preserving bins, p1_agg_direct_kernel over the [bin][chunk] starts), with the narrow value columns in the key word"""
+    one = RANGED.replace("PT, PK, RG = capi.PLAN_PART_TWO, capi.PLAN_PACKED_VALUES, capi.PLAN_RANGE_PARTITIONS", "PT, PK, RG = capi.PLAN_PART_ONE, capi.PLAN_PACKED_VALUES, capi.PLAN_RANGE_PARTITIONS")
+    # (a domain of 1.5e7 values for 4e5 groups would need more bins than the hashed plan was given: hashed here, the value column still packed)
+    one = one.replace("check([sparse], [ck.RED_SUM, ck.RED_SUM], [v1, v3], 500_000, PT | PK | RG)", "check([sparse], [ck.RED_SUM, ck.RED_SUM], [v1, v3], 500_000, PT | PK)")
+    assert one.count("500_000, PT | PK)") == 1
     run_forced({}, one)
 
 
