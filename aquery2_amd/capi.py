@@ -25,7 +25,7 @@ TAG2NP = {
 NP2TAG = {v: k for k, v in TAG2NP.items() if k != BOOL}
 NP2TAG[np.dtype(np.bool_)] = BOOL
 VEC_VEC, VEC_SCALAR, SCALAR_VEC = 0, 1, 2
-PLAN_FAST_LDS, PLAN_SMALL_LDS, PLAN_BIG_LDS, PLAN_DENSE, PLAN_PART_ONE, PLAN_PART_TWO, PLAN_PART_ROUND1, PLAN_PART_WIDE, PLAN_SORTED_TAIL, PLAN_HBM_TABLE, PLAN_BUILD_PARTITIONED, PLAN_GID_PARTITION, PLAN_PACKED_VALUES, PLAN_RANGE_PARTITIONS, PLAN_ROW_EMIT, PLAN_PACKED_KEYS = (1 << i for i in range(16))
+PLAN_FAST_LDS, PLAN_SMALL_LDS, PLAN_BIG_LDS, PLAN_DENSE, PLAN_PART_ONE, PLAN_PART_TWO, PLAN_PART_ROUND1, PLAN_PART_WIDE, PLAN_SORTED_TAIL, PLAN_HBM_TABLE, PLAN_BUILD_PARTITIONED, PLAN_GID_PARTITION, PLAN_PACKED_VALUES, PLAN_RANGE_PARTITIONS, PLAN_ROW_EMIT, PLAN_PACKED_KEYS, PLAN_BUILD_LOOKUP = (1 << i for i in range(17))
 
 
 class AqgError(RuntimeError):

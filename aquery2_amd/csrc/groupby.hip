@@ -722,6 +722,39 @@ struct RowRecord {
         return v;                                                                                               // 0 + v; min(~0, v); max(0, v)
     }
 };
+// The BUILD over a dense 4-byte key domain of up to 2^21 values (8 MB: what the L2s hold of it, the Infinity Cache the rest): the id of every
+// row comes from a look-up table key -> group id filled from the group table, read in ROW order -- instead of probing the partitioned rows
+// and routing {row, id} pairs back by row (2.3 + 12 ms per 1e9 rows).  1e9 random 4-byte gathers cost 6.3 ms out of a 4 MB table and 17 ms
+// out of a 40 MB one (request-rate bound), hence the limit.  The domain comes from a sample: a key outside it, or one the table does not
+// know, sets the flag and the call repeats through the routed form.
+__global__ void __launch_bounds__(256) lookup_fill_kernel(GTable gt, const uint32_t* __restrict__ slot_gid, uint32_t kmin, uint32_t D, uint32_t* __restrict__ table, uint32_t* __restrict__ flag) {
+    const uint32_t G = gt.flags[1];
+    for (uint32_t s = blockIdx.x * 256 + threadIdx.x; s < G; s += gridDim.x * 256) {
+        const uint32_t x = (uint32_t)*gt.key_p(s) - kmin;
+        if (x < D) table[x] = slot_gid[s]; else *flag = 1u;
+    }
+}
+__global__ void __launch_bounds__(256) lookup_assign_kernel(const uint32_t* __restrict__ keys, uint32_t n, uint32_t kmin, uint32_t D, const uint32_t* __restrict__ table,
+                                                            uint32_t* __restrict__ reversemap, uint32_t* __restrict__ flag) {
+    const uint32_t nvec = n >> 2;
+    uint32_t bad = 0;
+    for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < nvec; c += gridDim.x * 256) {
+        const uint4 k = reinterpret_cast<const uint4*>(keys)[c];
+        const uint32_t x0 = k.x - kmin, x1 = k.y - kmin, x2 = k.z - kmin, x3 = k.w - kmin;
+        bad |= (x0 >= D) | (x1 >= D) | (x2 >= D) | (x3 >= D);
+        uint4 g;
+        g.x = table[x0 < D ? x0 : 0]; g.y = table[x1 < D ? x1 : 0]; g.z = table[x2 < D ? x2 : 0]; g.w = table[x3 < D ? x3 : 0];
+        bad |= (g.x == 0xFFFFFFFFu) | (g.y == 0xFFFFFFFFu) | (g.z == 0xFFFFFFFFu) | (g.w == 0xFFFFFFFFu);
+        reinterpret_cast<uint4*>(reversemap)[c] = g;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const uint32_t i = (nvec << 2) + threadIdx.x, x = keys[i] - kmin;
+        const uint32_t g = table[x < D ? x : 0];
+        bad |= (x >= D) | (g == 0xFFFFFFFFu);
+        reversemap[i] = g;
+    }
+    if (bad) *flag = 1u;
+}
 // a column copied at the rate the shifts stream at (one 16-byte vector per lane, exact grid: 6.0 TB/s of combined traffic; the runtime's
 // device-to-device copy moves the same bytes at 4.4)
 __global__ void __launch_bounds__(256) copy_vec_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t nvec) {
@@ -1240,6 +1273,22 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         const uint32_t bp = aqg_partition_parts(ks.total_bytes <= 4 ? 4 : 8, as, plan.need_count, hint);
         if (!bp || bp > AQG_P2_MAXPARTS) use_part = false;
     }
+    // the build over a dense key domain small enough for a key -> id look-up table (lookup_assign_kernel): no partitioned rows kept, no routing
+    bool lookup_build = false;
+    uint32_t lk_min = 0, lk_D = 0;
+    static const bool lookup_off = getenv("AQG_DISABLE_LOOKUP_BUILD") != nullptr;     // A/B measurements only
+    if (use_part && for_build && !lookup_off && !h->no_lookup_build && ks.nkeys == 1 && !ks.wide && (ks.dt[0] == AQG_INT32 || ks.dt[0] == AQG_UINT32) &&
+        ((uintptr_t)ks.col[0] & 15) == 0 && n >= (1u << 22)) {
+        long long mn[MAXKEYS], mx[MAXKEYS];
+        bool ok = false;
+        AQG_TRY(aqg_ws_reset(ctx));
+        AQG_TRY(aqg_ws_ensure(ctx, 4096));
+        AQG_TRY(aqg_key_ranges(ctx, ks, 1u << 20, mn, mx, &ok));            // (a sample: the look-up pass checks every row)
+        if (ok && mx[0] >= mn[0]) {
+            const long long span = mx[0] - mn[0] + 1, room = span / 64 + 1024, lo = mn[0] - room, hi = mx[0] + room;
+            if (hi - lo + 1 <= (1ll << 21)) { lookup_build = true; lk_min = (uint32_t)lo; lk_D = (uint32_t)(hi - lo + 1); }
+        }
+    }
     uint32_t part_lcap = 0, pbits = 0;
     if (use_part) {
         // LDS table of one partition: as many slots as fit the budget (the slot of a hash is a multiply-shift, so the
@@ -1288,7 +1337,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
     // (the partition buffers are dead once the record table is written: the ordering pass takes their place in the arena)
     const size_t sort_need = sorted_tail ? aqg_sorted_tail_ws_bytes(gcap, n, as.nacc, ks.wide != 0) : 0;
     need += part_need > sort_need ? part_need : sort_need;
-    if (for_build && use_part) need += aqg_partition_assign_ws_bytes(n);
+    if (for_build && use_part) need += lookup_build ? ((size_t)lk_D + 64) * 4 + 4096 : aqg_partition_assign_ws_bytes(n);
     AQG_TRY(aqg_ws_reset(ctx));
     AQG_TRY(aqg_ws_ensure(ctx, need));
     GTable gt;
@@ -1407,13 +1456,13 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         }
         else if (p1_bins) {
             int ranged = h->no_pack ? 0 : 1;
-            AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap, for_build ? &prows : nullptr, part_layout, &ranged));
+            AQG_TRY(aqg_partition1_aggregate(ctx, ks, as, n, p1_bins, plan.need_count, gt, gcap, for_build && !lookup_build ? &prows : nullptr, part_layout, &ranged));
             if (ranged & 2) h->plan_bits |= AQG_PLAN_RANGE_PARTITIONS;
             if (ranged & 1) h->plan_bits |= AQG_PLAN_PACKED_VALUES;
         }
         else if (p2_parts) {
             int pack = h->no_pack ? 0 : 1;
-            AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap, for_build ? &prows : nullptr, &pack, part_layout));
+            AQG_TRY(aqg_partition2_aggregate(ctx, ks, as, n, p2_parts, plan.need_count, gt, gcap, for_build && !lookup_build ? &prows : nullptr, &pack, part_layout));
             if (pack & 1) h->plan_bits |= AQG_PLAN_PACKED_VALUES;
             if (pack & 2) h->plan_bits |= AQG_PLAN_RANGE_PARTITIONS;
         }
@@ -1608,7 +1657,24 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         ctx->tail_in_flight = true;
     }
     h->build_assigned = false;
-    if (for_build && use_part && n && G && prows.valid) {       // the id of every row from the rows still lying partitioned in the workspace
+    if (for_build && use_part && n && G && lookup_build) {       // the id of every row through a key -> id table, in row order
+        size_t c = h->reversemap ? h->cap_rows * 4 : 0;
+        AQG_TRY(dev_realloc(ctx, (void**)&h->reversemap, &c, ((size_t)n + 4) * 4));
+        h->cap_rows = c / 4;
+        uint32_t* table;
+        AQG_TRY(aqg_ws_get(ctx, (size_t)lk_D + 64, &table));
+        AQG_HIP(ctx, hipMemsetAsync(table, 0xFF, (size_t)lk_D * 4, ctx->stream));
+        hipLaunchKernelGGL(lookup_fill_kernel, dim3(aqg_grid(ctx, G, 256, 1, 8)), dim3(256), 0, ctx->stream, gt, (const uint32_t*)slot_gid, lk_min, lk_D, table, gt.flags + 8);
+        hipLaunchKernelGGL(lookup_assign_kernel, dim3(aqg_grid(ctx, n / 4 + 1, 256, 1, 8)), dim3(256), 0, ctx->stream, static_cast<const uint32_t*>(ks.col[0]), n, lk_min, lk_D,
+                           (const uint32_t*)table, h->reversemap, gt.flags + 8);
+        AQG_TRY(aqg_check_launch(ctx, "lookup_assign_kernel"));
+        uint32_t miss = 0;
+        AQG_HIP(ctx, hipMemcpyAsync(&miss, gt.flags + 8, 4, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (miss) { h->no_lookup_build = true; return AQG_ERR_RANGE_MISS; }      // a key outside the sampled domain: once more, through the routed form
+        h->build_assigned = true;
+        h->plan_bits |= AQG_PLAN_BUILD_PARTITIONED | AQG_PLAN_BUILD_LOOKUP;
+    } else if (for_build && use_part && n && G && prows.valid) {       // the id of every row from the rows still lying partitioned in the workspace
         size_t c = h->reversemap ? h->cap_rows * 4 : 0;
         AQG_TRY(dev_realloc(ctx, (void**)&h->reversemap, &c, ((size_t)n + 4) * 4));
         h->cap_rows = c / 4;

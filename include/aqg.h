@@ -272,7 +272,8 @@ enum { AQG_PLAN_FAST_LDS = 1, AQG_PLAN_SMALL_LDS = 2, AQG_PLAN_BIG_LDS = 4, AQG_
        AQG_PLAN_PACKED_VALUES = 4096 /* narrow value columns travelled inside the 4-byte key word of a two-level partition plan */,
        AQG_PLAN_RANGE_PARTITIONS = 8192 /* a dense 4-byte key domain: order-preserving range partitions, direct-indexed LDS accumulators */,
        AQG_PLAN_ROW_EMIT = 16384 /* every row turned out to be its own group: the result columns are written as a map of the input */,
-       AQG_PLAN_PACKED_KEYS = 32768 /* the key columns of a wide tuple travelled packed into fewer dword planes (sampled ranges, every row verified) */ };
+       AQG_PLAN_PACKED_KEYS = 32768 /* the key columns of a wide tuple travelled packed into fewer dword planes (sampled ranges, every row verified) */,
+       AQG_PLAN_BUILD_LOOKUP = 65536 /* aqg_groupby_build: row ids through a key -> group id look-up table (a dense key domain of up to 2^21 values) */ };
 uint32_t aqg_groupby_plan(const aqg_groupby* g);
 
 /* ---- hash join (new functionality; reference runs joins in MonetDB)

@@ -305,6 +305,39 @@ check_build([(key %% 1000).astype(np.int16), (key // 1000).astype(np.int32)], %s
 '''
 
 
+LOOKUP = r"""
+n = 4_500_037
+def check_build(keys, lookup):
+    o = oracle.groupby(keys)
+    gb = gpu.groupby_build(keys)
+    assert bool(gb.plan & capi.PLAN_BUILD_LOOKUP) == lookup and gb.plan & capi.PLAN_BUILD_PARTITIONED, ("plan", gb.plan, lookup)
+    assert gb.ngroups == o["ngroups"]
+    assert np.array_equal(gb.reversemap(), o["reversemap"]) and np.array_equal(gb.counts(), o["counts"]) and np.array_equal(gb.first_rows(), o["first_rows"])
+    assert np.array_equal(gb.keys(0, keys[0].dtype), keys[0][o["first_rows"]])
+    off, rows = gb.postproc()
+    assert np.array_equal(off[:-1], o["offsets"]) and np.array_equal(rows, o["row_ids"])
+    v = rng.integers(-9, 10, n).astype(np.int32)
+    assert gu.same_bits(gpu.grouped_reduce(gb, ck.RED_SUM, v), oracle.grouped_reduce(ck.RED_SUM, v, o))
+    print("OK", gb.ngroups, flush=True)
+key = rng.integers(0, 300_000, n).astype(np.int32)
+check_build([key], True)                                       # a domain of 3e5 values: ids through the key -> id table
+check_build([key - 150_000], True)                             # around zero
+check_build([(key.astype(np.int64) + 2**32 - 400_000).astype(np.uint32)], True)
+check_build([key * 9], False)                                  # 2.7e6 values: beyond the table's 2^21, the routed form
+late = key.copy(); late[n - 5] = 1_900_000                     # a key outside the sampled domain: caught by the look-up pass, the call repeats routed
+check_build([late], False)
+hole = key.copy(); hole[: 1 << 20] = np.arange(1 << 20, dtype=np.int32) % 200_000      # (the sample sees 2e5 values, the rest of the column 3e5: still inside the room given)
+check_build([hole], False if hole.max() > 200_000 + 200_000 // 64 + 1024 else True)
+"""
+
+
+def test_build_over_a_small_dense_key_domain_goes_through_a_lookup_table():
+    """aqg_groupby_build above the LDS tables over one 4-byte integer key whose sampled domain has at most 2^21 values: the group table from the
+    partition plan, then reversemap[row] = table[key - kmin] in row order (no partitioned rows kept, no routing back); keys outside the sampled
+    domain repeat the call through the routed form"""
+    run_forced({}, LOOKUP)
+
+
 @pytest.mark.parametrize("G", [300_000, 2_500_000])
 def test_build_through_the_partition_plans(G):
     """aqg_groupby_build above the LDS tables: the group table from the one- / two-level partition plan (counts only), then the id of every row
