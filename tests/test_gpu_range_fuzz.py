@@ -58,7 +58,11 @@ def test_partition_plans_over_one_integer_key(gpu, oracle, seed):
     n, key, aggs, hint = make_case(int(os.environ.get("AQG_FUZZ_BASE", "3000")) + seed)
     o = oracle.groupby([key])
     ops = [ck.RED_NAMES[op] for op, _ in aggs]
-    gb = gpu.groupby_agg([key], ops, [v for _, v in aggs], hint=hint)
+    try:
+        gb = gpu.groupby_agg([key], ops, [v for _, v in aggs], hint=hint)
+    except Exception as e:                                   # the documented limit: 8 accumulators per call (three VARs over 8-byte integers)
+        assert "too many accumulators" in str(e), e
+        return
     assert gb.ngroups == o["ngroups"], seed
     assert np.array_equal(gb.first_rows(), o["first_rows"]), seed
     assert np.array_equal(gb.keys(0, key.dtype), key[o["first_rows"]]), seed
