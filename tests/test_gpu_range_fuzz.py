@@ -78,3 +78,50 @@ def test_partition_plans_over_one_integer_key(gpu, oracle, seed):
         assert b.ngroups == o["ngroups"]
         assert np.array_equal(b.reversemap(), o["reversemap"]) and np.array_equal(b.counts(), o["counts"]) and np.array_equal(b.first_rows(), o["first_rows"]), (seed, b.plan)
         b.destroy()
+
+
+def make_wide_case(seed):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([4_300_003, 5_000_017]))
+    nk = int(rng.choice([3, 4, 5, 6]))
+    distinct = int(rng.choice([n, n, n // 2, n // 3]))           # all rows distinct (the row map) or a few rows per tuple
+    r = rng.permutation(n).astype(np.int64) if distinct == n else rng.integers(0, distinct, n)
+    keys, rest = [], r.copy()
+    widths = [int(rng.choice([3, 13, 100, 1000, 70_000])) for _ in range(nk - 1)]
+    for w in widths:
+        lo = int(rng.choice([0, 1, -50, 2_000_000_000]))
+        dt = np.int32 if lo < 0 or rng.random() < 0.7 else np.uint32
+        keys.append((lo + rest % w).astype(dt))
+        rest = rest // w
+    keys.append(rest.astype(np.int32))                            # what is left of the tuple number: the tuples stay distinct where r is
+    if rng.random() < 0.3: keys[0][rng.integers(1 << 20, n, 2)] += 5_000_000     # values far outside the sampled range of a packed column
+    order = rng.permutation(nk)
+    keys = [keys[i] for i in order]
+    aggs = []
+    for _ in range(int(rng.integers(1, 3))):
+        vdt = VAL_DTYPES[rng.integers(len(VAL_DTYPES))]
+        op = OPS[rng.integers(5)]
+        v = np.round(rng.uniform(-100, 100, n), 3).astype(vdt) if np.dtype(vdt).kind == "f" else rng.integers(-100 if np.dtype(vdt).kind == "i" else 0, 100, n).astype(vdt)
+        aggs.append((op, v))
+    return n, keys, aggs, distinct
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AQG_FUZZ_SEEDS", "12"))))
+def test_wide_tuples_packed_and_row_map(gpu, oracle, seed):
+    """tuples of 3 .. 6 four-byte columns with more than 2^20 groups expected: the wide-tuple plan with the key columns packed under sampled
+    ranges (or not, when they do not fit or a row misses its range), all-distinct inputs through the row map"""
+    n, keys, aggs, distinct = make_wide_case(int(os.environ.get("AQG_FUZZ_BASE", "5000")) + seed)
+    o = oracle.groupby(keys)
+    ops = [ck.RED_NAMES[op] for op, _ in aggs]
+    gb = gpu.groupby_agg(keys, ops, [v for _, v in aggs], hint=min(n, distinct + 1000))
+    assert gb.ngroups == o["ngroups"], seed
+    assert np.array_equal(gb.first_rows(), o["first_rows"]), seed
+    for k, c in enumerate(keys):
+        assert np.array_equal(gb.keys(k, c.dtype), c[o["first_rows"]]), (seed, k)
+    for j, (op, v) in enumerate(aggs):
+        got, want = gb.result(j, ops[j], ck.tag_of(v)), oracle.grouped_reduce(ops[j], v, o)
+        if v.dtype.kind == "f" and op in ("sum", "avg") and o["ngroups"] != n:
+            assert np.allclose(got, want, rtol=1e-9, atol=1e-6), (seed, j, op)
+        else:
+            assert gu.same_bits(got, want), (seed, j, op, gb.plan)
+    gb.destroy()
