@@ -989,7 +989,7 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
             uint32_t hw;
             if constexpr (MODE == BIN_HASHED) hw = key_hash<false>(kw[r] & ~lv.kclear);
             else if constexpr (MODE == BIN_RANGED) { hw = (kw[r] & ~lv.kclear) - lv.kmin; outside |= hw > lv.xmax ? 1u : 0u; hw = hw < lv.xmax ? hw : lv.xmax; }
-            else hw = kw[r];
+            else hw = kw[r] & ~lv.kclear;
             const uint32_t d = (__umulhi(hw, lv.P) >> lv.shift) & lv.mask;
             dpk[r >> 2] |= d << (8 * (r & 3));
             if (FULL || trow<TB>(r) < nrows) atomicAdd(&lb[d], 1u);
@@ -2532,6 +2532,8 @@ struct GidAgg {
     const uint32_t* gid; const void* val; int vdt; int op;
     const uint32_t* pstart; const uint32_t* pfirst; const uint32_t* counts;
     void* out; uint32_t nparts, cap;
+    // the value travelled INSIDE the id word (a 4-byte integer column of a narrow sampled range above the id's bits): word = id | (v - pmin) << pshift
+    uint32_t packed, idmask, pshift, pmin;
 };
 // value of row i as the operand of accumulator `which` (0: the value, 1: its square in the promoted type) -- wave-uniform dtype switch
 __device__ inline uint64_t gid_operand(const GidAgg& a, size_t i, int kind, int square) {
@@ -2574,9 +2576,16 @@ __global__ void __launch_bounds__(1024) gid_agg_kernel(GidAgg a) {
             for (int k = 0; k < 4; ++k) {
                 const uint32_t i = i0 + k * 1024;
                 const uint32_t ic = i < r1 ? i : r1 - 1;
-                g[k] = a.gid[ic] - g0;
-                v[k] = gid_operand(a, ic, kind, 0);
-                q[k] = two ? gid_operand(a, ic, kind, 1) : 0;
+                const uint32_t word = a.gid[ic];
+                g[k] = (word & a.idmask) - g0;
+                if (a.packed) {
+                    const uint32_t raw = (word >> a.pshift) + a.pmin;
+                    v[k] = a.vdt == AQG_INT32 ? val_operand_t((int32_t)raw, kind, 0) : val_operand_t(raw, kind, 0);
+                    q[k] = !two ? 0 : a.vdt == AQG_INT32 ? val_operand_t((int32_t)raw, kind, 1) : val_operand_t(raw, kind, 1);
+                } else {
+                    v[k] = gid_operand(a, ic, kind, 0);
+                    q[k] = two ? gid_operand(a, ic, kind, 1) : 0;
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -2635,7 +2644,12 @@ __global__ void __launch_bounds__(1024) gid_agg_kernel(GidAgg a) {
 
 // out[g] = op(x[rows whose id is g]) for dense ids 0 .. G-1 with known group sizes (offsets = their exclusive scan, G + 1 entries).
 // AQG_ERR_DTYPE: this (op, dtype) is not served here (8-byte integer sums need 128 bits per group): the caller takes the hashed plans.
+static int gid_reduce_impl(aqg_ctx* ctx, const uint32_t* gid, const uint32_t* offsets, const uint32_t* counts, uint32_t n, uint32_t G, int op, int t, const void* x, void* out_dev, bool allow_pack);
 int aqg_gid_reduce(aqg_ctx* ctx, const uint32_t* gid, const uint32_t* offsets, const uint32_t* counts, uint32_t n, uint32_t G, int op, int t, const void* x, void* out_dev) {
+    const int rc = gid_reduce_impl(ctx, gid, offsets, counts, n, G, op, t, x, out_dev, true);
+    return rc == -1001 ? gid_reduce_impl(ctx, gid, offsets, counts, n, G, op, t, x, out_dev, false) : rc;     // (a value outside the sampled range of its field: once more, as its own plane)
+}
+static int gid_reduce_impl(aqg_ctx* ctx, const uint32_t* gid, const uint32_t* offsets, const uint32_t* counts, uint32_t n, uint32_t G, int op, int t, const void* x, void* out_dev, bool allow_pack) {
     const bool two = op == AQG_RED_VAR || op == AQG_RED_STDDEV;
     if (!(op == AQG_RED_SUM || op == AQG_RED_AVG || op == AQG_RED_MIN || op == AQG_RED_MAX || two)) return AQG_ERR_DTYPE;
     const bool wide_int = t == AQG_INT64 || t == AQG_UINT64;
@@ -2670,10 +2684,39 @@ int aqg_gid_reduce(aqg_ctx* ctx, const uint32_t* gid, const uint32_t* offsets, c
         hipLaunchKernelGGL(p1_widen_kernel, dim3(aqg_grid(ctx, n, 256, 4, 16)), dim3(256), 0, ctx->stream, x, esz, n, wide);
         vsrc = wide;
     }
+    // a 4-byte integer value column of a narrow sampled range travels INSIDE the id word (ids below 2^24 leave eight bits: h2o v1, v2): one plane per
+    // level instead of two.  Every row is verified while it is packed (p2_scatter's PL_PACK); a miss repeats the call with the value as its own plane.
+    uint32_t pk_on = 0, pk_shift = 0, pk_min = 0, pk_mask = 0, *pk_flag = nullptr;
+    static const bool pack_off = getenv("AQG_DISABLE_PACK") != nullptr;
+    if (allow_pack && !pack_off && (t == AQG_INT32 || t == AQG_UINT32) && n >= (1u << 22) && ((uintptr_t)x & 15) == 0) {
+        KeySpec probe;
+        memset(&probe, 0, sizeof probe);
+        probe.nkeys = 1; probe.dt[0] = t; probe.col[0] = x;
+        long long mn[MAXKEYS], mx[MAXKEYS];
+        bool ok = false;
+        AQG_TRY(aqg_key_ranges(ctx, probe, 1u << 20, mn, mx, &ok));
+        int gbits = 1;
+        while (gbits < 32 && (1ull << gbits) < (unsigned long long)G) ++gbits;
+        if (ok && mx[0] >= mn[0]) {
+            const unsigned long long range = (unsigned long long)(mx[0] - mn[0]);
+            int fb = 1;
+            while (fb < 32 && (1ull << fb) <= range) ++fb;
+            if (gbits + fb <= 32) {
+                pk_on = 1; pk_shift = (uint32_t)gbits; pk_min = (uint32_t)mn[0]; pk_mask = (uint32_t)((1ull << fb) - 1);
+                AQG_TRY(aqg_ws_get(ctx, 16, &pk_flag));
+                AQG_HIP(ctx, hipMemsetAsync(pk_flag, 0, 4, ctx->stream));
+            }
+        }
+    }
+    const uint32_t kclear = pk_on ? pk_mask << pk_shift : 0u;
     hipLaunchKernelGGL(gid_setup_kernel, dim3(aqg_grid(ctx, (uint64_t)PP + 1, 256, 1, 4)), dim3(256), 0, ctx->stream, offsets, G, M, PP, pstart, pfirst);
     const size_t scat_lds = (size_t)P2_PT * 4;
     AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, true, false>), scat_lds));
     AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, false, false>), scat_lds));
+    if (pk_on) {
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, true, BIN_RAW, true>), scat_lds));
+        AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, false, BIN_RAW, true>), scat_lds));
+    }
     uint32_t nseg = 1, bits_left = bits;
     const uint32_t* gsrc = gid;
     const void* vs = vsrc;
@@ -2695,17 +2738,36 @@ int aqg_gid_reduce(aqg_ctx* ctx, const uint32_t* gid, const uint32_t* offsets, c
             Q.dst = static_cast<uint32_t*>(d); Q.dst_stride_dw = dstride; Q.dst_off_dw = doff;
         };
         add(gsrc, 1, 0, gdst, 1, 0);
-        if (vsz == 4) add(vs, 1, 0, vdst, 1, 0); else { add(vs, 2, 0, vdst, 2, 0); add(vs, 2, 1, vdst, 2, 1); }
-        P2Level lv{seg, tp, cur, nseg, M, shift, mask, nb, nb};
+        if (pk_on) {
+            if (l == 0) {
+                pl.p[0].kind = PL_PACK;
+                pl.pk.n = 1; pl.pk.kmax = 0xFFFFFFFFu; pl.pk.flag = pk_flag;
+                pl.pk.src[0] = static_cast<const uint32_t*>(x); pl.pk.min[0] = pk_min; pl.pk.shift[0] = pk_shift; pl.pk.fmask[0] = pk_mask;
+            }
+        }
+        else if (vsz == 4) add(vs, 1, 0, vdst, 1, 0); else { add(vs, 2, 0, vdst, 2, 0); add(vs, 2, 1, vdst, 2, 1); }
+        P2Level lv{seg, tp, cur, nseg, M, shift, mask, nb, nb, l == 0 ? 0u : kclear};
         const unsigned tiles = (unsigned)((uint64_t)n / P2_PT) + nseg + 1;
-        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, true, false>), dim3(tiles), dim3(P2_TB), scat_lds, ctx->stream, gsrc, pl, lv);
-        hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, false, false>), dim3(nseg), dim3(P2_TB), scat_lds, ctx->stream, gsrc, pl, lv);
+        if (pk_on && l == 0) {
+            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, true, BIN_RAW, true>), dim3(tiles), dim3(P2_TB), scat_lds, ctx->stream, gsrc, pl, lv);
+            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, false, BIN_RAW, true>), dim3(nseg), dim3(P2_TB), scat_lds, ctx->stream, gsrc, pl, lv);
+        } else {
+            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, true, false>), dim3(tiles), dim3(P2_TB), scat_lds, ctx->stream, gsrc, pl, lv);
+            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, false, false>), dim3(nseg), dim3(P2_TB), scat_lds, ctx->stream, gsrc, pl, lv);
+        }
         AQG_TRY(aqg_check_launch(ctx, "id-partitioned grouped reduce: level"));
+        if (pk_on && l == 0) {                                  // a row that did not fit its field: the caller repeats the call unpacked
+            uint32_t miss = 0;
+            AQG_HIP(ctx, hipMemcpyAsync(&miss, pk_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+            AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if (miss) return -1001;
+        }
         nseg *= nb;
         gsrc = gdst; vs = vdst;
     }
     GidAgg a;
     a.gid = gsrc; a.val = vs; a.vdt = t; a.op = op; a.pstart = pstart; a.pfirst = pfirst; a.counts = counts; a.out = out_dev; a.nparts = PP; a.cap = cap;
+    a.packed = pk_on; a.idmask = pk_on ? ~kclear : 0xFFFFFFFFu; a.pshift = pk_shift; a.pmin = pk_min;
     const size_t lds = (size_t)cap * 8 * (two ? 2 : 1);
     AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&gid_agg_kernel), lds));
     aqg_kernel_timer_begin(ctx);

@@ -278,6 +278,11 @@ def test_grouped_reduce_partitioned_on_the_dense_group_id(n, G):
                     assert np.allclose(got, want, rtol=1e-9, atol=1e-6), (dt, name)
                 else:
                     assert gu.same_bits(got, want), (dt, name)
+        # (the narrow int32 / uint32 columns above travelled inside the id word; here one late row does not fit the field its sample gave it)
+        x = rng.integers(1, 6, n).astype(np.int32)
+        x[n - 3] = 1 << 20
+        for name in ("sum", "max"):
+            assert gu.same_bits(d.grouped_reduce(gb, ck.RED_NAMES[name], x), oracle.grouped_reduce(ck.RED_NAMES[name], x, o)), name
     finally:
         d.close()
 
