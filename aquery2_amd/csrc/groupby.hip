@@ -1119,6 +1119,7 @@ int make_keyspec(aqg_ctx* ctx, int nkeys, const int* dts, const void* const* key
     if (nkeys < 1 || nkeys > MAXKEYS) return aqg_fail(ctx, AQG_ERR_ARG, "group-by: 1..8 key columns");
     int bits = 0;
     ks->nkeys = nkeys;
+    ks->range_known = 0; ks->range_lo = ks->range_hi = 0;
     for (int j = 0; j < nkeys; ++j) {
         if (!(dt_is_num(dts[j]) || dts[j] == AQG_BOOL)) return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: key dtype");
         if (dt_is_fp(dts[j])) return aqg_fail(ctx, AQG_ERR_DTYPE, "group-by: internal: floating key column reached the packed-key layer");
@@ -2119,7 +2120,8 @@ int aqg_grouped_reduce_keyed(aqg_ctx* ctx, aqg_groupby* g, const uint32_t* gid_c
     const uint32_t G = g->ngroups, n = g->n;
     // beyond the LDS tables: the build's ids are dense and its group sizes known -- partitioned on the id, direct-indexed (partition1.hip)
     static const bool gid_off = getenv("AQG_DISABLE_GID_REDUCE") != nullptr;       // A/B measurements only
-    if (!gid_off && gid_col == g->reversemap && g->has_counts && G > (3u << 20) && n >= (1u << 22)) {       // (up to ~3e6 groups the one-level hashed plan is as fast: 8.0-8.4 ms against 9.0 per 1e9 rows; 1e7 groups: 17 against 9)
+    static const uint32_t gid_min = getenv("AQG_GID_MIN") ? (uint32_t)atoi(getenv("AQG_GID_MIN")) : (1u << 16);       // (measured again in round 3, with the value inside the id word: 6.5 against 7.5 ms at 1e5 groups, equal for values that do not pack)
+    if (!gid_off && gid_col == g->reversemap && g->has_counts && G > gid_min && n >= (1u << 22)) {       // (up to ~3e6 groups the one-level hashed plan is as fast: 8.0-8.4 ms against 9.0 per 1e9 rows; 1e7 groups: 17 against 9)
         const uint32_t* off = aqg_groupby_offsets(g);
         if (off) {
             const int rc = aqg_gid_reduce(ctx, gid_col, off, g->counts, n, G, op, t, x, out_dev);
@@ -2130,6 +2132,7 @@ int aqg_grouped_reduce_keyed(aqg_ctx* ctx, aqg_groupby* g, const uint32_t* gid_c
     const void* kcol = gid_col;
     KeySpec ks;
     AQG_TRY(make_keyspec(ctx, 1, &kdt, &kcol, n, &ks));
+    ks.range_known = 1; ks.range_lo = 0; ks.range_hi = (long long)G - 1;      // dense group ids
     if (!g->scratch) g->scratch = new aqg_groupby();
     aqg_groupby* h = g->scratch;
     h->ctx = ctx; h->n = n; h->has_reversemap = false;
@@ -2158,6 +2161,7 @@ int aqg_grouped_reduce(aqg_ctx* ctx, const aqg_groupby* gc, int op, int t, const
     if (op == AQG_RED_LAST) return aqg_gather(ctx, t, x, g->first_rows, G, out_dev);
     KeySpec ks;
     AQG_TRY(make_keyspec(ctx, 1, &kdt, &kcol, n, &ks));
+    ks.range_known = 1; ks.range_lo = 0; ks.range_hi = (long long)G - 1;      // dense group ids
     if (!g->scratch) g->scratch = new aqg_groupby();
     aqg_groupby* h = g->scratch;
     h->ctx = ctx; h->n = n; h->has_reversemap = false;
@@ -2202,6 +2206,7 @@ int aqg_grouped_corr(aqg_ctx* ctx, aqg_groupby* g, int tx, const void* x, int ty
         const void* kcol = g->reversemap;
         KeySpec ks;
         rc = make_keyspec(ctx, 1, &kdt, &kcol, n, &ks);
+        ks.range_known = 1; ks.range_lo = 0; ks.range_hi = (long long)G - 1;      // dense group ids
         if (!g->scratch) g->scratch = new aqg_groupby();
         aqg_groupby* h = g->scratch;
         h->ctx = ctx; h->n = n; h->has_reversemap = false;

@@ -16,7 +16,13 @@ enum : int { ACC_ADD_I = 0, ACC_ADD_F = 1, ACC_MIN = 2, ACC_MAX = 3 };
 enum : int { VC_I = 0, VC_U = 1, VC_F = 2 };   // value class of a column: signed / unsigned / floating
 
 // wide != 0: the tuple does not fit 64 bits; the table then stores a REPRESENTATIVE ROW per slot and compares key columns
-struct KeySpec { int nkeys; int dt[MAXKEYS]; const void* col[MAXKEYS]; int shift[MAXKEYS]; int total_bytes; int wide; };
+struct KeySpec {
+    int nkeys; int dt[MAXKEYS]; const void* col[MAXKEYS]; int shift[MAXKEYS]; int total_bytes; int wide;
+    // the exact value range of a single key column when the caller knows it (the dense group ids of a build: 0 .. G-1).  The plans that
+    // otherwise sample the first 2^20 rows take it as it is: ids are numbered by first occurrence, so a sample of the first rows sees only
+    // the low ones and every such call paid a failed attempt
+    int range_known; long long range_lo, range_hi;
+};
 // square: accumulate x*x (in the promoted type).  part: 0 whole value; 1 / 2 = low / high 32 bits of an 8-byte
 // integer, so that sums of 8-byte integers stay exact (the two 64-bit accumulators cannot overflow for n < 2^32)
 struct AccSpec { int nacc; int kind[MAXACC]; int dt[MAXACC]; const void* col[MAXACC]; int square[MAXACC]; int part[MAXACC]; };

@@ -1485,7 +1485,7 @@ static bool p1_key_is_column(const KeySpec& ks, int ksz) { return ks.nkeys == 1 
 
 // which value columns travel inside the key word (PackSpec): one 4-byte integer key column whose sampled maximum leaves spare bits, 4-byte
 // integer value columns whose sampled range fits them (at most two), every accumulator over such a column a plain sum / min / max / square
-struct PackPlan { int n; const void* col[2]; uint32_t min[2], shift[2], fmask[2]; uint32_t kmax, kclear; bool have_range; long long key_lo, key_hi; };
+struct PackPlan { int n; const void* col[2]; uint32_t min[2], shift[2], fmask[2]; uint32_t kmax, kclear; bool have_range, exact; long long key_lo, key_hi; };
 static int plan_pack(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, const ValCols& vc, PackPlan* pp) {
     memset(pp, 0, sizeof *pp);
     static const bool off = getenv("AQG_DISABLE_PACK") != nullptr;           // A/B measurements only
@@ -1506,7 +1506,8 @@ static int plan_pack(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_
     bool ok = false;
     AQG_TRY(aqg_key_ranges(ctx, probe, 1u << 20, mins, maxs, &ok));          // (a sample: every row is verified while it is packed / binned)
     if (!ok) return AQG_OK;
-    pp->have_range = true; pp->key_lo = mins[0]; pp->key_hi = maxs[0];
+    if (ks.range_known) { mins[0] = ks.range_lo; maxs[0] = ks.range_hi; }     // (the key's range as the caller knows it; the value columns' from the sample)
+    pp->have_range = true; pp->key_lo = mins[0]; pp->key_hi = maxs[0]; pp->exact = ks.range_known != 0;
     if (!nc || mins[0] < 0 || maxs[0] >= (1ll << 31)) return AQG_OK;
     auto bits_of = [](unsigned long long v) { int b = 0; while (b < 33 && (1ull << b) <= v) ++b; return b; };
     int used = bits_of((unsigned long long)maxs[0]);
@@ -1569,7 +1570,7 @@ static void plan_range(const PackPlan& pp, const AccSpec& as, int need_count, ui
     memset(rp, 0, sizeof *rp);
     static const bool off = getenv("AQG_DISABLE_RANGED") != nullptr;         // A/B measurements only
     if (off || !pp.have_range || pp.key_hi < pp.key_lo) return;
-    const long long span = pp.key_hi - pp.key_lo + 1, slack = span / 64 + 1024;
+    const long long span = pp.key_hi - pp.key_lo + 1, slack = pp.exact ? 0 : span / 64 + 1024;
     // (the key column is int32 or uint32: its values as 64-bit integers; the bins work on the 32-bit difference to kmin, which wraps correctly)
     const long long lo = pp.key_lo - slack, hi = pp.key_hi + slack;
     const unsigned long long D = (unsigned long long)(hi - lo + 1);

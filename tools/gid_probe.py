@@ -8,7 +8,7 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
 K = int(float(sys.argv[2])) if len(sys.argv) > 2 else 100
 d = A.Device(0)
 key = d.gen_column(ck.GEN_ID3, 42, 0, n, n, K)
-v1 = d.gen_column(ck.GEN_V1, 42, 0, n, n, 100)
+v1 = d.gen_column(ck.GEN_V3 if len(sys.argv) > 3 and sys.argv[3] == "v3" else ck.GEN_V1, 42, 0, n, n, 100)    # v3: a float column (nothing packs)
 gb = d.groupby_build([key])
 print("groups", gb.ngroups, flush=True)
 out = d.empty(gb.ngroups, ck.I128)
