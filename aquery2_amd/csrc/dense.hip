@@ -15,31 +15,35 @@
 namespace {
 
 // ---- [min, max] of every key column, as int64 -------------------------------------------------------------------------------
+// `total` != 0: the n rows are a SPREAD sample of a column of `total` rows -- 1024 blocks of n / 1024 consecutive rows, evenly spaced (a column
+// sorted or clustered by its key shows its whole range to such a sample; the first n rows of it show one end)
 template <class T>
-__device__ inline void col_range(const void* col, uint32_t n, long long& mn, long long& mx) {
+__device__ inline void col_range(const void* col, uint32_t n, uint32_t total, long long& mn, long long& mx) {
     const T* p = static_cast<const T*>(col);
     const uint32_t nchunk = n >> 2;
     uint32_t c_lo, c_hi;
     wg_span(nchunk, c_lo, c_hi);
+    const uint32_t cpb = nchunk >> 10;                       // chunks of four rows per block
     for (uint32_t c = c_lo + threadIdx.x; c < c_hi; c += blockDim.x) {
-        pack<T, 4> v = *reinterpret_cast<const pack<T, 4>*>(p + (size_t)c * 4);
+        const size_t src = total ? (size_t)(((uint64_t)(c / cpb) * (total >> 2)) >> 10) + c % cpb : (size_t)c;
+        pack<T, 4> v = *reinterpret_cast<const pack<T, 4>*>(p + src * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { long long x = (long long)v.v[j]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { long long x = (long long)p[(nchunk << 2) + threadIdx.x]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
+    if (!total && blockIdx.x == 0 && threadIdx.x < (n & 3)) { long long x = (long long)p[(nchunk << 2) + threadIdx.x]; mn = x < mn ? x : mn; mx = x > mx ? x : mx; }
 }
-__global__ void __launch_bounds__(256) key_range_kernel(KeySpec ks, uint32_t n, long long* __restrict__ out /* [2 * nkeys]: min_j, max_j */) {
+__global__ void __launch_bounds__(256) key_range_kernel(KeySpec ks, uint32_t n, uint32_t total, long long* __restrict__ out /* [2 * nkeys]: min_j, max_j */) {
     __shared__ long long smn[4], smx[4];
     for (int c = 0; c < ks.nkeys; ++c) {
         long long mn = INT64_MAX, mx = INT64_MIN;
         switch (ks.dt[c]) {
-        case AQG_INT8: col_range<int8_t>(ks.col[c], n, mn, mx); break;
-        case AQG_INT16: col_range<int16_t>(ks.col[c], n, mn, mx); break;
-        case AQG_INT32: col_range<int32_t>(ks.col[c], n, mn, mx); break;
-        case AQG_INT64: col_range<int64_t>(ks.col[c], n, mn, mx); break;
-        case AQG_UINT8: case AQG_BOOL: col_range<uint8_t>(ks.col[c], n, mn, mx); break;
-        case AQG_UINT16: col_range<uint16_t>(ks.col[c], n, mn, mx); break;
-        default: col_range<uint32_t>(ks.col[c], n, mn, mx); break;      // AQG_UINT32 (uint64 keys never come here)
+        case AQG_INT8: col_range<int8_t>(ks.col[c], n, total, mn, mx); break;
+        case AQG_INT16: col_range<int16_t>(ks.col[c], n, total, mn, mx); break;
+        case AQG_INT32: col_range<int32_t>(ks.col[c], n, total, mn, mx); break;
+        case AQG_INT64: col_range<int64_t>(ks.col[c], n, total, mn, mx); break;
+        case AQG_UINT8: case AQG_BOOL: col_range<uint8_t>(ks.col[c], n, total, mn, mx); break;
+        case AQG_UINT16: col_range<uint16_t>(ks.col[c], n, total, mn, mx); break;
+        default: col_range<uint32_t>(ks.col[c], n, total, mn, mx); break;      // AQG_UINT32 (uint64 keys never come here)
         }
         mn = wave_reduce((int64_t)mn, OpMin{});
         mx = wave_reduce((int64_t)mx, OpMax{});
@@ -370,13 +374,15 @@ int aqg_dense_assign(aqg_ctx* ctx, const KeySpec& ks, const DenseSpec& ds, const
 }
 
 // Ranges of the key columns over n rows (synchronises).  Returns false when some column cannot take part (uint64 keys).
-int aqg_key_ranges(aqg_ctx* ctx, const KeySpec& ks, uint32_t n, long long* mins, long long* maxs, bool* ok) {
+int aqg_key_ranges(aqg_ctx* ctx, const KeySpec& ks, uint32_t n, long long* mins, long long* maxs, bool* ok, uint32_t total) {
+    if (total && (total < 4 * n || (n & 4095) || total < (1u << 22))) total = 0;      // (a spread sample needs room to spread: else the first n rows)
+    if (total) for (int c = 0; c < ks.nkeys; ++c) if ((uintptr_t)ks.col[c] & 15) total = 0;
     *ok = false;
     for (int c = 0; c < ks.nkeys; ++c) if (ks.dt[c] == AQG_UINT64) return AQG_OK;
     long long* d = nullptr;
     AQG_TRY(aqg_ws_get(ctx, 2 * MAXKEYS, &d));
     hipLaunchKernelGGL(range_init_kernel, dim3(1), dim3(64), 0, ctx->stream, d, ks.nkeys);
-    hipLaunchKernelGGL(key_range_kernel, dim3(aqg_grid(ctx, n / 4 + 1, 256, 4, 8)), dim3(256), 0, ctx->stream, ks, n, d);
+    hipLaunchKernelGGL(key_range_kernel, dim3(aqg_grid(ctx, n / 4 + 1, 256, 4, 8)), dim3(256), 0, ctx->stream, ks, n, total, d);
     AQG_TRY(aqg_check_launch(ctx, "key_range_kernel"));
     long long h[2 * MAXKEYS];
     AQG_TRY(aqg_d2h(ctx, h, d, sizeof(long long) * 2 * ks.nkeys));

@@ -14,7 +14,7 @@ struct DenseSpec {
     uint32_t per_pass, npass;    // idx in [p * per_pass, (p + 1) * per_pass) belongs to pass p
 };
 
-int aqg_key_ranges(aqg_ctx* ctx, const KeySpec& ks, uint32_t n, long long* mins, long long* maxs, bool* ok);   // over the first n rows
+int aqg_key_ranges(aqg_ctx* ctx, const KeySpec& ks, uint32_t n, long long* mins, long long* maxs, bool* ok, uint32_t total = 0);   // over the first n rows; total != 0: over n rows spread evenly (1024 blocks) over a column of `total` rows
 size_t aqg_dense_slot_bytes(const AccSpec& as, int need_count);
 bool aqg_dense_plan(const KeySpec& ks, const long long* mins, const long long* maxs, const AccSpec& as, int need_count, DenseSpec* ds);
 int aqg_dense_assign(aqg_ctx* ctx, const KeySpec& ks, const DenseSpec& ds, const uint32_t* slot_gid, uint32_t n, uint32_t G, uint32_t* reversemap, uint32_t* counts);

@@ -1239,7 +1239,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         for (int c = 0; c < ks.nkeys && cached; ++c) cached = h->range_col[c] == ks.col[c] && h->range_dt[c] == ks.dt[c];
         if (cached) { for (int c = 0; c < ks.nkeys; ++c) { mins[c] = h->range_min[c]; maxs[c] = h->range_max[c]; } ok = true; }
         else {
-            AQG_TRY(aqg_key_ranges(ctx, ks, sampled ? (1u << 20) : n, mins, maxs, &ok));
+            AQG_TRY(aqg_key_ranges(ctx, ks, sampled ? (1u << 20) : n, mins, maxs, &ok, sampled ? n : 0u));
             h->range_valid = sampled && ok;
             if (h->range_valid) {
                 h->range_nkeys = ks.nkeys; h->range_n = n;
@@ -1284,7 +1284,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, ui
         bool ok = false;
         AQG_TRY(aqg_ws_reset(ctx));
         AQG_TRY(aqg_ws_ensure(ctx, 4096));
-        AQG_TRY(aqg_key_ranges(ctx, ks, 1u << 20, mn, mx, &ok));            // (a sample: the look-up pass checks every row)
+        AQG_TRY(aqg_key_ranges(ctx, ks, 1u << 20, mn, mx, &ok, n));         // (a sample spread over the column: the look-up pass checks every row)
         if (ok && mx[0] >= mn[0]) {
             const long long span = mx[0] - mn[0] + 1, room = span / 64 + 1024, lo = mn[0] - room, hi = mx[0] + room;
             if (hi - lo + 1 <= (1ll << 21)) { lookup_build = true; lk_min = (uint32_t)lo; lk_D = (uint32_t)(hi - lo + 1); }

@@ -1504,7 +1504,7 @@ static int plan_pack(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_
     }
     long long mins[MAXKEYS], maxs[MAXKEYS];
     bool ok = false;
-    AQG_TRY(aqg_key_ranges(ctx, probe, 1u << 20, mins, maxs, &ok));          // (a sample: every row is verified while it is packed / binned)
+    AQG_TRY(aqg_key_ranges(ctx, probe, 1u << 20, mins, maxs, &ok, n));       // (a sample spread over the column: every row is verified while it is packed / binned)
     if (!ok) return AQG_OK;
     if (ks.range_known) { mins[0] = ks.range_lo; maxs[0] = ks.range_hi; }     // (the key's range as the caller knows it; the value columns' from the sample)
     pp->have_range = true; pp->key_lo = mins[0]; pp->key_hi = maxs[0]; pp->exact = ks.range_known != 0;
@@ -2007,7 +2007,7 @@ static bool plan_packw(aqg_ctx* ctx, const KeySpec& ks, uint32_t n, PackW* pk, i
     for (int k = 0; k < ks.nkeys; ++k) if (!(ks.dt[k] == AQG_INT32 || ks.dt[k] == AQG_UINT32) || ((uintptr_t)ks.col[k] & 15)) return false;
     long long mins[MAXKEYS], maxs[MAXKEYS];
     bool ok = false;
-    *err = aqg_key_ranges(ctx, ks, 1u << 20, mins, maxs, &ok);              // (a sample: every row is verified while it is packed)
+    *err = aqg_key_ranges(ctx, ks, 1u << 20, mins, maxs, &ok, n);           // (a sample spread over the column: every row is verified while it is packed)
     if (*err != AQG_OK || !ok) return false;
     int bits[MAXKEYS], order[MAXKEYS];
     for (int k = 0; k < ks.nkeys; ++k) {
@@ -2695,7 +2695,7 @@ static int gid_reduce_impl(aqg_ctx* ctx, const uint32_t* gid, const uint32_t* of
         probe.nkeys = 1; probe.dt[0] = t; probe.col[0] = x;
         long long mn[MAXKEYS], mx[MAXKEYS];
         bool ok = false;
-        AQG_TRY(aqg_key_ranges(ctx, probe, 1u << 20, mn, mx, &ok));
+        AQG_TRY(aqg_key_ranges(ctx, probe, 1u << 20, mn, mx, &ok, n));
         int gbits = 1;
         while (gbits < 32 && (1ull << gbits) < (unsigned long long)G) ++gbits;
         if (ok && mx[0] >= mn[0]) {
