@@ -1192,8 +1192,17 @@ int make_plan(aqg_ctx* ctx, int naggs, const int* ops, const int* dts, const voi
 struct DenseOut { bool used; DenseSpec spec; };
 constexpr int AQG_ERR_RANGE_MISS = -1001;            // internal: sampled key ranges missed a value; run_with_retry repeats the attempt      // tells aqg_groupby_build that the table is the direct-indexed one
 
-int run_agg(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan_in, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
+int run_agg(aqg_ctx* ctx, const KeySpec& ks_in, const Plan& plan_in, uint32_t n, uint32_t hint, bool for_build, aqg_groupby* h,
             GTable* gt_out, uint32_t** slot_gid_out, uint32_t** occ_out = nullptr, DenseOut* dense_out = nullptr) {
+    // Packed keys (<= 8 bytes) with more groups expected than their partition plans reach (2^25) are handled as WIDE tuples: that plan
+    // partitions on a hash of the tuple and compares tuples through representative rows, whatever the key width, up to one group per row
+    // (2e8 unique 4-byte keys: 107 ms through the HBM table of scattered device atomics they fell to before)
+    KeySpec ks = ks_in;
+    static const bool widen_off = getenv("AQG_DISABLE_WIDEN_PACKED") != nullptr;      // A/B measurements only
+    if (!widen_off && !ks.wide && !for_build && hint > (1u << 25) && n >= (1u << 20) && !plan_in.sj && plan_in.as.nacc <= 4) {
+        ks.wide = 1;
+        for (int j = 0; j < ks.nkeys; ++j) ks.shift[j] = 0;
+    }
     // more than ~1.6e7 groups expected out of a partition plan: the records are ORDERED (aqg_sorted_tail) instead of ranked through a
     // bitmap over the rows and gathered (h2o Q10, 1e9 groups: that tail took 219 of 317 ms and fetched 900 GB)
     static const uint32_t sorted_min = getenv("AQG_SORTED_TAIL_MIN") ? (uint32_t)atoi(getenv("AQG_SORTED_TAIL_MIN")) : (1u << 24);

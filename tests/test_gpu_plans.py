@@ -249,6 +249,35 @@ def test_h2o_q10_at_1e8_rows_default_thresholds_groups_of_two():
         d.close()
 
 
+def test_packed_keys_beyond_the_partition_plans_take_the_wide_tuple_plan():
+    """more than 2^25 groups expected over a key of <= 8 bytes (a nearly unique 4-byte key, a pair of them): the packed-key partition plans end
+    there, and the call is handled like a wide tuple -- hash partitions, representative rows, the ordering tail -- instead of falling to the
+    HBM table (2e8 unique keys: 105 -> 11 ms)"""
+    import aquery2_amd
+    import golden_util as gu
+    from aquery2_amd import capi
+    d = aquery2_amd.Device(0)
+    oracle = ck.load_oracle()
+    try:
+        n = 40_000_003
+        i = np.arange(n, dtype=np.int64)
+        key = ((i * 2654435761) % (1 << 31)).astype(np.int32)       # all distinct
+        key[1::10] = key[0::10][: key[1::10].size]                   # ... but every tenth row repeats its neighbour: 3.6e7 groups
+        v = (i % 1000 - 500).astype(np.int32)
+        for keys in ([key], [(key & 0xFFFF).astype(np.uint16), (key >> 16).astype(np.int16)]):
+            o = oracle.groupby(keys)
+            gb = d.groupby_agg(keys, [ck.RED_SUM, ck.RED_COUNT, ck.RED_MIN], [v, v, v], hint=n)
+            assert gb.plan & capi.PLAN_PART_WIDE, gb.plan
+            assert gb.ngroups == o["ngroups"] and np.array_equal(gb.first_rows(), o["first_rows"])
+            for k, c in enumerate(keys):
+                assert np.array_equal(gb.keys(k, c.dtype), c[o["first_rows"]]), k
+            for j, op in enumerate((ck.RED_SUM, ck.RED_COUNT, ck.RED_MIN)):
+                assert gu.same_bits(gb.result(j, op, ck.tag_of(v)), oracle.grouped_reduce(op, v, o)), j
+            gb.destroy()
+    finally:
+        d.close()
+
+
 @pytest.mark.parametrize("n,G", [(9_000_017, 4_000_000), (4_200_000, -1)])
 def test_grouped_reduce_partitioned_on_the_dense_group_id(n, G):
     """aqg_grouped_reduce beyond the LDS tables: rows {id, value} partitioned on the build's dense group id (one and two levels of
