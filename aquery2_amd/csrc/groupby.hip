@@ -1727,7 +1727,7 @@ __global__ void __launch_bounds__(256) sample_gather_kernel(const void* __restri
 __global__ void __launch_bounds__(1024) sample_block_distinct_kernel(KeySpec ks /* over the gathered sample */, uint32_t* __restrict__ out) {
     __shared__ uint64_t key[1024];
     __shared__ uint32_t cnt;
-    const size_t row = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    const size_t row = (size_t)blockIdx.x * 8 * 1024 + threadIdx.x;            // (every eighth block of the sample: an estimate of an estimate)
     const uint64_t k = ks.wide ? (uint64_t)hash_wide(ks, row) : pack_key(ks, row);      // (wide tuples by their 32-bit hash: 1024 rows, an estimate)
     key[threadIdx.x] = k;
     if (threadIdx.x == 0) cnt = 0;
@@ -1761,9 +1761,10 @@ uint64_t estimate_groups(aqg_ctx* ctx, const KeySpec& ks, uint32_t n) {
     }
     uint32_t* d2 = reinterpret_cast<uint32_t*>(static_cast<char*>(buf) + off);
     (void)hipMemsetAsync(d2, 0, 4, ctx->stream);
-    hipLaunchKernelGGL(sample_block_distinct_kernel, dim3(1024), dim3(1024), 0, ctx->stream, sk, d2);
+    hipLaunchKernelGGL(sample_block_distinct_kernel, dim3(128), dim3(1024), 0, ctx->stream, sk, d2);
     uint32_t D2 = 0;
     bool ok = hipMemcpyAsync(&D2, d2, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    D2 *= 8;
     aqg_groupby* tmp = new aqg_groupby();
     tmp->ctx = ctx; tmp->n = s; tmp->count_only = true;
     uint64_t est = 0;
