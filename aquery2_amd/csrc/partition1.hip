@@ -741,7 +741,7 @@ struct WideIn {
     const uint32_t* rows;                     // partitioned global row ids
     const void* vcol[MAXACC]; int vesz[MAXACC];   // partitioned value arrays per accumulator (null: the row id)
 };
-constexpr uint32_t WEMPTY = 0xFFFFu;
+constexpr uint32_t WEMPTY = 0xFFFFu, WEMPTY32 = 0xFFFFFFFFu;
 // one workgroup of NT threads per partition (grid-stride); R <= 3 NT = row capacity.  LDS: acc u64[NACC][R] | keys u32[nkd][R] |
 // first u32[R] | count u32[R] | table u16[2R] | rep u16[R]; a row's id and values stay in the registers of the thread that loaded it.
 // The phases are separated by barriers and each is a chain of LDS round trips, so the kernel lives on workgroups per CU: the plan
@@ -755,8 +755,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
     uint32_t* lkey = reinterpret_cast<uint32_t*>(lacc + (size_t)NACC * R);     // [nkd][R]
     uint32_t* lfirst = lkey + (size_t)in.nkd * R;
     uint32_t* lcount = lfirst + R;
-    uint16_t* table = reinterpret_cast<uint16_t*>(lcount + R);                 // [2R]
-    uint16_t* rep = table + 2 * R;                                             // [R]
+    uint32_t* table = lcount + R;                                              // [2R] slot -> the row that represents the slot's tuple
+    uint16_t* rep = reinterpret_cast<uint16_t*>(table + 2 * R);                // [R]
     __shared__ uint32_t lemit, gbase, ngrp;
     const uint32_t T = 2 * R;
     for (uint32_t part = blockIdx.x; part < nparts; part += gridDim.x) {
@@ -784,7 +784,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
                 }
             }
         }
-        for (uint32_t s = threadIdx.x; s < T; s += NT) table[s] = (uint16_t)WEMPTY;
+        for (uint32_t s = threadIdx.x; s < T; s += NT) table[s] = WEMPTY32;
         if (threadIdx.x == 0) { lemit = 0; ngrp = 0; }
         __syncthreads();
         // representative of every row: the first row index that claimed the slot of an equal tuple
@@ -794,19 +794,10 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
             uint32_t s = __umulhi(h ^ (h >> 15), T);
             uint32_t r = WEMPTY;
             for (uint32_t step = 0; step < T; ++step) {
-                uint32_t cur = *reinterpret_cast<volatile uint16_t*>(&table[s]);
-                if (cur == WEMPTY) {
-                    // claim through a 32-bit CAS on the aligned pair holding the slot
-                    uint32_t* w = reinterpret_cast<uint32_t*>(table) + (s >> 1);
-                    const uint32_t sh = (s & 1) * 16;
-                    uint32_t old = *reinterpret_cast<volatile uint32_t*>(w);
-                    while (((old >> sh) & 0xFFFFu) == WEMPTY) {
-                        const uint32_t want = (old & ~(0xFFFFu << sh)) | (i << sh);
-                        const uint32_t got = atomicCAS(w, old, want);
-                        if (got == old) break;
-                        old = got;
-                    }
-                    cur = (*reinterpret_cast<volatile uint32_t*>(w) >> sh) & 0xFFFFu;
+                uint32_t cur = *reinterpret_cast<volatile uint32_t*>(&table[s]);
+                if (cur == WEMPTY32) {                                          // claim the slot for this row (a plain 32-bit compare-and-swap: the 16-bit
+                    const uint32_t got = atomicCAS(&table[s], WEMPTY32, i);     //  slots of rounds 2 - 3 took a read-modify-write loop on the pair holding them)
+                    cur = got == WEMPTY32 ? i : got;
                 }
                 bool eq = cur == i;
                 if (!eq) { eq = true; for (int k = 0; k < in.nkd && eq; ++k) eq = lkey[(size_t)k * R + cur] == lkey[(size_t)k * R + i]; }
@@ -1221,7 +1212,7 @@ int aqg_partition2_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
 
 // ---- wide tuples: host ----------------------------------------------------------------------------------------------------------------
 struct WidePlan { uint32_t R, P, B1; int L, nkd, low[3], nt; size_t lds; bool ok; };   // low[l]: bits of level l + 1 (the levels below the first)
-static size_t pw_row_lds(int nkd, int nacc) { return 4 * (size_t)nkd + 4 + 4 + 8 * (size_t)nacc + 4 + 2; }
+static size_t pw_row_lds(int nkd, int nacc) { return 4 * (size_t)nkd + 4 + 4 + 8 * (size_t)nacc + 8 + 2; }   // key dwords | first | count | accumulators | two 4-byte slots | representative
 // `hint` = the expected number of groups: with m = n / hint rows per tuple the rows of a partition are not independent -- the tuples are --
 // and the spread of a partition's ROW count grows to sqrt(mean * m) (every tuple brings its m rows along); sizing by sqrt(mean) alone sent
 // every table of multi-row tuples through two overflowing attempts to the HBM table (3.2e6 rows, 1.26e6 tuples: partitions at mean + 7 sigma)
