@@ -200,6 +200,48 @@ def test_full_size_properties_q5_and_windows(gpu):
     assert (int(last["hi"]) << 64) + int(last["lo"]) == int(gpu.reduce(ck.RED_SUM, price))
 
 
+def test_h2o_q5_q3_q7_at_the_full_1e9_rows(gpu):
+    """BASELINE config 2 at its full size, through the plan the bench takes (two levels of range partitions, value columns inside the key word, the
+    direct-indexed aggregation): invariants that do not need the oracle -- the plan bits, the group count, every key once, groups in first-occurrence
+    order, sums of group sums / counts against whole-column reductions, avg = sum / count, max and min inside the columns' ranges and met"""
+    from aquery2_amd import capi
+    n = 1_000_000_000
+    id6, id3, v1, v2, v3 = (gpu.gen_column(c, 42, 0, n, n, K) for c in (ck.GEN_ID6, ck.GEN_ID3, ck.GEN_V1, ck.GEN_V2, ck.GEN_V3))
+    want = capi.PLAN_PART_TWO | capi.PLAN_PACKED_VALUES | capi.PLAN_RANGE_PARTITIONS
+    # Q5: sum(v1), sum(v2), sum(v3), count BY id6
+    gb = gpu.groupby_agg([id6], [ck.RED_SUM, ck.RED_SUM, ck.RED_SUM, ck.RED_COUNT], [v1, v2, v3, v1], hint=n // K + 1024)
+    assert gb.plan == want, gb.plan
+    G = gb.ngroups
+    assert 0.999 * (n // K) < G <= n // K
+    keys = gb.keys(0, np.int32)
+    assert keys.min() >= 1 and keys.max() <= n // K and np.unique(keys).size == G                   # every key once
+    first = gb.first_rows().astype(np.int64)
+    assert np.all(np.diff(first) > 0) and first[0] == 0 and first[-1] < n                           # first-occurrence order
+    s1, s2 = gb.result(0, ck.RED_SUM, ck.INT32), gb.result(1, ck.RED_SUM, ck.INT32)
+    assert int(s1["lo"].astype(np.int64).sum()) == int(gpu.reduce(ck.RED_SUM, v1)) and not s1["hi"].any()
+    assert int(s2["lo"].astype(np.int64).sum()) == int(gpu.reduce(ck.RED_SUM, v2)) and not s2["hi"].any()
+    cnt = gb.result(3, ck.RED_COUNT, ck.INT32)
+    assert int(cnt.sum()) == n
+    s3 = gb.result(2, ck.RED_SUM, ck.FLOAT)
+    tot3 = float(gpu.reduce(ck.RED_SUM, v3))
+    assert abs(float(s3.sum()) - tot3) <= 1e-9 * abs(tot3)                                          # (float sums: order-dependent in the last bits)
+    gb.destroy()
+    # Q3: sum(v1), avg(v3) BY id3 -- avg against the sums of Q5's kind
+    gb = gpu.groupby_agg([id3], [ck.RED_SUM, ck.RED_AVG, ck.RED_SUM, ck.RED_COUNT], [v1, v3, v3, v3], hint=n // K + 1024)
+    assert gb.plan == want, gb.plan
+    avg, s3, cnt = gb.result(1, ck.RED_AVG, ck.FLOAT), gb.result(2, ck.RED_SUM, ck.FLOAT), gb.result(3, ck.RED_COUNT, ck.FLOAT)
+    assert np.array_equal(avg, s3 / cnt.astype(np.float64)) and int(cnt.sum()) == n
+    gb.destroy()
+    # Q7: max(v1), min(v2) BY id3 -- no value plane at all
+    gb = gpu.groupby_agg([id3], [ck.RED_MAX, ck.RED_MIN], [v1, v2], hint=n // K + 1024)
+    assert gb.plan == want, gb.plan
+    mx, mn = gb.result(0, ck.RED_MAX, ck.INT32), gb.result(1, ck.RED_MIN, ck.INT32)
+    assert mx.max() == int(gpu.reduce(ck.RED_MAX, v1)) and mx.min() >= int(gpu.reduce(ck.RED_MIN, v1))
+    assert mn.min() == int(gpu.reduce(ck.RED_MIN, v2)) and mn.max() <= int(gpu.reduce(ck.RED_MAX, v2))
+    gb.destroy()
+    for c in (id6, id3, v1, v2, v3): c.free()
+
+
 def test_shard_exchange_pack_and_merge(gpu, oracle):
     """SURVEY 8e on one device: three row-range shards grouped separately, their tables packed (aqg_groupby_pack) into the
     buffer an all_gather would fill, merged by aqg_groupby_merge_packed == the group-by of the whole table"""
