@@ -100,13 +100,26 @@ __global__ void __launch_bounds__(SB) p1_hist_kernel(const key_t_<K64>* __restri
     __syncthreads();
     uint64_t cb, ce;
     chunk_range(ch, blockIdx.x, cb, ce);
-    for (uint64_t rb = cb; rb < ce; rb += (uint64_t)SB * HR) {
-        const uint32_t nrows = ce - rb < (uint64_t)SB * HR ? (uint32_t)(ce - rb) : SB * HR;
+    constexpr uint64_t STEP = (uint64_t)SB * HR;
+    if (!(ch.has_tail && blockIdx.x + 1 == ch.nchunks)) {     // whole tiles, so whole steps: the next step's keys in flight while this one's are counted
+        key_t_<K64> cur[HR];
+        if (cb < ce) load_rows<true>(keys, cb, (uint32_t)STEP, 0, cur);
+        for (uint64_t rb = cb; rb < ce; rb += STEP) {
+            key_t_<K64> nxt[HR];
+            load_rows<true>(keys, rb + STEP < ce ? rb + STEP : rb, (uint32_t)STEP, 0, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < HR; ++r) { uint32_t o_ = 0; atomicAdd(&cnt[p1_bin<K64, RANGED>(ch, cur[r], o_)], 1u); }      // (a key outside the sampled domain: the scatter flags it)
+#pragma unroll
+            for (int r = 0; r < HR; ++r) cur[r] = nxt[r];
+        }
+    } else for (uint64_t rb = cb; rb < ce; rb += STEP) {      // the tail chunk (less than one tile)
+        const uint32_t nrows = ce - rb < STEP ? (uint32_t)(ce - rb) : (uint32_t)STEP;
         key_t_<K64> key[HR];
-        if (nrows == SB * HR) load_rows<true>(keys, rb, nrows, 0, key); else load_rows<false>(keys, rb, nrows, 0, key);
+        load_rows<false>(keys, rb, nrows, 0, key);
 #pragma unroll
         for (int r = 0; r < HR; ++r)
-            if (tile_row(r) < nrows) { uint32_t o_ = 0; atomicAdd(&cnt[p1_bin<K64, RANGED>(ch, key[r], o_)], 1u); }      // (a key outside the sampled domain: the scatter flags it)
+            if (tile_row(r) < nrows) { uint32_t o_ = 0; atomicAdd(&cnt[p1_bin<K64, RANGED>(ch, key[r], o_)], 1u); }
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < ch.nbins; b += SB) hist[(size_t)b * ch.nchunks + blockIdx.x] = cnt[b];
@@ -303,10 +316,7 @@ __global__ void __launch_bounds__(1024) p2_hist_kernel(const key_t_<K64>* __rest
     for (uint32_t b = threadIdx.x; b < (RANGED ? __umulhi(xmax, P) + 1 : P); b += 1024) cnt[b] = 0;
     __syncthreads();
     const uint64_t step = (uint64_t)1024 * HB;
-    for (uint64_t rb = (uint64_t)blockIdx.x * step; rb < n; rb += (uint64_t)gridDim.x * step) {
-        const uint32_t nrows = n - rb < step ? (uint32_t)(n - rb) : (uint32_t)step;
-        key_t_<K64> key[HB];
-        if (nrows == step) load_rows_t<1024, true>(keys, rb, nrows, 0, key); else load_rows_t<1024, false>(keys, rb, nrows, 0, key);
+    auto count = [&](const key_t_<K64> (&key)[HB], uint32_t nrows) {
 #pragma unroll
         for (int r = 0; r < HB; ++r) {
             if (!(trow<1024>(r) < nrows)) continue;
@@ -315,6 +325,28 @@ __global__ void __launch_bounds__(1024) p2_hist_kernel(const key_t_<K64>* __rest
             else h = key_hash<K64>(key[r]);
             atomicAdd(&cnt[__umulhi(h, P)], 1u);
         }
+    };
+    // whole steps, the next one's keys in flight while this one's are counted (one code path for the loads: a loader that may take the
+    // clamped form is waited for right behind its loads); the partial step at the end of the column by itself
+    const uint64_t nfull = (uint64_t)n / step, stride = gridDim.x;
+    uint64_t t = blockIdx.x;
+    key_t_<K64> cur[HB];
+    if (t < nfull) load_rows_t<1024, true>(keys, t * step, (uint32_t)step, 0, cur);
+    while (t < nfull) {
+        const uint64_t tn = t + stride;
+        key_t_<K64> nxt[HB];
+        load_rows_t<1024, true>(keys, (tn < nfull ? tn : t) * step, (uint32_t)step, 0, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        count(cur, (uint32_t)step);
+#pragma unroll
+        for (int r = 0; r < HB; ++r) cur[r] = nxt[r];
+        t = tn;
+    }
+    if (blockIdx.x == 0 && nfull * step < n) {
+        key_t_<K64> last[HB];
+        const uint32_t nrows = (uint32_t)(n - nfull * step);
+        load_rows_t<1024, false>(keys, nfull * step, nrows, 0, last);
+        count(last, nrows);
     }
     __syncthreads();
     const uint32_t nb = RANGED ? __umulhi(xmax, P) + 1 : P;                                        // (RANGED: P is the multiplier, not the bin count)
@@ -374,13 +406,15 @@ __global__ void __launch_bounds__(1024) p2_setup_kernel(const uint32_t* __restri
 }
 
 // FULL: grid over all tiles of all segments, whole tiles only.  !FULL: one workgroup per segment takes its last, partial tile.
-template <int TB, int TR, bool K64, bool FULL, int MODE = BIN_HASHED, bool PACK = false>
+// NBMAX: bins per level, 128 (the levels of the two-level and wide plans) or 256 (the one-level range plan: FUSE0 keeps a bin in a byte)
+template <int TB, int TR, bool K64, bool FULL, int MODE = BIN_HASHED, bool PACK = false, int NBMAX = 128>
 __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2_scatter_kernel(const key_t_<K64>* __restrict__ keys, Planes pl, P2Level lv) {
     constexpr int TPT = TB * TR;
     constexpr int HH = TR < 16 ? TR : 16;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint32_t* stage = reinterpret_cast<uint32_t*>(smem_raw);      // [TPT]
-    __shared__ uint32_t lb[129], gd[128], wtot;                // up to 128 bins per level
+    static_assert(NBMAX == 128 || NBMAX == 256, "bins per level");
+    __shared__ uint32_t lb[NBMAX + 1], gd[NBMAX], wtot, wbin[NBMAX / 64];
     __shared__ uint8_t tb[(TPT + 127) / 128];                   // FUSE0: the bin at every 128th staged position
     uint32_t seg, rb, nrows;
     if constexpr (FULL) {
@@ -432,7 +466,7 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
         rb = lv.seg_start[seg + 1] - nrows;
     }
     const uint32_t NB = lv.nbins;
-    if (threadIdx.x <= 128) lb[threadIdx.x] = 0;
+    if (threadIdx.x <= NBMAX) lb[threadIdx.x] = 0;
     __syncthreads();
     // FUSE0 (4-byte key words; every caller's plane 0 IS the key column): the keys stay in registers from the ranking to the staging of
     // plane 0 -- COUNT the bins (non-returning LDS atomics), scan, then take every row's staged position from its bin's running cursor
@@ -488,16 +522,17 @@ __global__ void __launch_bounds__(TB, (FULL && TB * TR * 4 <= 65536) ? 8 : 1) p2
     }
     if constexpr (MODE == BIN_RANGED) { if (outside) *lv.flag = 1u; }     // (rows beyond a partial tile repeat its last row: no false alarm)
     __syncthreads();
-    {   // first two wavefronts: exclusive scan of the bin counts; reserve this tile's run of every bin with one atomic per bin
+    {   // first wavefronts: exclusive scan of the bin counts; reserve this tile's run of every bin with one atomic per bin
         uint32_t c = 0, incl = 0;
-        if (threadIdx.x < 128) {
+        if (threadIdx.x < NBMAX) {
             c = threadIdx.x < NB ? lb[threadIdx.x] : 0;
             incl = wave_scan_incl(c, OpAdd{}, lane_id());
-            if (threadIdx.x == 63) wtot = incl;
+            if (lane_id() == 63) wbin[wave_id()] = incl;
         }
         __syncthreads();
-        if (threadIdx.x < 128) {
-            const uint32_t excl = incl - c + (threadIdx.x >= 64 ? wtot : 0);
+        if (threadIdx.x < NBMAX) {
+            uint32_t excl = incl - c;
+            for (int w = 0; w < wave_id(); ++w) excl += wbin[w];
             const uint32_t base = c ? atomicAdd(&lv.cursor[(size_t)seg * lv.cursor_per_seg + threadIdx.x], c) : 0;
             lb[threadIdx.x] = excl;
             gd[threadIdx.x] = base - excl;
@@ -857,6 +892,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
 
 } // namespace
 
+constexpr int P2_TB = 1024, P2_TR = 16, P2_PT = P2_TB * P2_TR;     // 16384-row tiles: 64 KB of staging, two workgroups per CU
+
 static void p1_geometry(const aqg_ctx* ctx, uint32_t n, Chunks* ch) {
     const uint64_t tiles = (uint64_t)n / PT;                                 // whole tiles
     const uint64_t target = (uint64_t)ctx->num_cu * 4;                       // chunks: four rounds of one workgroup per CU
@@ -1014,11 +1051,6 @@ int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
             vsrc[u] = wide;
         }
     }
-    const size_t hcount = (size_t)nbins * ch.nchunks;
-    uint32_t *hist, *bsum;
-    AQG_TRY(aqg_ws_get(ctx, hcount, &hist));
-    AQG_TRY(aqg_ws_get(ctx, hcount / 2048 + 64, &bsum));
-
     Planes pl;
     memset(&pl, 0, sizeof pl);
     auto add = [&](int kind, const void* s, int sstride, int soff, void* d, int dstride, int doff) {
@@ -1039,6 +1071,44 @@ int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         if (part_val_bytes(vc.dt[u]) == 4) add(PL_LOAD, vsrc[u], 1, 0, pvals[u], 1, 0);
         else { add(PL_LOAD, vsrc[u], 2, 0, pvals[u], 2, 0); add(PL_LOAD, vsrc[u], 2, 1, pvals[u], 2, 1); }
     }
+    // Range partitions of <= 256 bins go through the tile scatter of the two-level plan, as its only level: whole-column bin counts, write
+    // cursors instead of per-chunk histograms, 16384-row tiles with the keys kept in registers, two workgroups per CU so that one tile's
+    // loads run under the other's stores (h2o Q5 / Q7 at 1e9 rows, 1e6 groups: this kernel's own 32768-row tiles, one workgroup per CU,
+    // moved 3.9 / 2.8 TB/s)
+    static const bool cursor_off = getenv("AQG_DISABLE_P1_CURSORS") != nullptr;             // A/B measurements only
+    if (rp.on && ksz == 4 && nbins <= 256 && !cursor_off) {
+        const uint32_t P = nbins;
+        uint32_t *ftot, *fstart, *cur, *seg1, *tp1, *cur1, *seg2, *tp2;
+        AQG_TRY(aqg_ws_get(ctx, (size_t)P, &ftot));
+        AQG_TRY(aqg_ws_get(ctx, (size_t)P + 1, &fstart));
+        AQG_TRY(aqg_ws_get(ctx, (size_t)P, &cur));
+        AQG_TRY(aqg_ws_get(ctx, 2, &seg1));
+        AQG_TRY(aqg_ws_get(ctx, 2, &tp1));
+        AQG_TRY(aqg_ws_get(ctx, 64, &cur1));
+        AQG_TRY(aqg_ws_get(ctx, 65, &seg2));
+        AQG_TRY(aqg_ws_get(ctx, 65, &tp2));
+        AQG_HIP(ctx, hipMemsetAsync(ftot, 0, (size_t)P * 4, ctx->stream));
+        const uint32_t* kc = static_cast<const uint32_t*>(keycol);
+        hipLaunchKernelGGL((p2_hist_kernel<false, true>), dim3(aqg_grid(ctx, n, 1024, HB, 4)), dim3(1024), (size_t)P * 4, ctx->stream, kc, n, rp.M, ftot, rp.kmin, rp.D - 1);
+        hipLaunchKernelGGL(p2_setup_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)ftot, P, n, (uint32_t)P2_PT, fstart, cur, seg1, tp1, cur1, seg2, tp2, (uint32_t*)nullptr, 0u);
+        P2Level lv{seg1, tp1, cur, 1u, rp.M, 0u, 0xFFFFFFFFu, P, 0u, 0u, rp.kmin, rp.D - 1, out.flags + 6, nullptr, nullptr};
+        const size_t lds = (size_t)P2_PT * 4;
+        const unsigned tiles = (unsigned)(((uint64_t)n + P2_PT - 1) / P2_PT);
+        auto go = [&](auto packing) -> int {
+            constexpr bool PK = decltype(packing)::value;
+            AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, true, BIN_RANGED, PK, 256>), lds));
+            AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(&p2_scatter_kernel<P2_TB, P2_TR, false, false, BIN_RANGED, PK, 256>), lds));
+            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, true, BIN_RANGED, PK, 256>), dim3(tiles), dim3(P2_TB), lds, ctx->stream, kc, pl, lv);
+            hipLaunchKernelGGL((p2_scatter_kernel<P2_TB, P2_TR, false, false, BIN_RANGED, PK, 256>), dim3(1), dim3(P2_TB), lds, ctx->stream, kc, pl, lv);
+            return aqg_check_launch(ctx, "one-level partition scatter (cursors)");
+        };
+        if (pp.n) AQG_TRY(go(std::true_type{})); else AQG_TRY(go(std::false_type{}));
+        return p1_launch_agg_direct(ctx, as, vc, pkeys, prows, pvals, fstart, 1u, n, need_count, out, out_cap, pp.n ? &pp : nullptr, rp);
+    }
+    const size_t hcount = (size_t)nbins * ch.nchunks;
+    uint32_t *hist, *bsum;
+    AQG_TRY(aqg_ws_get(ctx, hcount, &hist));
+    AQG_TRY(aqg_ws_get(ctx, hcount / 2048 + 64, &bsum));
     const size_t hist_lds = (size_t)nbins * 4;
     const size_t scat_lds = (size_t)PT * 4 + ((size_t)nbins * 2 + 1) * 4;
     const unsigned nmain = ch.nchunks - ch.has_tail;
@@ -1067,8 +1137,6 @@ int aqg_partition1_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
 
 
 // ---- two levels: host ---------------------------------------------------------------------------------------------------------------
-constexpr int P2_TB = 1024, P2_TR = 16, P2_PT = P2_TB * P2_TR;     // 16384-row tiles: 64 KB of staging, two workgroups per CU
-
 static uint32_t p2_round_parts(uint32_t parts) { return (parts + 63) & ~63u; }
 
 size_t aqg_partition2_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t parts) {

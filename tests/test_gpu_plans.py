@@ -118,7 +118,8 @@ def test_one_level_plan_over_a_dense_key_domain_takes_range_partitions():
     # (a domain of 1.5e7 values for 4e5 groups would need more bins than the hashed plan was given: hashed here, the value column still packed)
     one = one.replace("check([sparse], [ck.RED_SUM, ck.RED_SUM], [v1, v3], 500_000, PT | PK | RG)", "check([sparse], [ck.RED_SUM, ck.RED_SUM], [v1, v3], 500_000, PT | PK)")
     assert one.count("500_000, PT | PK)") == 1
-    run_forced({}, one)
+    run_forced({}, one)                                     # <= 256 range bins: the cursor scatter of the two-level plan as the only level
+    run_forced({"AQG_DISABLE_P1_CURSORS": "1"}, one)        # the chunk-histogram scatter (what more than 256 range bins take)
 
 
 def test_two_level_plan_over_a_dense_key_domain_takes_range_partitions():
