@@ -1556,7 +1556,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks_in, const Plan& plan_in, uint32_t n,
     // still queued (stream-ordered, like every device result of this library), so the host's way to the next call overlaps them.
     // An overflow is noticed with the tail already queued on it: those kernels are bounded by the table and by `gmax`, their
     // results are discarded and the call re-plans as before.
-    const bool defer = n && (fast || plan.sj) && small_rank && !dense && !use_part && !use_wpart && !h->count_only;
+    const bool defer = n && (fast || plan.sj) && small_rank && !dense && !use_part && !use_wpart;
     const uint32_t gupper = (uint32_t)(slots + 1 < 4096 ? slots + 1 : 4096);
     uint32_t* pinned_flags = nullptr;
     if (defer) {
@@ -1565,7 +1565,6 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks_in, const Plan& plan_in, uint32_t n,
         AQG_HIP(ctx, hipEventRecord(ctx->ev_flags, ctx->stream));
     }
     if (!defer) AQG_TRY(read_flags());
-    if (h->count_only) { h->ngroups = G; return AQG_OK; }       // (estimate_groups: the rest of the tail would be thrown away)
     if ((defer || G) && n && fast) {
         // two launches: 32 workgroups over the first 32768 rows (where every group of an h2o-like column already shows up), then
         // the whole chip over the rest, whose workgroups leave at once when nothing is missing.  One launch of 256 workgroups
@@ -1714,63 +1713,63 @@ int run_with_retry(aqg_ctx* ctx, const KeySpec& ks, const Plan& plan, uint32_t n
 // by its key, or arriving key by key -- show themselves by blocks that share no tuples (d ~ D2) although rows repeat inside the blocks (D2 < s):
 // every run of equal keys is then seen about once per n / s rows, G ~ d n / s.  (With the first 2^20 rows as the sample, 1e9 rows sorted by a key
 // of 1e7 values were estimated at 13,000 groups; the escalation behind that ended in the HBM table: 7.9 s for a 21 ms call.)
-__global__ void __launch_bounds__(256) sample_gather_kernel(const void* __restrict__ src, int esz, uint32_t total, void* __restrict__ dst) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;                       // sample row: block i >> 10, position i & 1023
-    const size_t r = (size_t)(((uint64_t)(i >> 10) * total) >> 10) + (i & 1023u);
-    switch (esz) {
-    case 1: static_cast<uint8_t*>(dst)[i] = static_cast<const uint8_t*>(src)[r]; break;
-    case 2: static_cast<uint16_t*>(dst)[i] = static_cast<const uint16_t*>(src)[r]; break;
-    case 4: static_cast<uint32_t*>(dst)[i] = static_cast<const uint32_t*>(src)[r]; break;
-    default: static_cast<uint64_t*>(dst)[i] = static_cast<const uint64_t*>(src)[r]; break;
+// Both counts from ONE kernel over the rows where they lie (block b = sample block b, 1024 consecutive rows from row (b * total) >> 10): the
+// tuples go into an open-addressing table in HBM (2^21 8-byte slots for 2^20 rows; wide tuples by their 32-bit hash: an estimate) and into one of
+// 2048 slots in LDS; the first of every tuple is counted.  One launch, one host round trip: ~50 us.  (Before: the sample gathered into columns of its
+// own, a quadratic per-block distinct count -- 69 us -- and a count-only group-by through the one-level partition plan: ~0.3 ms with its three host
+// round trips, a fifth of h2o Q1's first call at 1e9 rows.)
+constexpr uint32_t SAMPLE_ROWS = 1u << 20, SAMPLE_SLOTS = 1u << 21;
+__device__ inline uint32_t sample_mix(uint64_t k) { k ^= k >> 33; k *= 0xFF51AFD7ED558CCDull; k ^= k >> 33; k *= 0xC4CEB9FE1A85EC53ull; return (uint32_t)(k >> 32); }
+__global__ void __launch_bounds__(1024) sample_distinct_kernel(KeySpec ks, uint32_t total, unsigned long long* __restrict__ table /* [SAMPLE_SLOTS], all ones */,
+                                                               uint32_t* __restrict__ out /* [0] distinct in the sample, [1] sum of the blocks' distinct counts, [2] the all-ones tuple seen */) {
+    constexpr unsigned long long NONE = ~0ull;
+    __shared__ unsigned long long lkey[2048];
+    __shared__ uint32_t cnt[2];
+    lkey[threadIdx.x] = NONE; lkey[threadIdx.x + 1024] = NONE;
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t row = (size_t)(((uint64_t)blockIdx.x * total) >> 10) + threadIdx.x;
+    const unsigned long long k = ks.wide ? (unsigned long long)hash_wide(ks, row) : (unsigned long long)pack_key(ks, row);
+    bool first_here = false, first_all = false;
+    if (k == NONE) atomicOr(&out[2], 1u);                       // (the empty mark itself: counted once by the host)
+    else {
+        const uint32_t h = sample_mix(k);
+        for (uint32_t s = h & 2047u, p = 0; p < 2048; ++p, s = (s + 1) & 2047u) {
+            const unsigned long long old = atomicCAS(&lkey[s], NONE, k);
+            if (old == NONE) { first_here = true; break; }
+            if (old == k) break;
+        }
+        if (first_here) {                                       // (only a block's first row of a tuple goes to the shared table)
+            for (uint32_t s = (h >> 11) & (SAMPLE_SLOTS - 1), p = 0; p < SAMPLE_SLOTS; ++p, s = (s + 1) & (SAMPLE_SLOTS - 1)) {
+                const unsigned long long old = atomicCAS(&table[s], NONE, k);
+                if (old == NONE) { first_all = true; break; }
+                if (old == k) break;
+            }
+        }
     }
-}
-__global__ void __launch_bounds__(1024) sample_block_distinct_kernel(KeySpec ks /* over the gathered sample */, uint32_t* __restrict__ out) {
-    __shared__ uint64_t key[1024];
-    __shared__ uint32_t cnt;
-    const size_t row = (size_t)blockIdx.x * 8 * 1024 + threadIdx.x;            // (every eighth block of the sample: an estimate of an estimate)
-    const uint64_t k = ks.wide ? (uint64_t)hash_wide(ks, row) : pack_key(ks, row);      // (wide tuples by their 32-bit hash: 1024 rows, an estimate)
-    key[threadIdx.x] = k;
-    if (threadIdx.x == 0) cnt = 0;
+    const uint64_t mh = __ballot(first_here), ma = __ballot(first_all);
+    if (lane_id() == 0) { atomicAdd(&cnt[0], (uint32_t)__popcll(ma)); atomicAdd(&cnt[1], (uint32_t)__popcll(mh)); }
     __syncthreads();
-    bool first = true;
-    for (uint32_t j = 0; j < threadIdx.x && first; ++j) first = key[j] != k;  // (a wavefront reads one address at a time: broadcasts)
-    const uint64_t m = __ballot(first);
-    if (lane_id() == 0) atomicAdd(&cnt, (uint32_t)__popcll(m));
-    __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, cnt);
+    if (threadIdx.x < 2 && cnt[threadIdx.x]) atomicAdd(&out[threadIdx.x], cnt[threadIdx.x]);
 }
 uint64_t estimate_groups(aqg_ctx* ctx, const KeySpec& ks, uint32_t n) {
-    const uint32_t s = 1u << 20;
-    Plan none;
-    memset(&none, 0, sizeof none);
-    // the gathered sample (its own allocation: the group-by below owns the workspace arena)
-    size_t need = 64;
-    for (int c = 0; c < ks.nkeys; ++c) need += ((size_t)s * aqg_dtype_size(ks.dt[c]) + 15) & ~(size_t)15;
+    const uint32_t s = SAMPLE_ROWS;
+    const size_t need = (size_t)SAMPLE_SLOTS * 8 + 64;
     void* buf = nullptr;
     size_t cap = 0;
     buf = aqg_pool_take(ctx, need, &cap);
     if (!buf) { if (hipMalloc(&buf, need) != hipSuccess) { (void)hipGetLastError(); return 0; } cap = need; }
-    KeySpec sk = ks;
-    size_t off = 0;
-    for (int c = 0; c < ks.nkeys; ++c) {
-        const int esz = (int)aqg_dtype_size(ks.dt[c]);
-        void* dst = static_cast<char*>(buf) + off;
-        hipLaunchKernelGGL(sample_gather_kernel, dim3(s / 256), dim3(256), 0, ctx->stream, ks.col[c], esz, n, dst);
-        sk.col[c] = dst;
-        off += ((size_t)s * esz + 15) & ~(size_t)15;
+    unsigned long long* table = static_cast<unsigned long long*>(buf);
+    uint32_t* dout = reinterpret_cast<uint32_t*>(static_cast<char*>(buf) + (size_t)SAMPLE_SLOTS * 8);
+    uint32_t got[4] = {0, 0, 0, 0};
+    bool ok = hipMemsetAsync(table, 0xFF, (size_t)SAMPLE_SLOTS * 8, ctx->stream) == hipSuccess && hipMemsetAsync(dout, 0, 16, ctx->stream) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(sample_distinct_kernel, dim3(1024), dim3(1024), 0, ctx->stream, ks, n, table, dout);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(got, dout, 16, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
     }
-    uint32_t* d2 = reinterpret_cast<uint32_t*>(static_cast<char*>(buf) + off);
-    (void)hipMemsetAsync(d2, 0, 4, ctx->stream);
-    hipLaunchKernelGGL(sample_block_distinct_kernel, dim3(128), dim3(1024), 0, ctx->stream, sk, d2);
-    uint32_t D2 = 0;
-    bool ok = hipMemcpyAsync(&D2, d2, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
-    D2 *= 8;
-    aqg_groupby* tmp = new aqg_groupby();
-    tmp->ctx = ctx; tmp->n = s; tmp->count_only = true;
     uint64_t est = 0;
-    // (sized for a sample of all-distinct tuples at once: from 4096 up the attempts overflowed twice before the HBM table took 2 ms for the 2^20 rows)
-    if (ok && run_with_retry(ctx, sk, none, s, s, false, tmp, nullptr, nullptr) == AQG_OK && hipStreamSynchronize(ctx->stream) == hipSuccess) {
-        const double d = (double)tmp->ngroups, sd = (double)s;
+    if (ok) {
+        const double d = (double)got[0] + (got[2] ? 1.0 : 0.0), sd = (double)s, D2 = (double)got[1] + (got[2] ? 1.0 : 0.0);
         if (d <= 0.5 * sd) est = (uint64_t)(d * 1.25) + 64;                 // the sample has seen (nearly) every group
         else if (d >= 0.999 * sd) est = n;                                  // (nearly) all distinct
         else {
@@ -1778,13 +1777,12 @@ uint64_t estimate_groups(aqg_ctx* ctx, const KeySpec& ks, uint32_t n) {
             for (int it = 0; it < 60; ++it) { double g = 0.5 * (lo + hi); if (g * (1.0 - exp(-sd / g)) < d) lo = g; else hi = g; }
             est = (uint64_t)(hi * 1.25) + 64;
         }
-        if (D2 && d >= 0.8 * (double)D2 && (double)D2 <= 0.9 * sd) {        // clustered keys: blocks share (nearly) no tuples, rows repeat inside them
+        if (D2 > 0 && d >= 0.8 * D2 && D2 <= 0.9 * sd) {                    // clustered keys: blocks share (nearly) no tuples, rows repeat inside them
             const uint64_t clustered = (uint64_t)(d * ((double)n / sd) * 1.1) + 64;
             if (clustered > est) est = clustered;
         }
         if (est > n) est = n;
     }
-    aqg_groupby_destroy(tmp);
     aqg_pool_give(ctx, buf, cap);
     return est;
 }

@@ -39,7 +39,6 @@ struct aqg_groupby {
     void* norm_buf[2 * MAXKEYS] = {nullptr};
     size_t cap_norm[2 * MAXKEYS] = {0};
     bool build_assigned = false;                // the last build took a partition plan: reversemap and counts are already written
-    bool count_only = false;                    // estimate_groups: the call ends once the number of groups is known (no first rows, ranks, output columns)
     bool no_lookup_build = false;               // a key outside the sampled domain met the look-up build: the routed form from now on
     bool no_sorted_tail = false;                // the ordering tail met a partition outside its plan: the bitmap tail from now on
     bool no_pack = false;                       // a value column did not keep to the sampled range of its field in the key word: unpacked planes from now on
