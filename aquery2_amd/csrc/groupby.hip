@@ -1325,6 +1325,9 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks_in, const Plan& plan_in, uint32_t n,
     const uint32_t p1_bins = parts && parts <= p1_max && parts <= AQG_P1_MAXBINS ? parts : 0;
     const uint32_t p2_parts = parts && !p1_bins && parts <= AQG_P2_MAXPARTS ? parts : 0;
     // tuples wider than 8 bytes with many groups (h2o Q10): hash-partitioned rows, every partition grouped inside LDS
+    // every row its own group out of a partition plan: the result can be written from the input rows (emit_rows_kernel below) -- when nobody asks for the table itself
+    static const bool rows_off = getenv("AQG_DISABLE_ROW_EMIT") != nullptr;                 // A/B measurements only
+    const bool rows_possible = !rows_off && n >= (1u << 16) && !for_build && !plan.sj && !gt_out && !slot_gid_out && !occ_out;
     const bool use_wpart = !part_off && !p1_off && !dense && !use_lds && ks.wide && !for_build && !plan.sj && n >= (1u << 20) && hint > (1u << 20) && as.nacc <= 4 &&
                            !h->no_wide_part && aqg_partitionw_applies(ks, as, n, hint);
     if (use_wpart) gcap = (uint32_t)((uint64_t)hint + hint / 4 + 4096 > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : (uint64_t)hint + hint / 4 + 4096);
@@ -1461,7 +1464,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks_in, const Plan& plan_in, uint32_t n,
         h->plan_bits = (use_wpart ? AQG_PLAN_PART_WIDE : p1_bins ? AQG_PLAN_PART_ONE : p2_parts ? AQG_PLAN_PART_TWO : AQG_PLAN_PART_ROUND1) | (sorted_tail ? AQG_PLAN_SORTED_TAIL : 0u);
         if (use_wpart) {
             int pack = h->no_pack ? 0 : 1;
-            AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed, hint, &pack, &h->wide_rows));
+            AQG_TRY(aqg_partitionw_aggregate(ctx, ks, as, n, plan.need_count, gt, gcap, h->wide_seed, hint, &pack, &h->wide_rows, rows_possible));
             if (pack) h->plan_bits |= AQG_PLAN_PACKED_KEYS;
         }
         else if (p1_bins) {
@@ -1580,8 +1583,7 @@ int run_agg(aqg_ctx* ctx, const KeySpec& ks_in, const Plan& plan_in, uint32_t n,
         AQG_TRY(aqg_check_launch(ctx, "first_rows_kernel"));
     }
     // every row its own group: the result is a map of the input (emit_rows_kernel) -- nothing to rank or order
-    static const bool rows_off = getenv("AQG_DISABLE_ROW_EMIT") != nullptr;                 // A/B measurements only
-    const bool row_emit = !rows_off && !defer && G == n && n >= (1u << 16) && (use_part || use_wpart) && !for_build && !plan.sj && !gt_out && !slot_gid_out && !occ_out;
+    const bool row_emit = rows_possible && !defer && G == n && (use_part || use_wpart);
     SortedParts sparts;
     if (row_emit) {
         h->plan_bits |= AQG_PLAN_ROW_EMIT;

@@ -783,7 +783,7 @@ constexpr uint32_t WEMPTY = 0xFFFFu, WEMPTY32 = 0xFFFFFFFFu;
 // sizes a partition for three workgroups of 512 threads where the level structure allows it (pw_plan).
 template <int NACC, int NT>
 __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in, AccSpec as, AggOps ops, const uint32_t* __restrict__ pstart, uint32_t nparts, uint32_t ntotal,
-                                                                        uint32_t R, int need_count, GTable out, uint32_t out_cap) {
+                                                                        uint32_t R, int need_count, GTable out, uint32_t out_cap, uint8_t* __restrict__ dmark, uint32_t* __restrict__ dcount, int mode, int lazy_vals) {
     constexpr int RPT = 3;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     uint64_t* lacc = reinterpret_cast<uint64_t*>(smem_raw);                    // [NACC][R]
@@ -799,6 +799,8 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
         const uint32_t m = e - b;
         if (!m) continue;
         if (m > R) { if (threadIdx.x == 0) { out.flags[0] = 1; out.flags[4] = part; out.flags[5] = m; } continue; }   // a partition larger than LDS holds: the host falls back (flags 4, 5: which, how large)
+        if (mode == 2 && !dmark[part]) continue;                                // second launch: only the partitions the first one put off
+        const bool lazy = mode == 1 && lazy_vals;
         uint32_t myrow[RPT];
         uint64_t myval[NACC > 0 ? NACC : 1][RPT];
 #pragma unroll
@@ -811,11 +813,12 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
                 uint32_t kv[2 * MAXKEYS];
                 _Pragma("unroll") for (int k = 0; k < 2 * MAXKEYS; ++k) if (k < in.nkd) kv[k] = in.kplane[k][b + i];
                 _Pragma("unroll") for (int k = 0; k < 2 * MAXKEYS; ++k) if (k < in.nkd) lkey[(size_t)k * R + i] = kv[k];
-                myrow[q] = in.rows[b + i];
-                lfirst[i] = NOROW; lcount[i] = 0;
-                _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
-                    lacc[(size_t)a * R + i] = acc_init(as.kind[a]);
-                    myval[a][q] = !in.vcol[a] ? (uint64_t)myrow[q] : in.vesz[a] == 4 ? (uint64_t)static_cast<const uint32_t*>(in.vcol[a])[b + i] : static_cast<const uint64_t*>(in.vcol[a])[b + i];
+                if (!lazy) {
+                    lfirst[i] = NOROW; lcount[i] = 0;
+                    _Pragma("unroll") for (int a = 0; a < NACC; ++a) lacc[(size_t)a * R + i] = acc_init(as.kind[a]);
+                    myrow[q] = in.rows[b + i];
+                    _Pragma("unroll") for (int a = 0; a < NACC; ++a)
+                        myval[a][q] = !in.vcol[a] ? (uint64_t)myrow[q] : in.vesz[a] == 4 ? (uint64_t)static_cast<const uint32_t*>(in.vcol[a])[b + i] : static_cast<const uint64_t*>(in.vcol[a])[b + i];
                 }
             }
         }
@@ -823,6 +826,7 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
         if (threadIdx.x == 0) { lemit = 0; ngrp = 0; }
         __syncthreads();
         // representative of every row: the first row index that claimed the slot of an equal tuple
+        uint32_t mine = 0;
         for (uint32_t i = threadIdx.x; i < m; i += NT) {
             uint32_t h = 0x9E3779B1u;
             for (int k = 0; k < in.nkd; ++k) h = (h ^ lkey[(size_t)k * R + i]) * 0x85EBCA6Bu;
@@ -840,15 +844,39 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
                 s = s + 1 == T ? 0 : s + 1;
             }
             rep[i] = (uint16_t)r;
+            mine += r == i;                                                     // groups = rows that represent themselves
         }
+        mine = wave_reduce(mine, OpAdd{});
+        if (lane_id() == 0 && mine) atomicAdd(&ngrp, mine);
         __syncthreads();
-        uint32_t mine = 0;
+        // mode 1 (the caller can emit straight from the input rows when EVERY row turns out to be its own group -- h2o Q10, any grouping by a
+        // unique key): a partition of distinct rows is put off -- marked and counted, nothing accumulated, no records written (32 of the
+        // 56 bytes per row this kernel moves).  All partitions put off: the records were never needed.  Otherwise the host launches mode 2
+        // over the marked ones.
+        if (mode == 1 && ngrp == m) {
+            __syncthreads();                                                    // (everybody has read ngrp: the next partition may clear it)
+            if (threadIdx.x == 0) { dmark[part] = 1; atomicAdd(dcount, m); }
+            continue;
+        }
+        if (lazy) {                                                             // (the rows are expected to be distinct: ids and values only now, for the partition that has a duplicate)
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const uint32_t i = threadIdx.x + q * NT;
+                if (i >= m) continue;
+                myrow[q] = in.rows[b + i];
+                lfirst[i] = NOROW; lcount[i] = 0;
+                _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
+                    lacc[(size_t)a * R + i] = acc_init(as.kind[a]);
+                    myval[a][q] = !in.vcol[a] ? (uint64_t)myrow[q] : in.vesz[a] == 4 ? (uint64_t)static_cast<const uint32_t*>(in.vcol[a])[b + i] : static_cast<const uint64_t*>(in.vcol[a])[b + i];
+                }
+            }
+            __syncthreads();                                                    // (the accumulators of all rows are initialised before the first is used)
+        }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const uint32_t i = threadIdx.x + q * NT;
             if (i >= m) continue;
             const uint32_t r = rep[i];
-            mine += r == i;                                                     // groups = rows that represent themselves
             atomicMin(&lfirst[r], myrow[q]);
             if (need_count) atomicAdd(&lcount[r], 1u);
             _Pragma("unroll") for (int a = 0; a < NACC; ++a) {
@@ -863,8 +891,6 @@ __global__ void __launch_bounds__(NT, NT == 512 ? 6 : 4) pw_agg_kernel(WideIn in
                 }
             }
         }
-        mine = wave_reduce(mine, OpAdd{});
-        if (lane_id() == 0 && mine) atomicAdd(&ngrp, mine);
         __syncthreads();
         if (threadIdx.x == 0) gbase = atomicAdd(&out.flags[1], ngrp);
         __syncthreads();
@@ -1331,7 +1357,7 @@ size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n
     size_t per_row = 4 + 2 * (4 + 4 + 4 * (size_t)w.nkd);                    // the hash column; two sets of {hash, row, key dwords}
     for (int k = 0; k < ks.nkeys; ++k) if (aqg_dtype_size(ks.dt[k]) < 4) per_row += 4;       // widened key columns
     for (int u = 0; u < vc.n; ++u) per_row += 2 * part_val_bytes(vc.dt[u]) + (aqg_dtype_size(vc.dt[u]) < 4 ? 4 : 0);
-    return ((size_t)n + 64) * per_row + 256 * (16 + 8 * MAXACC + 8 * MAXKEYS) + ((size_t)w.P + 4096) * 24 + ((size_t)n / P2_PT + (size_t)w.P + 64) * 8 + 65536;
+    return ((size_t)n + 64) * per_row + 256 * (16 + 8 * MAXACC + 8 * MAXKEYS) + ((size_t)w.P + 4096) * 24 + ((size_t)n / P2_PT + (size_t)w.P + 64) * 8 + ((size_t)w.P + 8192) + 65536;   // (… + the put-off marks of pw_agg)
 }
 
 // the packing of wide tuples (PackW): fields by first fit, widest first; worth it when a third of the dword planes goes
@@ -1382,7 +1408,7 @@ static bool plan_packw(aqg_ctx* ctx, const KeySpec& ks, uint32_t n, PackW* pk, i
     return true;
 }
 
-int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap, uint32_t seed, uint32_t hint, int* pack, uint32_t* rows_out) {
+int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap, uint32_t seed, uint32_t hint, int* pack, uint32_t* rows_out, bool may_defer) {
     WidePlan w = pw_plan(ks, as, n, hint);
     if (!w.ok) return aqg_fail(ctx, AQG_ERR_OVERFLOW, "wide-tuple partitioned group-by: the input does not fit 128 x 128 x 128 partitions");
     ValCols vc;
@@ -1548,12 +1574,35 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     if (per_cu > 2048u / (unsigned)w.nt) per_cu = 2048u / (unsigned)w.nt;
     if (per_cu < 1) per_cu = 1;
     const unsigned grid = nseg < per_cu * (unsigned)ctx->num_cu ? nseg : per_cu * (unsigned)ctx->num_cu;
+    static const bool defer_off = getenv("AQG_DISABLE_PW_DEFER") != nullptr;                // A/B measurements only
+    if (defer_off) may_defer = false;
+    uint32_t* dwords = nullptr;                                                            // [0] rows of the partitions put off | marks, a byte per partition
+    if (may_defer) {
+        AQG_TRY(aqg_ws_get(ctx, (size_t)nseg / 4 + 8, &dwords));
+        AQG_HIP(ctx, hipMemsetAsync(dwords, 0, ((size_t)nseg / 4 + 8) * 4, ctx->stream));
+    }
+    uint8_t* dmark = may_defer ? reinterpret_cast<uint8_t*>(dwords + 4) : nullptr;
+    const int lazy_vals = may_defer && (uint64_t)hint * 10 >= (uint64_t)n * 9 ? 1 : 0;     // nearly as many groups expected as rows: row ids and values are read only where a partition has a duplicate
     auto launch = [&](auto kern) -> int {
         AQG_TRY(aqg_allow_lds(ctx, reinterpret_cast<const void*>(kern), lds));
         aqg_kernel_timer_begin(ctx);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(w.nt), lds, ctx->stream, in, as, ops, (const uint32_t*)seg, nseg, n, w.R, need_count, out, out_cap);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(w.nt), lds, ctx->stream, in, as, ops, (const uint32_t*)seg, nseg, n, w.R, need_count, out, out_cap, dmark, dwords, may_defer ? 1 : 0, lazy_vals);
         aqg_kernel_timer_end(ctx);
-        return aqg_check_launch(ctx, "pw_agg_kernel");
+        AQG_TRY(aqg_check_launch(ctx, "pw_agg_kernel"));
+        if (!may_defer) return AQG_OK;
+        // every row its own group?  (one host round trip on a call of tens of milliseconds)
+        uint32_t fl[2] = {0, 0}, put_off = 0;
+        AQG_HIP(ctx, hipMemcpyAsync(fl, out.flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipMemcpyAsync(&put_off, dwords, 4, hipMemcpyDeviceToHost, ctx->stream));
+        AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (fl[0] || !put_off) return AQG_OK;                                               // (an overflow is the caller's to judge)
+        if ((uint64_t)fl[1] + put_off == n) {                                               // yes: the caller emits from the rows, the record table is not read
+            AQG_HIP(ctx, hipMemcpyAsync(out.flags + 1, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+            AQG_HIP(ctx, hipStreamSynchronize(ctx->stream));                                // (`n` lives on this stack frame)
+            return AQG_OK;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(w.nt), lds, ctx->stream, in, as, ops, (const uint32_t*)seg, nseg, n, w.R, need_count, out, out_cap, dmark, dwords, 2, 0);
+        return aqg_check_launch(ctx, "pw_agg_kernel (partitions put off)");
     };
     auto pick = [&](auto nacc) -> int {
         constexpr int N = decltype(nacc)::value;

@@ -20,7 +20,7 @@ size_t aqg_partition_assign_ws_bytes(uint32_t n);
 bool aqg_partitionw_applies(const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t hint);
 uint32_t aqg_partitionw_rows(const KeySpec& ks, const AccSpec& as, uint32_t n, uint32_t hint);      // rows one partition may hold
 size_t aqg_partitionw_ws_bytes(const aqg_ctx* ctx, const KeySpec& ks, uint32_t n, const AccSpec& as, uint32_t hint);
-int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap, uint32_t seed, uint32_t hint, int* pack = nullptr, uint32_t* rows_out = nullptr);   // *pack: in, key packing allowed; out, the key columns travelled packed; *rows_out: rows one partition may hold
+int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as, uint32_t n, int need_count, GTable out, uint32_t out_cap, uint32_t seed, uint32_t hint, int* pack = nullptr, uint32_t* rows_out = nullptr, bool may_defer = false);   // *pack: in, key packing allowed; out, the key columns travelled packed; *rows_out: rows one partition may hold
 // ordering a huge group table (more than ~1.6e7 groups): the record planes partitioned by first row with the tile scatter (order-preserving
 // bins, up to three levels) until a partition's row interval fits LDS; sorted_emit_kernel (groupby.hip) ranks and emits from there
 struct SortedPlan { uint32_t levels, bits, M, cap; size_t lds; };    // cap: rows (so records at most) of one partition

@@ -193,6 +193,27 @@ def test_wide_tuple_partition_plan_with_and_without_the_ordering_tail():
     run_forced({"AQG_SORTED_TAIL_MIN": "1"}, WIDE % "capi.PLAN_PART_WIDE | capi.PLAN_SORTED_TAIL")
 
 
+NEARLY = r"""
+n = 2_700_017
+r = rng.permutation(n)                                          # every row its own 16-byte tuple ...
+r[rng.integers(0, n, 4000)] = r[rng.integers(0, n, 4000)]      # ... except ~4000 rows that repeat another row's
+ids = [(r % 1000).astype(np.int32), (r // 1000).astype(np.int32), np.zeros(n, np.int32), (r % 7).astype(np.int32)]
+v1, v3 = rng.integers(-9, 10, n).astype(np.int32), np.round(rng.uniform(0, 100, n), 3).astype(np.float32)
+W = capi.PLAN_PART_WIDE
+check(ids, [ck.RED_SUM, ck.RED_COUNT, ck.RED_MAX], [v3, v1, v1], n, W)                 # hint ~ rows: ids and values are read only where a partition has a duplicate
+check(ids, [ck.RED_SUM, ck.RED_COUNT, ck.RED_MIN], [v1, v1, v3], 1_700_000, W)         # a hint well below the rows: everything loaded up front
+"""
+
+
+def test_wide_tuples_nearly_all_distinct_put_off_their_distinct_partitions():
+    """pw_agg when the caller could emit from the input rows (every row its own group): a partition of distinct rows is marked and counted, nothing
+    accumulated or written; here ~4000 of 2.7e6 rows repeat another row, so most partitions are put off, G != n, and the second launch (mode 2)
+    aggregates exactly the marked ones -- against the oracle, with and without the late loads of row ids and values; and the same with
+    AQG_DISABLE_PW_DEFER=1 (one launch over everything)"""
+    run_forced({}, NEARLY)
+    run_forced({"AQG_DISABLE_PW_DEFER": "1"}, NEARLY)
+
+
 WIDEPACK = r"""
 n = 4_400_021                                                  # (key packing is planned from 2^22 rows on)
 r = rng.integers(0, 1_900_000, n)                              # ~2.3 rows per tuple
