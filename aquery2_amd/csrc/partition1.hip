@@ -657,10 +657,17 @@ __device__ inline uint32_t pw_hash_row(const uint32_t* k, int nk, uint32_t seed)
 // through pw_agg's LDS; tuple equality on the packed planes IS tuple equality (the map is injective on verified rows), and the result's
 // key columns are fetched through the groups' first rows as before.
 struct PackW { int nout; uint32_t min[MAXKEYS], mask[MAXKEYS]; int word[MAXKEYS], shift[MAXKEYS]; uint32_t* out[4]; uint32_t* flag; };
+// The pass also counts the bins of the FIRST partition level (lc.cnt: <= 128 bins, counted in LDS, flushed with one atomic per bin and workgroup):
+// the hash is in a register here, and pn_level_hist read the whole hash plane again for it (1.1 ms per 1e9 rows).
+struct Level1Count { uint32_t* cnt; uint32_t P, shift; };
+__device__ inline uint32_t pw_level1_bin(uint32_t h, const Level1Count& lc) { return __umulhi(key_hash<false>(h), lc.P) >> lc.shift; }
 template <bool PACKW>
-__global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, uint32_t seed, uint32_t* __restrict__ out, PackW pk) {
+__global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, uint32_t seed, uint32_t* __restrict__ out, PackW pk, Level1Count lc) {
     const uint32_t nchunk = n >> 2;
     uint32_t bad = 0;
+    __shared__ uint32_t lbin[128];
+    if (threadIdx.x < 128) lbin[threadIdx.x] = 0;
+    __syncthreads();
     for (uint32_t c = blockIdx.x * 256 + threadIdx.x; c < nchunk; c += gridDim.x * 256) {
         pack<uint32_t, 4> v[MAXKEYS];
 #pragma unroll
@@ -678,6 +685,8 @@ __global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, u
 #pragma unroll
         for (int j = 0; j < 4; ++j) h.v[j] = pw_fin32(a.v[j] ^ pw_fin32(b.v[j]));
         *reinterpret_cast<pack<uint32_t, 4>*>(out + (size_t)c * 4) = h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(&lbin[pw_level1_bin(h.v[j], lc) & 127u], 1u);
         if constexpr (PACKW) {
 #pragma unroll
             for (int k = 0; k < MAXKEYS; ++k) {
@@ -709,6 +718,7 @@ __global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, u
         uint32_t k[MAXKEYS];
         for (int j = 0; j < ks.n; ++j) k[j] = ks.col[j][i];
         out[i] = pw_hash_row(k, ks.n, seed);
+        atomicAdd(&lbin[pw_level1_bin(out[i], lc) & 127u], 1u);
         if constexpr (PACKW) {
             for (int o = 0; o < pk.nout; ++o) {
                 uint32_t w = 0;
@@ -717,6 +727,8 @@ __global__ void __launch_bounds__(256) pw_hash32_kernel(Keys32 ks, uint32_t n, u
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x < 128 && lbin[threadIdx.x]) atomicAdd(&lc.cnt[threadIdx.x], lbin[threadIdx.x]);
     if constexpr (PACKW) { if (bad) *pk.flag = 1u; }
 }
 __global__ void __launch_bounds__(256) pn_gather_strided_kernel(const uint32_t* __restrict__ src, uint32_t stride, uint32_t count, uint32_t* __restrict__ dst) {
@@ -1418,7 +1430,9 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
     uint32_t* h32;
     AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &h32));
     PackW pk;
-    bool packed = false;
+    bool packed = false, level1_counted = false;
+    uint32_t *seg = nullptr, *tp = nullptr, *cnt = nullptr, *cur = nullptr, *bsum = nullptr;
+    size_t maxseg = 0;
     {
         Keys32 k32;
         memset(&k32, 0, sizeof k32);
@@ -1435,19 +1449,31 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
             packed = plan_packw(ctx, ks, n, &pk, &err);
             AQG_TRY(err);
         }
+        if (packed) {                                     // fewer key dwords per row: more rows per partition, fewer partitions (the workspace was sized for the unpacked plan: more of each)
+            const WidePlan wp = pw_plan(ks, as, n, hint, pk.nout);
+            if (wp.ok && wp.P <= w.P) w = wp;
+        }
+        // level bookkeeping (segments of level l = the bins of level l - 1); the 32-bit hash passes count the first level's bins themselves
+        maxseg = (size_t)w.P + 2;
+        AQG_TRY(aqg_ws_get(ctx, maxseg, &seg));
+        AQG_TRY(aqg_ws_get(ctx, maxseg, &tp));
+        AQG_TRY(aqg_ws_get(ctx, maxseg, &cnt));
+        AQG_TRY(aqg_ws_get(ctx, maxseg, &cur));
+        AQG_TRY(aqg_ws_get(ctx, maxseg / 2048 + 64, &bsum));
+        uint32_t shift1 = 0;
+        for (int j = 1; j < w.L; ++j) shift1 += (uint32_t)w.low[j - 1];
+        const Level1Count lc{cnt, w.P, shift1};
+        level1_counted = all32 && !generic_hash && w.B1 <= 128;
+        if (level1_counted) AQG_HIP(ctx, hipMemsetAsync(cnt, 0, ((size_t)w.B1 + 1) * 4, ctx->stream));
         if (packed) {
             for (int o = 0; o < pk.nout; ++o) AQG_TRY(aqg_ws_get(ctx, (size_t)n + 64, &pk.out[o]));
             pk.flag = out.flags + 6;
-            hipLaunchKernelGGL(pw_hash32_kernel<true>, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 16)), dim3(256), 0, ctx->stream, k32, n, seed, h32, pk);
+            hipLaunchKernelGGL(pw_hash32_kernel<true>, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 16)), dim3(256), 0, ctx->stream, k32, n, seed, h32, pk, lc);
         }
-        else if (all32 && !generic_hash) hipLaunchKernelGGL(pw_hash32_kernel<false>, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 16)), dim3(256), 0, ctx->stream, k32, n, seed, h32, pk);
+        else if (all32 && !generic_hash) hipLaunchKernelGGL(pw_hash32_kernel<false>, dim3(aqg_grid(ctx, n / 4 + 1, 256, 2, 16)), dim3(256), 0, ctx->stream, k32, n, seed, h32, pk, lc);
         else hipLaunchKernelGGL(pw_hash_kernel, dim3(g4), dim3(256), 0, ctx->stream, ks, n, seed, h32);
     }
     if (pack) *pack = packed ? 1 : 0;
-    if (packed) {                                         // fewer key dwords per row: more rows per partition, fewer partitions (the workspace was sized for the unpacked plan: more of each)
-        const WidePlan wp = pw_plan(ks, as, n, hint, pk.nout);
-        if (wp.ok && wp.P <= w.P) w = wp;
-    }
     if (rows_out) *rows_out = w.R;
     const int nkd = packed ? pk.nout : w.nkd;             // key dword planes that travel
     // source planes: the key columns as dwords (1- / 2-byte ones widened, 8-byte ones as two planes), then the distinct value columns
@@ -1507,14 +1533,6 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         return pl;
     };
     if (2 + nkd + 2 * vc.n > MAXPL) return aqg_fail(ctx, AQG_ERR_ARG, "wide-tuple partitioned group-by: too many planes");
-    // level bookkeeping: segments of level l = the bins of level l - 1
-    uint32_t *seg, *tp, *cnt, *cur, *bsum;
-    const size_t maxseg = (size_t)w.P + 2;
-    AQG_TRY(aqg_ws_get(ctx, maxseg, &seg));
-    AQG_TRY(aqg_ws_get(ctx, maxseg, &tp));
-    AQG_TRY(aqg_ws_get(ctx, maxseg, &cnt));
-    AQG_TRY(aqg_ws_get(ctx, maxseg, &cur));
-    AQG_TRY(aqg_ws_get(ctx, maxseg / 2048 + 64, &bsum));
     const uint32_t h0[2] = {0u, n};
     void* st = nullptr;
     AQG_TRY(aqg_host_stage(ctx, 16, &st));
@@ -1533,9 +1551,11 @@ int aqg_partitionw_aggregate(aqg_ctx* ctx, const KeySpec& ks, const AccSpec& as,
         const uint32_t* keys = l == 1 ? h32 : from->hash;
         const unsigned tiles = (unsigned)((uint64_t)n / P2_PT) + nseg + 1;
         hipLaunchKernelGGL(pn_tiles_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)seg, nseg, (uint32_t)P2_PT, tp);
-        AQG_HIP(ctx, hipMemsetAsync(cnt, 0, ((size_t)nseg * nb + 1) * 4, ctx->stream));
         P2Level lv{seg, tp, cur, nseg, w.P, shift, mask, nb, nb};
-        hipLaunchKernelGGL((pn_level_hist_kernel<P2_TB, P2_TR, true>), dim3(tiles), dim3(P2_TB), 0, ctx->stream, keys, lv, cnt);
+        if (!(l == 1 && level1_counted)) {
+            AQG_HIP(ctx, hipMemsetAsync(cnt, 0, ((size_t)nseg * nb + 1) * 4, ctx->stream));
+            hipLaunchKernelGGL((pn_level_hist_kernel<P2_TB, P2_TR, true>), dim3(tiles), dim3(P2_TB), 0, ctx->stream, keys, lv, cnt);
+        }
         AQG_TRY(aqg_exclusive_scan_u32(ctx, cnt, (uint64_t)nseg * nb + 1, bsum));        // cnt[i] = start of (segment, bin) i; the last word = n
         AQG_HIP(ctx, hipMemcpyAsync(cur, cnt, (size_t)nseg * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
         const Planes pl = planes(l, from, set[to]);
