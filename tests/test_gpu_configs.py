@@ -210,7 +210,7 @@ def test_h2o_q5_q3_q7_at_the_full_1e9_rows(gpu):
     want = capi.PLAN_PART_TWO | capi.PLAN_PACKED_VALUES | capi.PLAN_RANGE_PARTITIONS
     # Q5: sum(v1), sum(v2), sum(v3), count BY id6
     gb = gpu.groupby_agg([id6], [ck.RED_SUM, ck.RED_SUM, ck.RED_SUM, ck.RED_COUNT], [v1, v2, v3, v1], hint=n // K + 1024)
-    assert gb.plan == want, gb.plan
+    assert gb.plan & ~capi.PLAN_SORTED_TAIL == want, gb.plan      # (tools/fuzz_more.sh forces the ordering tail onto every partition plan)
     G = gb.ngroups
     assert 0.999 * (n // K) < G <= n // K
     keys = gb.keys(0, np.int32)
@@ -228,13 +228,13 @@ def test_h2o_q5_q3_q7_at_the_full_1e9_rows(gpu):
     gb.destroy()
     # Q3: sum(v1), avg(v3) BY id3 -- avg against the sums of Q5's kind
     gb = gpu.groupby_agg([id3], [ck.RED_SUM, ck.RED_AVG, ck.RED_SUM, ck.RED_COUNT], [v1, v3, v3, v3], hint=n // K + 1024)
-    assert gb.plan == want, gb.plan
+    assert gb.plan & ~capi.PLAN_SORTED_TAIL == want, gb.plan      # (tools/fuzz_more.sh forces the ordering tail onto every partition plan)
     avg, s3, cnt = gb.result(1, ck.RED_AVG, ck.FLOAT), gb.result(2, ck.RED_SUM, ck.FLOAT), gb.result(3, ck.RED_COUNT, ck.FLOAT)
     assert np.array_equal(avg, s3 / cnt.astype(np.float64)) and int(cnt.sum()) == n
     gb.destroy()
     # Q7: max(v1), min(v2) BY id3 -- no value plane at all
     gb = gpu.groupby_agg([id3], [ck.RED_MAX, ck.RED_MIN], [v1, v2], hint=n // K + 1024)
-    assert gb.plan == want, gb.plan
+    assert gb.plan & ~capi.PLAN_SORTED_TAIL == want, gb.plan      # (tools/fuzz_more.sh forces the ordering tail onto every partition plan)
     mx, mn = gb.result(0, ck.RED_MAX, ck.INT32), gb.result(1, ck.RED_MIN, ck.INT32)
     assert mx.max() == int(gpu.reduce(ck.RED_MAX, v1)) and mx.min() >= int(gpu.reduce(ck.RED_MIN, v1))
     assert mn.min() == int(gpu.reduce(ck.RED_MIN, v2)) and mn.max() <= int(gpu.reduce(ck.RED_MAX, v2))
